@@ -1,0 +1,141 @@
+"""CPU tests: pin the oracle (our C restatement, and the compiled reference when present)
+to the golden vectors generated from the reference (oracle/gen_golden.py)."""
+import hashlib
+
+import pytest
+
+from util import P, R, cat, golden
+
+
+@pytest.fixture(params=["port", "reference"])
+def orc(request, oracle_port):
+    if request.param == "port":
+        return oracle_port
+    return request.getfixturevalue("oracle_ref")
+
+
+def test_anchor_values(orc):
+    # SURVEY.md §8(c) anchors captured from the compiled reference
+    g1 = orc.g1_generator()
+    assert orc.g1_compress(g1).hex() == ("0317f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac58"
+                                         "6c55e83ff97a1aeffb3af00adb22c6bb")
+    g2c = orc.g2_compress(orc.g2_generator())
+    assert hashlib.sha256(g2c).hexdigest() == "db334b743fa2679e10f00105e29074a4a3a34fda7e4d3e5cbc790e145c07df68"
+    gt = orc.pair(g1, orc.g2_generator())
+    assert gt.hex().startswith("0f41e58663bf08cf068672cbd01a7ec7")
+    assert hashlib.sha256(gt).hexdigest() == "8d47ab0b1283a6346b774d68d578b1c29b8e9e922e1105eca27a7126b4a6676b"
+
+
+def test_fp_golden(orc):
+    g = golden("fp")
+    a, b = cat(g["a"]), cat(g["b"])
+    for op in ("mul", "add", "sub", "sqr", "neg", "inv"):
+        out, _ = orc.fp_op(op, a, b)
+        assert out == cat(g[op]), op
+    out, ok = orc.fp_op("sqrt", a, b)
+    assert list(ok) == g["sqrt_is_qr"]
+    for i, q in enumerate(ok):
+        if q:
+            s = int.from_bytes(out[48 * i:48 * i + 48], "big")
+            assert (s * s - int(g["a"][i], 16)) % P == 0
+
+
+def test_fp_against_python_ints(orc):
+    g = golden("fp")
+    a, b = cat(g["a"]), cat(g["b"])
+    out, _ = orc.fp_op("mul", a, b)
+    for i in range(len(g["a"])):
+        assert int.from_bytes(out[48 * i:48 * i + 48], "big") == int(g["a"][i], 16) * int(g["b"][i], 16) % P
+
+
+def test_g1_golden(orc):
+    g = golden("g1")
+    pts, sc = cat(g["points"]), cat(g["scalars"])
+    assert orc.g1_mul(pts, sc, 49) == cat(g["mul49"])
+    assert orc.g1_mul(pts, sc, 96, nthreads=3) == cat(g["mul96"])
+    assert orc.g1_add(cat(g["add_a"]), cat(g["add_b"]), 96) == cat(g["add96"])
+    assert orc.g1_add(cat(g["add_a"]), cat(g["add_b"]), 49) == cat(g["add49"])
+    dec, st = orc.g1_decompress(cat(g["compressed"]))
+    assert list(st) == g["decompress_status"]
+    assert dec == cat(g["decompressed"])
+    assert orc.g1_msm(pts, sc, 49, 1).hex() == g["msm49"]
+    assert orc.g1_msm(pts, sc, 49, 5).hex() == g["msm49"]
+    assert orc.g1_generator().hex() == g["generator"]
+
+
+def test_g1_edge_semantics(orc):
+    """Edge cases the reference's unit tests pin as laws (unit-tests/g1_point.cpp:51-78)."""
+    g = golden("g1")
+    p0 = bytes.fromhex(g["points"][0])
+    inf = bytes(96)
+    k = lambda v: (v % (1 << 256)).to_bytes(32, "big")
+    assert orc.g1_mul(p0, k(0), 96) == inf                      # scalar 0 -> identity
+    assert orc.g1_mul(p0, k(R), 96) == inf                      # scalar = r -> identity
+    assert orc.g1_mul(p0, k(1), 96) == p0
+    assert orc.g1_mul(p0, k(R + 1), 96) == p0                   # reduced mod r first
+    assert orc.g1_mul(inf, k(12345), 96) == inf                 # infinity in -> infinity out
+    m = orc.g1_mul(p0, k(R - 1), 96)                            # -P
+    assert orc.g1_add(p0, m, 96) == inf
+    assert orc.g1_compress(inf) == bytes(49)
+
+
+def test_g2_golden(orc):
+    g = golden("g2")
+    pts, sc = cat(g["points"]), cat(g["scalars"])
+    assert orc.g2_mul(pts, sc, 97) == cat(g["mul97"])
+    assert orc.g2_mul(pts, sc, 192, nthreads=2) == cat(g["mul192"])
+    assert orc.g2_add(cat(g["add_a"]), cat(g["add_b"]), 192) == cat(g["add192"])
+    dec, st = orc.g2_decompress(cat(g["compressed"]))
+    assert list(st) == g["decompress_status"]
+    assert dec == cat(g["decompressed"])
+    assert orc.g2_generator().hex() == g["generator"]
+
+
+def test_pairing_golden(orc):
+    g = golden("pairing")
+    g1, g2 = cat(g["g1"]), cat(g["g2"])
+    gt = orc.pair(g1, g2, nthreads=2)
+    assert gt == cat(g["gt"])
+    one = bytes(575) + b"\x01"
+    # infinity in either argument gives the identity of GT (unit-tests/liner_pair.cpp:28-40)
+    assert gt[576 * 6:576 * 7] != gt[576 * 5:576 * 6]
+    assert orc.pair(bytes(96), g2[:192]) == orc.pair(g1[:96], bytes(192))
+    a1, a2, b1, b2 = g1[:96 * 4], g2[:192 * 4], g1[96 * 4:], g2[192 * 4:]
+    assert orc.pair2(a1, a2, b1, b2) == cat(g["pair2"])
+    assert list(orc.pair_eq(cat(g["eq_a1"]), cat(g["eq_a2"]), cat(g["eq_b1"]), cat(g["eq_b2"]))) == g["eq"]
+    gta, gtb = gt[:576 * 4], gt[576 * 4:]
+    assert orc.gt_op("mul", gta, gtb) == cat(g["gt_mul"])
+    assert orc.gt_op("conj", gta) == cat(g["gt_conj"])
+    assert orc.gt_op("pow", gta, cat(g["gt_pow_exp"])) == cat(g["gt_pow"])
+    del one
+
+
+def test_config1_bilinearity(orc):
+    """BASELINE.json configs[0]: pair(g1^x, g2^y) == pair(g1, g2)^(xy) on the reference's own seed."""
+    g = golden("config1_bilinearity")
+    sc = cat(g["scalars"])
+    x, y = sc[64:96], sc[96:128]
+    Pp, Qq = bytes.fromhex(g["P"]), bytes.fromhex(g["Q"])
+    lhs = orc.pair(orc.g1_mul(Pp, x, 96), orc.g2_mul(Qq, y, 192))
+    assert lhs.hex() == g["pair_Px_Qy"]
+    xy = ((int.from_bytes(x, "big") * int.from_bytes(y, "big")) % R).to_bytes(32, "big")
+    assert xy.hex() == g["xy"]
+    assert orc.gt_op("pow", orc.pair(Pp, Qq), xy) == lhs
+
+
+def test_reference_seeded_scalars(oracle_ref):
+    g = golden("config1_bilinearity")
+    assert oracle_ref.random_scalars(g["seed"].encode(), 4) == cat(g["scalars"])
+
+
+def test_port_matches_reference_on_fresh_inputs(oracle_port, oracle_ref):
+    """Beyond the committed fixtures: fresh seeded inputs, port vs compiled reference."""
+    from util import scalars
+    n = 12
+    g1, g2 = oracle_ref.g1_generator(), oracle_ref.g2_generator()
+    pts = oracle_ref.g1_mul(g1 * n, scalars(901, n), 96)
+    q = oracle_ref.g2_mul(g2 * n, scalars(902, n), 192)
+    sc = scalars(903, n, 1 << 256)
+    assert oracle_port.g1_mul(pts, sc, 49, 2) == oracle_ref.g1_mul(pts, sc, 49, 2)
+    assert oracle_port.g2_mul(q, sc, 97, 2) == oracle_ref.g2_mul(q, sc, 97, 2)
+    assert oracle_port.pair(pts[:96 * 4], q[:192 * 4], 2) == oracle_ref.pair(pts[:96 * 4], q[:192 * 4], 2)
