@@ -1,0 +1,145 @@
+"""ctypes binding of the C ABI in include/c12381_hip.h.
+
+This module is plumbing: it loads the in-tree HIP library and moves bytes.  There is NO CPU
+fallback — if the library is missing or no HIP device is usable, construction fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libc12381_hip.so")
+
+E_ARG, E_HIP, E_POINT, E_NOMEM = -1, -2, -3, -4
+
+
+class C12381Error(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"c12381 error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load_library() -> ctypes.CDLL:
+    """Load libc12381_hip.so (built by crypto12381_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                f"{LIB_PATH} not found: the HIP extension is not built (run `python -m crypto12381_amd.build`). "
+                "There is no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+        lib.c12381_create.argtypes = [ci, ctypes.POINTER(vp)]
+        lib.c12381_destroy.argtypes = [vp]
+        lib.c12381_destroy.restype = None
+        lib.c12381_last_error.argtypes = [vp]
+        lib.c12381_last_error.restype = ctypes.c_char_p
+        lib.c12381_set_stream.argtypes = [vp, vp]
+        lib.c12381_sync.argtypes = [vp]
+        lib.c12381_profile.argtypes = [vp, ci]
+        lib.c12381_profile_read.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
+        for name in ("c12381_fp_op_batch", "c12381_fp_op_batch_dev"):
+            getattr(lib, name).argtypes = [vp, ci, sz, vp, vp, vp]
+        lib.c12381_fp_mulchain_dev.argtypes = [vp, sz, ci, vp, vp, vp]
+        for name in ("c12381_g1_mul_batch", "c12381_g1_mul_batch_dev", "c12381_g1_add_batch", "c12381_g1_msm",
+                     "c12381_g1_msm_dev"):
+            getattr(lib, name).argtypes = [vp, sz, vp, vp, vp, ci]
+        _lib = lib
+    return _lib
+
+
+def _p(b):
+    """bytes / ctypes buffer / int device address -> c_void_p"""
+    if b is None:
+        return None
+    if isinstance(b, int):
+        return ctypes.c_void_p(b)
+    if isinstance(b, (bytes, bytearray)):
+        return ctypes.cast(ctypes.c_char_p(bytes(b)), ctypes.c_void_p)
+    return ctypes.cast(b, ctypes.c_void_p)
+
+
+class Context:
+    """One context per process/GPU (mirrors c12381_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        self.h = ctypes.c_void_p()
+        rc = self.lib.c12381_create(device, ctypes.byref(self.h))
+        if rc != 0:
+            self.h = None
+            raise C12381Error(rc, "c12381_create failed (no usable HIP device?)")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.c12381_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, allow_point=False):
+        if rc == 0 or (allow_point and rc == E_POINT):
+            return rc
+        raise C12381Error(rc, (self.lib.c12381_last_error(self.h) or b"").decode())
+
+    def set_stream(self, hip_stream):
+        self._ck(self.lib.c12381_set_stream(self.h, _p(hip_stream)))
+
+    def sync(self) -> int:
+        return self._ck(self.lib.c12381_sync(self.h), allow_point=True)
+
+    def profile(self, enable: bool):
+        self._ck(self.lib.c12381_profile(self.h, 1 if enable else 0))
+
+    def profile_read(self, kind: int):
+        ms, cnt = ctypes.c_double(), ctypes.c_uint64()
+        self._ck(self.lib.c12381_profile_read(self.h, kind, ctypes.byref(ms), ctypes.byref(cnt)))
+        return ms.value, cnt.value
+
+    # ---- host-buffer entry points (bytes in, bytes out)
+    FP_OPS = {"mul": 0, "add": 1, "sub": 2, "sqr": 3, "neg": 4, "inv": 5}
+
+    def fp_op(self, op: str, a: bytes, b: bytes | None = None) -> bytes:
+        n = len(a) // 48
+        out = ctypes.create_string_buffer(max(48 * n, 1))
+        self._ck(self.lib.c12381_fp_op_batch(self.h, self.FP_OPS[op], n, _p(a), _p(b), _p(out)))
+        return out.raw[:48 * n]
+
+    def g1_mul(self, pts: bytes, scalars: bytes, fmt: int = 49, strict: bool = True) -> bytes:
+        n = len(pts) // 96
+        out = ctypes.create_string_buffer(max(fmt * n, 1))
+        self._ck(self.lib.c12381_g1_mul_batch(self.h, n, _p(pts), _p(scalars), _p(out), fmt), allow_point=not strict)
+        return out.raw[:fmt * n]
+
+    def g1_add(self, a: bytes, b: bytes, fmt: int = 96, strict: bool = True) -> bytes:
+        n = len(a) // 96
+        out = ctypes.create_string_buffer(max(fmt * n, 1))
+        self._ck(self.lib.c12381_g1_add_batch(self.h, n, _p(a), _p(b), _p(out), fmt), allow_point=not strict)
+        return out.raw[:fmt * n]
+
+    def g1_msm(self, pts: bytes, scalars: bytes, fmt: int = 49) -> bytes:
+        n = len(pts) // 96
+        out = ctypes.create_string_buffer(fmt)
+        self._ck(self.lib.c12381_g1_msm(self.h, n, _p(pts), _p(scalars), _p(out), fmt))
+        return out.raw[:fmt]
+
+    # ---- device-pointer entry points (ints = device addresses, e.g. torch tensor.data_ptr())
+    def fp_mulchain_dev(self, n, iters, a_ptr, b_ptr, out_ptr):
+        self._ck(self.lib.c12381_fp_mulchain_dev(self.h, n, iters, _p(a_ptr), _p(b_ptr), _p(out_ptr)))
+
+    def fp_op_dev(self, op, n, a_ptr, b_ptr, out_ptr):
+        self._ck(self.lib.c12381_fp_op_batch_dev(self.h, self.FP_OPS[op], n, _p(a_ptr), _p(b_ptr), _p(out_ptr)))
+
+    def g1_mul_dev(self, n, pts_ptr, sc_ptr, out_ptr, fmt=49):
+        self._ck(self.lib.c12381_g1_mul_batch_dev(self.h, n, _p(pts_ptr), _p(sc_ptr), _p(out_ptr), fmt))
+
+    def g1_msm_dev(self, n, pts_ptr, sc_ptr, out_ptr, fmt=49):
+        self._ck(self.lib.c12381_g1_msm_dev(self.h, n, _p(pts_ptr), _p(sc_ptr), _p(out_ptr), fmt))

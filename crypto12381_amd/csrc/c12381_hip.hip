@@ -1,0 +1,509 @@
+// HIP kernels + C ABI of the batched BLS12-381 backend for MI355X (gfx950).
+// Public interface and reference citations: include/c12381_hip.h.
+//
+// Kernel inventory (one element per lane everywhere):
+//   fp_op_kernel / fp_mulchain_kernel   Fp test + VALU-roofline hook
+//   g1_mul_kernel      bytes -> on-curve check -> GLV windowed [k]P -> projective SoA in HBM
+//   g1_add_kernel      complete addition of two affine inputs -> projective SoA
+//   g1_finish_kernel   Montgomery's simultaneous inversion over a strided chunk per lane,
+//                      affine conversion, canonical encoding (49 B / 96 B)
+//   g1_reduce_kernel   tree sum of projective points (MSM combine)
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/c12381_hip.h"
+#include "codec.hpp"
+#include "fp.hpp"
+#include "g1.hpp"
+
+using namespace c12381;
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr size_t G1_CHUNK = (size_t)1 << 18;     // elements per scalar-mul launch (table slab = 704 MiB)
+constexpr int FINISH_M = 16;                     // elements per lane in the simultaneous inversion
+
+// ------------------------------------------------------------------ device helpers
+__device__ __forceinline__ void load_raw48(uint32_t* w, const uint8_t* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { uint4 v = q[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
+}
+__device__ __forceinline__ void store_raw48(uint8_t* p, const uint32_t* w) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+__device__ __forceinline__ void load_raw32(uint32_t* w, const uint8_t* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { uint4 v = q[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
+}
+// y^2 == x^3 + 4  (ECP_set ecp_BLS12381.cpp:232, ECP_rhs :279)
+__device__ __forceinline__ bool g1_on_curve(const fp& x, const fp& y) {
+    fp x2, x3, y2, four, rhs;
+    fp_sqr(x2, x); fp_mul(x3, x2, x);
+    fp_set_const(four, FP_FOUR);
+    fp_add(rhs, x3, four);
+    fp_sqr(y2, y);
+    return fp_equal(y2, rhs);
+}
+// parse a 96-byte affine point; all-zero = infinity
+__device__ __forceinline__ void g1_parse96(fp& x, fp& y, bool& inf, bool& ok, const uint8_t* p) {
+    uint32_t raw[24];
+    load_raw48(raw, p); load_raw48(raw + 12, p + 48);
+    inf = raw_all_zero(raw, 24);
+    fp_from_raw48(x, raw); fp_from_raw48(y, raw + 12);
+    ok = inf || g1_on_curve(x, y);
+}
+
+// ------------------------------------------------------------------ Fp kernels
+__global__ void __launch_bounds__(BLOCK) fp_op_kernel(int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint32_t raw[12];
+    fp x, y, r;
+    load_raw48(raw, a + 48 * i); fp_from_raw48(x, raw);
+    if (b) { load_raw48(raw, b + 48 * i); fp_from_raw48(y, raw); } else { fp_zero(y); }
+    switch (op) {
+        case 0: fp_mul(r, x, y); break;
+        case 1: fp_add(r, x, y); break;
+        case 2: fp_sub(r, x, y); break;
+        case 3: fp_sqr(r, x); break;
+        case 4: fp_neg(r, x); break;
+        default: fp_inv(r, x); break;
+    }
+    fp_to_raw48(raw, r);
+    store_raw48(out + 48 * i, raw);
+}
+
+__global__ void __launch_bounds__(BLOCK) fp_mulchain_kernel(size_t n, int iters, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint32_t raw[12];
+    fp x, y;
+    load_raw48(raw, a + 48 * i); fp_from_raw48(x, raw);
+    load_raw48(raw, b + 48 * i); fp_from_raw48(y, raw);
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+        fp z;
+        fp_mul(z, x, y);
+        x = y; y = z;                 // x_{n+2} = x_n * x_{n+1}: both operands stay live
+    }
+    fp_to_raw48(raw, y);
+    store_raw48(out + 48 * i, raw);
+}
+
+// ------------------------------------------------------------------ G1 kernels
+// proj layout: coordinate-major, limb-major SoA: proj[(c*NL + limb) * stride + element]
+__global__ void __launch_bounds__(BLOCK) g1_mul_kernel(size_t n, const uint8_t* pts, const uint8_t* scalars, int32_t* tab,
+                                                       size_t tab_stride, int32_t* proj, size_t proj_stride, size_t proj_off,
+                                                       int* bad_flag) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    fp px, py;
+    bool inf, ok;
+    g1_parse96(px, py, inf, ok, pts + 96 * i);
+    uint32_t raw[8], k[8];
+    load_raw32(raw, scalars + 32 * i);
+    scalar_from_raw32(k, raw);
+    g1p acc;
+    g1_scalar_mul(acc, px, py, inf || !ok, k, tab, tab_stride, i);
+    if (!ok) {
+        *bad_flag = 1;
+        // poison: Z = 0, X = 1 marks "invalid" for the finish kernel
+        fp_one(acc.x); fp_zero(acc.y); fp_zero(acc.z);
+    }
+    g1p o;
+    g1_norm1(o, acc);
+    soa_store_g1(proj, proj_stride, proj_off + i, o);
+}
+
+__global__ void __launch_bounds__(BLOCK) g1_add_kernel(size_t n, const uint8_t* a, const uint8_t* b, int32_t* proj, size_t proj_stride,
+                                                       int* bad_flag) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    g1p p, q, inf_pt;
+    bool ia, oa, ib, ob;
+    g1_parse96(p.x, p.y, ia, oa, a + 96 * i); fp_one(p.z);
+    g1_parse96(q.x, q.y, ib, ob, b + 96 * i); fp_one(q.z);
+    g1_set_inf(inf_pt);
+    fp_select(p.x, ia, inf_pt.x, p.x); fp_select(p.y, ia, inf_pt.y, p.y); fp_select(p.z, ia, inf_pt.z, p.z);
+    fp_select(q.x, ib, inf_pt.x, q.x); fp_select(q.y, ib, inf_pt.y, q.y); fp_select(q.z, ib, inf_pt.z, q.z);
+    g1_add(p, q);
+    if (!(oa && ob)) { *bad_flag = 1; fp_one(p.x); fp_zero(p.y); fp_zero(p.z); }
+    g1p o;
+    g1_norm1(o, p);
+    soa_store_g1(proj, proj_stride, i, o);
+}
+
+// Simultaneous inversion (Montgomery's trick) + affine + encode.  Lane t owns elements
+// t, t+T, t+2T, ... so every global access is coalesced across the wavefront.
+__global__ void __launch_bounds__(BLOCK) g1_finish_kernel(size_t n, const int32_t* proj, size_t stride, int32_t* pref, uint8_t* out,
+                                                          int fmt, size_t T) {
+    const size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= T || t >= n) return;
+    const int32_t* zbase = proj + (size_t)2 * NL * stride;
+    fp run;
+    fp_one(run);
+    size_t last = t;
+#pragma unroll 1
+    for (size_t e = t; e < n; e += T) {
+        fp z, one;
+        soa_load_fp(z, zbase, stride, e);
+        fp_one(one);
+        const bool inf = fp_is_zero(z);
+        fp_select(z, inf, one, z);
+        fp_mul(run, run, z);
+        soa_store_fp(pref, stride, e, run);
+        last = e;
+    }
+    fp inv;
+    fp_inv(inv, run);
+#pragma unroll 1
+    for (size_t e = last;; e -= T) {
+        g1p p;
+        soa_load_g1(p, proj, stride, e);
+        fp one, prev, zinv;
+        fp_one(one);
+        const bool inf = fp_is_zero(p.z);
+        fp_select(p.z, inf, one, p.z);
+        if (e >= T + t) soa_load_fp(prev, pref, stride, e - T); else prev = one;
+        fp_mul(zinv, inv, prev);
+        fp_mul(inv, inv, p.z);
+        fp ax, ay;
+        g1_to_affine(ax, ay, p, zinv);
+        uint32_t rx[12], ry[12];
+        fp_to_raw48(rx, ax);
+        uint8_t* o = out + (size_t)fmt * e;
+        // X = 1 (Montgomery), Z = 0 marks an invalid input; X = 0, Z = 0 is the point at infinity
+        const bool invalid = inf && !fp_is_zero(p.x);
+        if (fmt == 96) {
+            fp_to_raw48(ry, ay);
+            if (inf) {
+#pragma unroll
+                for (int j = 0; j < 12; ++j) { rx[j] = invalid ? 0xffffffffu : 0u; ry[j] = invalid ? 0xffffffffu : 0u; }
+            }
+            store_raw48(o, rx); store_raw48(o + 48, ry);
+        } else {
+            uint8_t tag = (uint8_t)(0x02 | fp_sign(ay));
+            if (inf) {
+                tag = invalid ? 0xff : 0x00;
+#pragma unroll
+                for (int j = 0; j < 12; ++j) rx[j] = invalid ? 0xffffffffu : 0u;
+            }
+            o[0] = tag;
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                const uint32_t v = rx[j];
+                o[1 + 4 * j] = (uint8_t)v; o[2 + 4 * j] = (uint8_t)(v >> 8); o[3 + 4 * j] = (uint8_t)(v >> 16); o[4 + 4 * j] = (uint8_t)(v >> 24);
+            }
+        }
+        if (e < T + t) break;
+    }
+}
+
+// One reduction level: out[j] = sum over i = j, j+m, j+2m, ... < n of in[i]   (projective, complete adds)
+__global__ void __launch_bounds__(BLOCK) g1_reduce_kernel(size_t n, const int32_t* in, size_t in_stride, size_t m, int32_t* outp,
+                                                          size_t out_stride) {
+    const size_t j = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= m) return;
+    g1p acc;
+    g1_set_inf(acc);
+#pragma unroll 1
+    for (size_t i = j; i < n; i += m) {
+        g1p q;
+        soa_load_g1(q, in, in_stride, i);
+        g1_add(acc, q);
+        g1p nn;
+        g1_norm1(nn, acc);
+        acc = nn;
+    }
+    soa_store_g1(outp, out_stride, j, acc);
+}
+
+}  // namespace
+
+// ====================================================================== host side
+struct c12381_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    char err[256] = {0};
+    enum { WS_TAB, WS_PROJ, WS_PREF, WS_IN0, WS_IN1, WS_OUT, WS_RED0, WS_RED1, WS_COUNT };
+    void* ws[WS_COUNT] = {nullptr};
+    size_t ws_bytes[WS_COUNT] = {0};
+    int* d_flag = nullptr;
+    int* h_flag = nullptr;          // pinned
+    // optional per-kernel timing (HIP events on the context's stream), see c12381_profile()
+    bool profiling = false;
+    struct ev_pair { hipEvent_t a, b; int kind; };
+    std::vector<ev_pair> events;
+};
+
+namespace {
+
+int fail(c12381_ctx* c, hipError_t e, const char* what) {
+    std::snprintf(c->err, sizeof c->err, "%s: %s", what, hipGetErrorString(e));
+    return C12381_E_HIP;
+}
+#define HIPCK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail((c), e_, #call); } while (0)
+
+int ensure(c12381_ctx* c, int slot, size_t bytes) {
+    if (c->ws_bytes[slot] >= bytes) return 0;
+    if (c->ws[slot]) { HIPCK(c, hipFree(c->ws[slot])); c->ws[slot] = nullptr; c->ws_bytes[slot] = 0; }
+    hipError_t e = hipMalloc(&c->ws[slot], bytes);
+    if (e != hipSuccess) { std::snprintf(c->err, sizeof c->err, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return C12381_E_NOMEM; }
+    c->ws_bytes[slot] = bytes;
+    return 0;
+}
+inline unsigned grid_for(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
+inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int bind(c12381_ctx* c) {
+    if (!c) return C12381_E_ARG;
+    HIPCK(c, hipSetDevice(c->device));
+    return 0;
+}
+
+// HIP-event bracket around a dominant-kernel launch (kind: 0 = g1_mul_kernel, 1 = g1_finish_kernel, ...)
+struct timed {
+    c12381_ctx* c; int idx = -1;
+    timed(c12381_ctx* c_, int kind) : c(c_) {
+        if (!c->profiling) return;
+        c12381_ctx::ev_pair p; p.kind = kind;
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+        (void)hipEventRecord(p.a, c->stream);
+        c->events.push_back(p); idx = (int)c->events.size() - 1;
+    }
+    ~timed() { if (idx >= 0) (void)hipEventRecord(c->events[idx].b, c->stream); }
+};
+
+// scalar multiplication of n elements into the projective SoA workspace (stride = padded n)
+int g1_mul_to_proj(c12381_ctx* c, size_t n, const uint8_t* d_pts, const uint8_t* d_sc, size_t stride) {
+    const size_t chunk = n < G1_CHUNK ? round_up(n, 64) : G1_CHUNK;
+    int rc;
+    if ((rc = ensure(c, c12381_ctx::WS_TAB, (size_t)G1_TAB_DWORDS * chunk * 4))) return rc;
+    if ((rc = ensure(c, c12381_ctx::WS_PROJ, (size_t)3 * NL * stride * 4))) return rc;
+    for (size_t off = 0; off < n; off += chunk) {
+        const size_t m = n - off < chunk ? n - off : chunk;
+        timed tm(c, 0);
+        hipLaunchKernelGGL(g1_mul_kernel, dim3(grid_for(m)), dim3(BLOCK), 0, c->stream, m, d_pts + 96 * off, d_sc + 32 * off,
+                           (int32_t*)c->ws[c12381_ctx::WS_TAB], chunk, (int32_t*)c->ws[c12381_ctx::WS_PROJ], stride, off, c->d_flag);
+        HIPCK(c, hipGetLastError());
+    }
+    return 0;
+}
+int g1_finish(c12381_ctx* c, size_t n, const int32_t* proj, size_t stride, uint8_t* d_out, int fmt) {
+    int rc;
+    if ((rc = ensure(c, c12381_ctx::WS_PREF, (size_t)NL * stride * 4))) return rc;
+    size_t T = round_up((n + FINISH_M - 1) / FINISH_M, 64);
+    if (T > n) T = n;
+    timed tm(c, 1);
+    hipLaunchKernelGGL(g1_finish_kernel, dim3(grid_for(T)), dim3(BLOCK), 0, c->stream, n, proj, stride,
+                       (int32_t*)c->ws[c12381_ctx::WS_PREF], d_out, fmt, T);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+int read_flag(c12381_ctx* c) {
+    HIPCK(c, hipMemcpyAsync(c->h_flag, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return *c->h_flag ? C12381_E_POINT : 0;
+}
+// stage host buffers: copies up to three inputs in, runs body, copies output back
+struct staged {
+    uint8_t *in0 = nullptr, *in1 = nullptr, *out = nullptr;
+};
+int stage_in(c12381_ctx* c, staged& s, const void* h0, size_t b0, const void* h1, size_t b1, size_t bout) {
+    int rc;
+    if ((rc = ensure(c, c12381_ctx::WS_IN0, round_up(b0 ? b0 : 16, 256)))) return rc;
+    if ((rc = ensure(c, c12381_ctx::WS_IN1, round_up(b1 ? b1 : 16, 256)))) return rc;
+    if ((rc = ensure(c, c12381_ctx::WS_OUT, round_up(bout ? bout : 16, 256)))) return rc;
+    s.in0 = (uint8_t*)c->ws[c12381_ctx::WS_IN0]; s.in1 = (uint8_t*)c->ws[c12381_ctx::WS_IN1]; s.out = (uint8_t*)c->ws[c12381_ctx::WS_OUT];
+    if (h0 && b0) HIPCK(c, hipMemcpyAsync(s.in0, h0, b0, hipMemcpyHostToDevice, c->stream));
+    if (h1 && b1) HIPCK(c, hipMemcpyAsync(s.in1, h1, b1, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+int stage_out(c12381_ctx* c, const staged& s, void* hout, size_t bout) {
+    HIPCK(c, hipMemcpyAsync(hout, s.out, bout, hipMemcpyDeviceToHost, c->stream));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int c12381_version(void) { return (0 << 16) | 1; }
+
+int c12381_create(int device, c12381_ctx** out) {
+    if (!out) return C12381_E_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return C12381_E_HIP;
+    c12381_ctx* c = new (std::nothrow) c12381_ctx;
+    if (!c) return C12381_E_NOMEM;
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return C12381_E_HIP; }
+    c->own_stream = true;
+    if (hipMalloc((void**)&c->d_flag, sizeof(int)) != hipSuccess || hipHostMalloc((void**)&c->h_flag, sizeof(int)) != hipSuccess ||
+        hipMemset(c->d_flag, 0, sizeof(int)) != hipSuccess) { c12381_destroy(c); return C12381_E_HIP; }
+    *out = c;
+    return 0;
+}
+
+void c12381_destroy(c12381_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (int i = 0; i < c12381_ctx::WS_COUNT; ++i) if (c->ws[i]) (void)hipFree(c->ws[i]);
+    if (c->d_flag) (void)hipFree(c->d_flag);
+    if (c->h_flag) (void)hipHostFree(c->h_flag);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* c12381_last_error(const c12381_ctx* c) { return c ? c->err : "null context"; }
+
+int c12381_set_stream(c12381_ctx* c, void* hip_stream) {
+    int rc = bind(c); if (rc) return rc;
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    if (c->own_stream) { HIPCK(c, hipStreamDestroy(c->stream)); c->own_stream = false; }
+    if (hip_stream) { c->stream = (hipStream_t)hip_stream; }
+    else { HIPCK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    return 0;
+}
+
+int c12381_sync(c12381_ctx* c) {
+    int rc = bind(c); if (rc) return rc;
+    return read_flag(c);
+}
+
+int c12381_profile(c12381_ctx* c, int enable) {
+    int rc = bind(c); if (rc) return rc;
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    for (auto& p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    c->events.clear();
+    c->profiling = enable != 0;
+    return 0;
+}
+int c12381_profile_read(c12381_ctx* c, int kind, double* total_ms, uint64_t* launches) {
+    int rc = bind(c); if (rc) return rc;
+    if (!total_ms || !launches) return C12381_E_ARG;
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    double ms = 0; uint64_t cnt = 0;
+    for (auto& p : c->events) {
+        if (p.kind != kind) continue;
+        float t = 0;
+        HIPCK(c, hipEventElapsedTime(&t, p.a, p.b));
+        ms += t; ++cnt;
+    }
+    *total_ms = ms; *launches = cnt;
+    return 0;
+}
+
+// ---------------------------------------------------------------- Fp
+int c12381_fp_op_batch_dev(c12381_ctx* c, int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    int rc = bind(c); if (rc) return rc;
+    if (op < 0 || op > 5 || !a || !out || (op <= 2 && !b)) return C12381_E_ARG;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(fp_op_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, op, n, a, op <= 2 ? b : nullptr, out);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+int c12381_fp_op_batch(c12381_ctx* c, int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    int rc = bind(c); if (rc) return rc;
+    if (op < 0 || op > 5 || !a || !out || (op <= 2 && !b)) return C12381_E_ARG;
+    if (n == 0) return 0;
+    staged s;
+    if ((rc = stage_in(c, s, a, 48 * n, op <= 2 ? b : nullptr, op <= 2 ? 48 * n : 0, 48 * n))) return rc;
+    if ((rc = c12381_fp_op_batch_dev(c, op, n, s.in0, s.in1, s.out))) return rc;
+    if ((rc = stage_out(c, s, out, 48 * n))) return rc;
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int c12381_fp_mulchain_dev(c12381_ctx* c, size_t n, int iters, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    int rc = bind(c); if (rc) return rc;
+    if (!a || !b || !out || iters < 0) return C12381_E_ARG;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(fp_mulchain_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, iters, a, b, out);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------- G1
+int c12381_g1_mul_batch_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
+    int rc = bind(c); if (rc) return rc;
+    if (!pts || !sc || !out || (fmt != 49 && fmt != 96)) return C12381_E_ARG;
+    if (n == 0) return 0;
+    const size_t stride = round_up(n, 64);
+    if ((rc = g1_mul_to_proj(c, n, pts, sc, stride))) return rc;
+    return g1_finish(c, n, (const int32_t*)c->ws[c12381_ctx::WS_PROJ], stride, out, fmt);
+}
+int c12381_g1_mul_batch(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
+    int rc = bind(c); if (rc) return rc;
+    if (!pts || !sc || !out || (fmt != 49 && fmt != 96)) return C12381_E_ARG;
+    if (n == 0) return 0;
+    staged s;
+    if ((rc = stage_in(c, s, pts, 96 * n, sc, 32 * n, (size_t)fmt * n))) return rc;
+    if ((rc = c12381_g1_mul_batch_dev(c, n, s.in0, s.in1, s.out, fmt))) return rc;
+    if ((rc = stage_out(c, s, out, (size_t)fmt * n))) return rc;
+    return read_flag(c);
+}
+int c12381_g1_add_batch(c12381_ctx* c, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out, int fmt) {
+    int rc = bind(c); if (rc) return rc;
+    if (!a || !b || !out || (fmt != 49 && fmt != 96)) return C12381_E_ARG;
+    if (n == 0) return 0;
+    staged s;
+    if ((rc = stage_in(c, s, a, 96 * n, b, 96 * n, (size_t)fmt * n))) return rc;
+    const size_t stride = round_up(n, 64);
+    if ((rc = ensure(c, c12381_ctx::WS_PROJ, (size_t)3 * NL * stride * 4))) return rc;
+    hipLaunchKernelGGL(g1_add_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, s.in0, s.in1, (int32_t*)c->ws[c12381_ctx::WS_PROJ], stride,
+                       c->d_flag);
+    HIPCK(c, hipGetLastError());
+    if ((rc = g1_finish(c, n, (const int32_t*)c->ws[c12381_ctx::WS_PROJ], stride, s.out, fmt))) return rc;
+    if ((rc = stage_out(c, s, out, (size_t)fmt * n))) return rc;
+    return read_flag(c);
+}
+
+// MSM, round-1 algorithm: n independent GLV scalar multiplications followed by a tree sum of the
+// projective results (the reference's Π is also O(n) full scalar-muls, g1_point.hpp:389-401); only
+// the final point is canonical.  A bucket method is a later optimisation behind the same entry.
+int c12381_g1_msm_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
+    int rc = bind(c); if (rc) return rc;
+    if (!out || (n && (!pts || !sc)) || (fmt != 49 && fmt != 96)) return C12381_E_ARG;
+    if (n == 0) { HIPCK(c, hipMemsetAsync(out, 0, fmt, c->stream)); return 0; }
+    const size_t stride = round_up(n, 64);
+    if ((rc = g1_mul_to_proj(c, n, pts, sc, stride))) return rc;
+    const int32_t* cur = (const int32_t*)c->ws[c12381_ctx::WS_PROJ];
+    size_t cur_n = n, cur_stride = stride;
+    int slot = c12381_ctx::WS_RED0;
+    while (cur_n > 1) {
+        size_t m = cur_n > 4096 ? round_up(cur_n / 32, 64) : (cur_n > 64 ? 64 : 1);
+        const size_t m_stride = round_up(m, 64);
+        if ((rc = ensure(c, slot, (size_t)3 * NL * m_stride * 4))) return rc;
+        hipLaunchKernelGGL(g1_reduce_kernel, dim3(grid_for(m)), dim3(BLOCK), 0, c->stream, cur_n, cur, cur_stride, m, (int32_t*)c->ws[slot], m_stride);
+        HIPCK(c, hipGetLastError());
+        cur = (const int32_t*)c->ws[slot]; cur_n = m; cur_stride = m_stride;
+        slot = slot == c12381_ctx::WS_RED0 ? c12381_ctx::WS_RED1 : c12381_ctx::WS_RED0;
+    }
+    return g1_finish(c, 1, cur, cur_stride, out, fmt);
+}
+int c12381_g1_msm(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
+    int rc = bind(c); if (rc) return rc;
+    if (!out || (n && (!pts || !sc)) || (fmt != 49 && fmt != 96)) return C12381_E_ARG;
+    staged s;
+    if ((rc = stage_in(c, s, pts, 96 * n, sc, 32 * n, (size_t)fmt))) return rc;
+    if ((rc = c12381_g1_msm_dev(c, n, s.in0, s.in1, s.out, fmt))) return rc;
+    if ((rc = stage_out(c, s, out, (size_t)fmt))) return rc;
+    return read_flag(c);
+}
+
+}  // extern "C"

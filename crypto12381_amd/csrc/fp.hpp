@@ -1,0 +1,318 @@
+// Fp arithmetic for BLS12-381 on CDNA4 — the leaf of the whole hot path
+// (replaces FP_mul/FP_sqr/FP_add/FP_sub/FP_neg/FP_imul/FP_inv/FP_sqrt of the reference's
+// fp_BLS12381.cpp:396-936 and BIG_mul/BIG_sqr/BIG_monty of big_B384_58.cpp:570-981).
+//
+// Number format (designed for gfx950, not MIRACL's 7x58-bit/__int128 format):
+//   * 14 SIGNED limbs of 28 bits, little-endian; Montgomery radix R = 2^392.
+//   * limbs are carried lazily: add/sub/neg are 14 independent v_add/v_sub with no carry
+//     chain and no conditional subtraction; values may be negative or exceed p.
+//   * a product is scanned column by column into ONE 64-bit accumulator with
+//     v_mad_i64_i32 (measured on MI355X at ~the v_add rate, profiles/r01_valu_rates.txt),
+//     Montgomery reduction interleaved in the same columns — no carry flags anywhere.
+//   * invariants are tracked as two bounds per element: LB = max |limb| and VB = |value|/p.
+//     fp_mul needs 14*LBa*LBb + 14*2^56 + 2^40 < 2^63 and VBa*VBb <= 2^11 and returns
+//     limbs 0..12 in [0,2^28), value in (-p, 2p).  Builds with C12381_CHECK_BOUNDS (host
+//     simulation used by the CPU tests) carry the bounds at run time and assert them; the
+//     bounds depend only on the operation sequence, never on the data.
+#pragma once
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define C12381_HD __host__ __device__ __forceinline__
+#define C12381_CONST __device__ constexpr
+#else
+#define C12381_HD inline
+#define C12381_CONST constexpr
+#endif
+
+#include "consts.hpp"
+
+#ifdef C12381_CHECK_BOUNDS
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#define C12381_BOUNDS(...) __VA_ARGS__
+#else
+#define C12381_BOUNDS(...)
+#endif
+
+namespace c12381 {
+
+struct fp {
+    int32_t l[NL];
+#ifdef C12381_CHECK_BOUNDS
+    double lb = 0, vb = 0;      // declared bounds: max |limb|, |value| / p
+#endif
+};
+
+#ifdef C12381_CHECK_BOUNDS
+inline void bounds_fail(const char* what, double a, double b) {
+    std::fprintf(stderr, "C12381 bound violation: %s (%.4g, %.4g)\n", what, a, b);
+    std::abort();
+}
+constexpr double P_OVER_R = 0.000396;          // p / 2^392 < this
+constexpr double TOP_PER_P = 106514.0;         // p / 2^364 < this: |top limb| <= VB * TOP_PER_P + 1
+inline void check_actual(const fp& a, const char* where) {
+    for (int i = 0; i < NL; ++i)
+        if (std::fabs((double)a.l[i]) > a.lb) bounds_fail(where, (double)a.l[i], a.lb);
+}
+inline void set_bounds(fp& r, double lb, double vb, const char* where) {
+    r.lb = lb; r.vb = vb;
+    if (lb > 2147483648.0) bounds_fail("limb bound exceeds int32", lb, vb);
+    check_actual(r, where);
+}
+#endif
+
+// ------------------------------------------------------------------ limb-wise lazy ops
+C12381_HD void fp_add(fp& r, const fp& a, const fp& b) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = a.l[i] + b.l[i];
+    C12381_BOUNDS(set_bounds(r, a.lb + b.lb, a.vb + b.vb, "fp_add");)
+}
+C12381_HD void fp_sub(fp& r, const fp& a, const fp& b) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = a.l[i] - b.l[i];
+    C12381_BOUNDS(set_bounds(r, a.lb + b.lb, a.vb + b.vb, "fp_sub");)
+}
+C12381_HD void fp_neg(fp& r, const fp& a) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = -a.l[i];
+    C12381_BOUNDS(set_bounds(r, a.lb, a.vb, "fp_neg");)
+}
+C12381_HD void fp_dbl(fp& r, const fp& a) { fp_add(r, a, a); }
+C12381_HD void fp_zero(fp& r) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = 0;
+    C12381_BOUNDS(r.lb = 0; r.vb = 0;)
+}
+C12381_HD void fp_set_const(fp& r, const int32_t (&c)[NL]) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = c[i];
+    C12381_BOUNDS(r.lb = 268435456.0; r.vb = 1.0;)
+}
+C12381_HD void fp_one(fp& r) { fp_set_const(r, FP_R1); }
+// r = c ? a : b   (lane-wise select, no divergence)
+C12381_HD void fp_select(fp& r, bool c, const fp& a, const fp& b) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = c ? a.l[i] : b.l[i];
+    C12381_BOUNDS(r.lb = a.lb > b.lb ? a.lb : b.lb; r.vb = a.vb > b.vb ? a.vb : b.vb;)
+}
+
+// One parallel carry round: limbs 0..12 -> [0, 2^28) + incoming carry, top limb keeps the sign.
+// Output LB = 2^28 + (LB_in >> 28) + 1.  No dependency chain between limbs.
+C12381_HD void fp_norm1(fp& r, const fp& a) {
+    int32_t c[NL];
+#pragma unroll
+    for (int i = 0; i < NL - 1; ++i) c[i] = a.l[i] >> LB;
+    int32_t t13 = a.l[NL - 1] + c[NL - 2];
+#pragma unroll
+    for (int i = NL - 2; i >= 1; --i) r.l[i] = (int32_t)((uint32_t)a.l[i] & LMASK) + c[i - 1];
+    r.l[0] = (int32_t)((uint32_t)a.l[0] & LMASK);
+    r.l[NL - 1] = t13;
+    C12381_BOUNDS({ double top = a.vb * TOP_PER_P + 4.0 + std::floor(a.lb / 268435456.0);
+                    double lb = 268435456.0 + std::floor(a.lb / 268435456.0) + 1.0;
+                    set_bounds(r, lb > top ? lb : top, a.vb, "fp_norm1"); })
+}
+
+// r = k * a for a small non-negative integer k (k * LB may exceed int32: carries are
+// propagated exactly with a 64-bit running value).  Replaces FP_imul fp_BLS12381.cpp:420.
+C12381_HD void fp_mul_small(fp& r, const fp& a, int32_t k) {
+    int64_t t = 0;
+#pragma unroll
+    for (int i = 0; i < NL - 1; ++i) {
+        t += (int64_t)a.l[i] * k;
+        r.l[i] = (int32_t)((uint32_t)t & LMASK);
+        t >>= LB;
+    }
+    t += (int64_t)a.l[NL - 1] * k;
+    r.l[NL - 1] = (int32_t)t;
+    C12381_BOUNDS({ double top = a.vb * k * TOP_PER_P + 2.0;
+                    set_bounds(r, top > 268435456.0 ? top : 268435456.0, a.vb * k, "fp_mul_small"); })
+}
+
+// ------------------------------------------------------------------ Montgomery multiply / square
+#ifdef C12381_CHECK_BOUNDS
+inline void check_mul_operands(const fp& a, const fp& b, const char* where) {
+    check_actual(a, where); check_actual(b, where);
+    double col = 14.0 * a.lb * b.lb + 14.0 * 72057594037927936.0 + 1099511627776.0;
+    if (col >= 9223372036854775808.0) bounds_fail(where, a.lb, b.lb);
+    if (a.vb * b.vb > 2048.0) bounds_fail("fp_mul value bound", a.vb, b.vb);
+}
+#endif
+
+// r = a * b / R mod p.   14x14 product scanning + interleaved Montgomery reduction:
+// 392 v_mad_i64_i32 + 14 v_mul_lo_u32 and ~70 shifts/masks per call.
+C12381_HD void fp_mul(fp& r, const fp& a, const fp& b) {
+    C12381_BOUNDS(check_mul_operands(a, b, "fp_mul");)
+    int32_t m[NL];
+    int32_t out[NL];
+    int64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+#pragma unroll
+        for (int i = 0; i <= k; ++i) acc += (int64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+        for (int i = 0; i < k; ++i) acc += (int64_t)m[i] * FP_P[k - i];
+        m[k] = (int32_t)(((uint32_t)acc * FP_N0) & LMASK);
+        acc += (int64_t)m[k] * FP_P[0];
+        acc >>= LB;
+    }
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; ++k) {
+#pragma unroll
+        for (int i = k - NL + 1; i < NL; ++i) acc += (int64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+        for (int i = k - NL + 1; i < NL; ++i) acc += (int64_t)m[i] * FP_P[k - i];
+        out[k - NL] = (int32_t)((uint32_t)acc & LMASK);
+        acc >>= LB;
+    }
+    out[NL - 1] = (int32_t)acc;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = out[i];
+    C12381_BOUNDS({ double vb = a.vb * b.vb * P_OVER_R + 1.0;
+                    double top = vb * TOP_PER_P + 2.0;
+                    set_bounds(r, top > 268435456.0 ? top : 268435456.0, vb, "fp_mul"); })
+}
+
+// r = a^2 / R mod p.  Cross terms once, doubled per column: 105 + 196 multiply-adds.
+C12381_HD void fp_sqr(fp& r, const fp& a) {
+    C12381_BOUNDS(check_mul_operands(a, a, "fp_sqr");)
+    int32_t m[NL];
+    int32_t out[NL];
+    int64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        int64_t x = 0;
+#pragma unroll
+        for (int i = 0; 2 * i < k; ++i) x += (int64_t)a.l[i] * a.l[k - i];
+        acc += 2 * x;
+        if ((k & 1) == 0) acc += (int64_t)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+        for (int i = 0; i < k; ++i) acc += (int64_t)m[i] * FP_P[k - i];
+        m[k] = (int32_t)(((uint32_t)acc * FP_N0) & LMASK);
+        acc += (int64_t)m[k] * FP_P[0];
+        acc >>= LB;
+    }
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; ++k) {
+        int64_t x = 0;
+#pragma unroll
+        for (int i = k - NL + 1; 2 * i < k; ++i) x += (int64_t)a.l[i] * a.l[k - i];
+        acc += 2 * x;
+        if ((k & 1) == 0) acc += (int64_t)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+        for (int i = k - NL + 1; i < NL; ++i) acc += (int64_t)m[i] * FP_P[k - i];
+        out[k - NL] = (int32_t)((uint32_t)acc & LMASK);
+        acc >>= LB;
+    }
+    out[NL - 1] = (int32_t)acc;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = out[i];
+    C12381_BOUNDS({ double vb = a.vb * a.vb * P_OVER_R + 1.0;
+                    double top = vb * TOP_PER_P + 2.0;
+                    set_bounds(r, top > 268435456.0 ? top : 268435456.0, vb, "fp_sqr"); })
+}
+
+// ------------------------------------------------------------------ canonical form, tests
+// Leaves Montgomery form and fully reduces: r = a / R mod p as canonical limbs in [0, p).
+// (FP_redc fp_BLS12381.cpp:234 + FP_reduce :549).  Cost: one fp_mul + compare/subtract.
+C12381_HD void fp_from_mont_canonical(fp& r, const fp& a) {
+    fp one;
+    fp_zero(one);
+    one.l[0] = 1;
+    C12381_BOUNDS(one.lb = 1; one.vb = 1e-100;)
+    fp t;
+    fp_mul(t, a, one);            // value in [0, p], limbs normalised, top limb >= 0
+    // t == p ?  (only when a is a non-zero multiple of p)
+    bool eqp = true;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) eqp = eqp && (t.l[i] == FP_P[i]);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = eqp ? 0 : t.l[i];
+    C12381_BOUNDS(r.lb = 268435456.0; r.vb = 1.0;)
+}
+// a == 0 mod p  (FP_iszilch fp_BLS12381.cpp:305)
+C12381_HD bool fp_is_zero(const fp& a) {
+    fp t;
+    fp_from_mont_canonical(t, a);
+    int32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) o |= t.l[i];
+    return o == 0;
+}
+C12381_HD bool fp_equal(const fp& a, const fp& b) {
+    fp d;
+    fp_sub(d, a, b);
+    return fp_is_zero(d);
+}
+
+// ------------------------------------------------------------------ bytes <-> limbs
+// 48 big-endian bytes -> Montgomery form; the integer is taken mod p like FP_nres
+// (fp_BLS12381.cpp:223 after BIG_fromBytes big_B384_58.cpp:186).
+C12381_HD void fp_from_words_be(fp& r, const uint32_t (&w)[12]) {
+    // w[0] is the most significant 32-bit word (already byte-swapped to host order)
+    fp t;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int bit = i * LB;
+        const int wi = bit / 32, sh = bit % 32;            // word index from the least significant end
+        uint64_t lo = w[11 - wi];
+        if (wi + 1 < 12) lo |= (uint64_t)w[11 - (wi + 1)] << 32;
+        t.l[i] = (int32_t)((uint32_t)(lo >> sh) & LMASK);
+    }
+    C12381_BOUNDS(t.lb = 268435456.0; t.vb = 10.0;)       // < 2^384 < 10 p
+    fp r2;
+    fp_set_const(r2, FP_R2);
+    fp_mul(r, t, r2);
+}
+// Montgomery form -> canonical integer as 12 big-endian-ordered 32-bit words (w[0] most significant)
+C12381_HD void fp_to_words_be(uint32_t (&w)[12], const fp& a) {
+    fp t;
+    fp_from_mont_canonical(t, a);
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        const int bit = j * 32;
+        const int li = bit / LB, sh = bit % LB;
+        uint64_t v = (uint64_t)(uint32_t)t.l[li] >> sh;
+        if (li + 1 < NL) v |= (uint64_t)(uint32_t)t.l[li + 1] << (LB - sh);
+        if (li + 2 < NL && 2 * LB - sh < 32) v |= (uint64_t)(uint32_t)t.l[li + 2] << (2 * LB - sh);
+        w[11 - j] = (uint32_t)v;
+    }
+}
+// parity of the canonical residue (FP_sign fp_BLS12381.cpp:912-936)
+C12381_HD int fp_sign(const fp& a) {
+    fp t;
+    fp_from_mont_canonical(t, a);
+    return t.l[0] & 1;
+}
+
+// ------------------------------------------------------------------ fixed exponentiations
+// r = a^e for a public 384-bit exponent, 4-bit fixed window (exponent is a compile-time
+// table in constant memory, so the schedule is identical in every lane).
+C12381_HD void fp_pow_fixed(fp& r, const fp& a, const uint32_t (&e)[12]) {
+    fp tab[16];
+    fp_one(tab[0]);
+    {
+        fp n;
+        fp_norm1(n, a);
+        tab[1] = n;
+    }
+#pragma unroll 1
+    for (int i = 2; i < 16; ++i) fp_mul(tab[i], tab[i - 1], tab[1]);
+    fp acc;
+    fp_one(acc);
+#pragma unroll 1
+    for (int wi = 95; wi >= 0; --wi) {
+        fp_sqr(acc, acc); fp_sqr(acc, acc); fp_sqr(acc, acc); fp_sqr(acc, acc);
+        const uint32_t d = (e[wi / 8] >> (4 * (wi % 8))) & 15u;
+        fp_mul(acc, acc, tab[d]);
+    }
+    r = acc;
+}
+// Fermat inversion a^(p-2); 0 -> 0 like the reference (FP_inv fp_BLS12381.cpp:817)
+C12381_HD void fp_inv(fp& r, const fp& a) { fp_pow_fixed(r, a, EXP_P_MINUS_2); }
+// candidate square root a^((p+1)/4) (p = 3 mod 4); caller verifies r^2 == a
+C12381_HD void fp_sqrt_candidate(fp& r, const fp& a) { fp_pow_fixed(r, a, EXP_P_PLUS_1_DIV_4); }
+
+}  // namespace c12381

@@ -1,0 +1,92 @@
+/* c12381_hip.h — C ABI of the MI355X-native batched BLS12-381 backend.
+ *
+ * This is the drop-in boundary for crypto12381's hot path.  The reference's seam is the set of
+ * C++ free functions in namespace crypto12381::detail::miracl_core
+ * (include/crypto12381/miracl_core_interface.hpp:16-204, defined in
+ * src/miracl_core_interface.cpp:12-289 of the reference); it is scalar (one element per call)
+ * and cannot express a 2^20 batch, so the entry points below are the batched forms of the
+ * throughput functions of that seam.  Each entry cites the reference function it replaces.
+ * INTEGRATION.md shows the reference-side binding (a replacement miracl_core_interface.cpp).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; every function returns 0 on success or a negative
+ *     C12381_E_* code; no exceptions, no allocation visible to the caller.
+ *   - All data is canonical big-endian bytes, bit-identical to the reference's encodings:
+ *       Fp      48 B
+ *       scalar  32 B   any value < 2^256; reduced mod r first (PAIR_G1mul pair_BLS12381.cpp:879-881)
+ *       G1      96 B   x||y affine (ECP_toOctet uncompressed body, ecp_BLS12381.cpp:478-488);
+ *                      96 zero bytes = point at infinity
+ *               49 B   02|03 || x   compressed; 49 zero bytes = infinity (g1_point.hpp:113-117)
+ *       G2     192 B   x.b||x.a||y.b||y.a (FP2_toBytes fp2_BLS12381.cpp:83-87: imaginary part first);
+ *                      zeros = infinity;   97 B compressed 02|03 || x.b || x.a
+ *       GT     576 B   c||b||a, each Fp4 b||a, each Fp2 b||a (FP12_toOctet fp12_BLS12381.cpp:923-929)
+ *   - "host" entry points take host pointers (the library stages through its own device buffers);
+ *     "_dev" entry points take DEVICE pointers (16-byte aligned) and run asynchronously on the
+ *     context's stream; call c12381_sync() before reading results.
+ *   - One context per host thread / per GPU; contexts are independent (thread-compatible).
+ *   - There is no CPU fallback: without a usable HIP device c12381_create fails.
+ */
+#ifndef C12381_HIP_H
+#define C12381_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct c12381_ctx c12381_ctx;
+
+enum {
+    C12381_OK = 0,
+    C12381_E_ARG = -1,      /* bad argument (null pointer, unknown format or op) */
+    C12381_E_HIP = -2,      /* HIP runtime error; see c12381_last_error */
+    C12381_E_POINT = -3,    /* at least one input point is not on the curve (its output is all 0xff) */
+    C12381_E_NOMEM = -4
+};
+
+/* context -------------------------------------------------------------------------------- */
+int c12381_create(int device, c12381_ctx** out);
+void c12381_destroy(c12381_ctx* ctx);
+const char* c12381_last_error(const c12381_ctx* ctx);
+/* use an existing hipStream_t (passed as void*) for all work of this context; NULL = own stream */
+int c12381_set_stream(c12381_ctx* ctx, void* hip_stream);
+/* wait for the context's stream; returns C12381_E_POINT if any kernel since the last sync saw an
+ * invalid input point */
+int c12381_sync(c12381_ctx* ctx);
+/* Per-kernel timing with HIP events on the context's stream (used by bench.py for the roofline
+ * figure).  enable != 0 starts a fresh recording; kind: 0 = G1 scalar-mul kernel, 1 = G1 finish
+ * (inversion + encode) kernel.  c12381_profile_read synchronises the stream. */
+int c12381_profile(c12381_ctx* ctx, int enable);
+int c12381_profile_read(c12381_ctx* ctx, int kind, double* total_ms, uint64_t* launches);
+/* ABI version: major << 16 | minor */
+int c12381_version(void);
+
+/* Fp (test / roofline hook) --------------------------------------------------------------- */
+/* op: 0 mul, 1 add, 2 sub, 3 sqr, 4 neg, 5 inv.  Replaces FP_nres + FP_mul/FP_add/FP_sub/FP_sqr/
+ * FP_neg/FP_inv + FP_redc (fp_BLS12381.cpp:223,396,485,500,466,588,817,234).  b may be NULL for
+ * unary ops. */
+int c12381_fp_op_batch(c12381_ctx* ctx, int op, size_t n, const uint8_t* a48, const uint8_t* b48, uint8_t* out48);
+int c12381_fp_op_batch_dev(c12381_ctx* ctx, int op, size_t n, const uint8_t* a48, const uint8_t* b48, uint8_t* out48);
+/* register-resident chain of `iters` Montgomery multiplications per element (x <- x*y), used to
+ * calibrate the integer-VALU roofline; out = final x */
+int c12381_fp_mulchain_dev(c12381_ctx* ctx, size_t n, int iters, const uint8_t* a48, const uint8_t* b48, uint8_t* out48);
+
+/* G1 ------------------------------------------------------------------------------------- */
+/* out[i] = scalars[i] * pts[i].  Batched form of multiply(point1&, const big&)
+ * (miracl_core_interface.hpp:122, src/miracl_core_interface.cpp:174-177 -> PAIR_G1mul) followed by
+ * to_bytes(bytes_view&, point1&, compressed) (:113-116 -> ECP_toOctet).  out_fmt = 49 or 96. */
+int c12381_g1_mul_batch(c12381_ctx* ctx, size_t n, const uint8_t* pts96, const uint8_t* scalars32, uint8_t* out, int out_fmt);
+int c12381_g1_mul_batch_dev(c12381_ctx* ctx, size_t n, const uint8_t* pts96, const uint8_t* scalars32, uint8_t* out, int out_fmt);
+/* out[i] = a[i] + b[i].  Batched add(point1&, point1&) (:129-132 -> ECP_add). */
+int c12381_g1_add_batch(c12381_ctx* ctx, size_t n, const uint8_t* a96, const uint8_t* b96, uint8_t* out, int out_fmt);
+/* out = sum_i scalars[i] * pts[i]  (the reference's Π[n](g[i]^x[i]), g1_point.hpp:371-404, and
+ * sum_of_products(point1&, int, point1*, const big*) :134-137 -> ECP_muln). */
+int c12381_g1_msm(c12381_ctx* ctx, size_t n, const uint8_t* pts96, const uint8_t* scalars32, uint8_t* out, int out_fmt);
+int c12381_g1_msm_dev(c12381_ctx* ctx, size_t n, const uint8_t* pts96, const uint8_t* scalars32, uint8_t* out, int out_fmt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* C12381_HIP_H */

@@ -1,0 +1,100 @@
+"""GPU parity tests (run on the MI355X box with -m gpu): HIP path through the C ABI vs the
+golden vectors generated from the reference and vs the CPU oracle on fresh seeded inputs."""
+import pytest
+
+from util import P, R, cat, golden, prng, scalars
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from crypto12381_amd import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def test_fp_ops_golden(ctx):
+    g = golden("fp")
+    a, b = cat(g["a"]), cat(g["b"])
+    for op in ("mul", "add", "sub", "sqr", "neg", "inv"):
+        assert ctx.fp_op(op, a, b if op in ("mul", "add", "sub") else None) == cat(g[op]), op
+
+
+def test_fp_mul_random_vs_python(ctx):
+    n = 4096
+    a = [prng(101, i, 48) % P for i in range(n)]
+    b = [prng(102, i, 48) % P for i in range(n)]
+    out = ctx.fp_op("mul", b"".join(x.to_bytes(48, "big") for x in a), b"".join(x.to_bytes(48, "big") for x in b))
+    for i in range(n):
+        assert int.from_bytes(out[48 * i:48 * i + 48], "big") == a[i] * b[i] % P
+
+
+def test_g1_mul_golden(ctx):
+    g = golden("g1")
+    pts, sc = cat(g["points"]), cat(g["scalars"])
+    assert ctx.g1_mul(pts, sc, 49) == cat(g["mul49"])
+    assert ctx.g1_mul(pts, sc, 96) == cat(g["mul96"])
+
+
+def test_g1_add_golden(ctx):
+    g = golden("g1")
+    assert ctx.g1_add(cat(g["add_a"]), cat(g["add_b"]), 96) == cat(g["add96"])
+    assert ctx.g1_add(cat(g["add_a"]), cat(g["add_b"]), 49) == cat(g["add49"])
+
+
+def test_g1_msm_golden(ctx):
+    g = golden("g1")
+    pts, sc = cat(g["points"]), cat(g["scalars"])
+    assert ctx.g1_msm(pts, sc, 49).hex() == g["msm49"]
+    assert ctx.g1_msm(pts[:96], sc[:32], 49) == ctx.g1_mul(pts[:96], sc[:32], 49)
+
+
+def test_g1_mul_vs_oracle_random(ctx, oracle_port):
+    """Fresh seeded batch (ragged size, not a multiple of the block) against the CPU oracle."""
+    n = 1000
+    g1 = bytes.fromhex(golden("g1")["generator"])
+    pts = ctx.g1_mul(g1 * n, scalars(201, n), 96)            # P_i = G^{s_i} built by the HIP path ...
+    assert pts[:96 * 64] == oracle_port.g1_mul(g1 * 64, scalars(201, 64), 96, 4)   # ... and spot-checked
+    sc = scalars(202, n, 1 << 256)                           # unreduced 256-bit scalars
+    got = ctx.g1_mul(pts, sc, 49)
+    assert got == oracle_port.g1_mul(pts, sc, 49, 16)
+
+
+def test_g1_invalid_point_is_flagged(ctx):
+    from crypto12381_amd import C12381Error
+    g = golden("g1")
+    good = bytes.fromhex(g["points"][0])
+    bad = good[:95] + bytes([good[95] ^ 1])                  # y perturbed: not on the curve
+    with pytest.raises(C12381Error):
+        ctx.g1_mul(good + bad, scalars(5, 2), 49)
+    out = ctx.g1_mul(good + bad, scalars(5, 2), 49, strict=False)
+    assert out[49:] == b"\xff" * 49
+    assert out[:49] == ctx.g1_mul(good, scalars(5, 1), 49)
+
+
+def test_g1_full_size_properties(ctx, oracle_port):
+    """BASELINE configs[1] size (2^20): size-independent checks — linearity through the MSM and
+    a sampled oracle comparison."""
+    n = 1 << 20
+    g1 = bytes.fromhex(golden("g1")["generator"])
+    m = 1 << 12
+    base = ctx.g1_mul(g1 * m, scalars(301, m), 96)
+    pts = base * (n // m)                                    # 2^20 points (period 2^12)
+    sc = scalars(302, n)
+    out = ctx.g1_mul(pts, sc, 96)
+    idx = [0, 1, m - 1, m, n // 2 + 17, n - 1] + [prng(303, i, 4) % n for i in range(58)]
+    sp = b"".join(pts[96 * i:96 * i + 96] for i in idx)
+    ss = b"".join(sc[32 * i:32 * i + 32] for i in idx)
+    exp = oracle_port.g1_mul(sp, ss, 96, 16)
+    assert b"".join(out[96 * i:96 * i + 96] for i in idx) == exp
+    # sum of all outputs == MSM of the inputs (both on the GPU), and == g^(sum s_i k_i) via one oracle mul
+    one = (1).to_bytes(32, "big")
+    lhs = ctx.g1_msm(out, one * n, 49)
+    assert lhs == ctx.g1_msm(pts, sc, 49)
+    s_base = [prng(301, i) % R for i in range(m)]
+    tot = 0
+    for i in range(n):
+        tot += s_base[i % m] * int.from_bytes(sc[32 * i:32 * i + 32], "big")
+    assert lhs == oracle_port.g1_mul(g1, (tot % R).to_bytes(32, "big"), 49)

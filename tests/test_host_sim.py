@@ -1,0 +1,81 @@
+"""CPU tests of the DEVICE algorithms: tests/host_sim/sim.cpp compiles crypto12381_amd/csrc/*.hpp
+for the host with C12381_CHECK_BOUNDS (every limb/value bound of fp.hpp asserted at run time) and the
+results are compared with the golden vectors / the oracle.  This is how the HIP code is validated in
+the build container, which has no GPU; it is not a product path."""
+import ctypes
+import os
+import subprocess
+
+import pytest
+
+from util import P, R, cat, golden, scalars
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SIM_DIR = os.path.join(HERE, "host_sim")
+CSRC = os.path.join(os.path.dirname(HERE), "crypto12381_amd", "csrc")
+sz = ctypes.c_size_t
+
+
+@pytest.fixture(scope="module")
+def sim():
+    so = os.path.join(SIM_DIR, "libsim.so")
+    srcs = [os.path.join(SIM_DIR, "sim.cpp")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.run(["g++", "-O1", "-std=c++17", "-DC12381_CHECK_BOUNDS", "-fPIC", "-shared", "-o", so,
+                        os.path.join(SIM_DIR, "sim.cpp")], check=True)
+    return ctypes.CDLL(so)
+
+
+def _fp(sim, op, a, b):
+    n = len(a) // 48
+    out = ctypes.create_string_buffer(48 * n)
+    assert sim.sim_fp_op_batch(op, sz(n), a, b, out) == 0
+    return out.raw
+
+
+def test_sim_fp_ops(sim):
+    g = golden("fp")
+    a, b = cat(g["a"]), cat(g["b"])
+    for op, name in ((0, "mul"), (1, "add"), (2, "sub"), (3, "sqr"), (4, "neg"), (5, "inv")):
+        assert _fp(sim, op, a, b) == cat(g[name]), name
+    out = _fp(sim, 7, a, b)
+    assert all(int.from_bytes(out[48 * i:48 * i + 48], "big") == int(g["a"][i], 16) * 12 % P for i in range(len(g["a"])))
+    out = _fp(sim, 8, a, b)
+    assert all(int.from_bytes(out[48 * i:48 * i + 48], "big") == int(g["a"][i], 16) % P for i in range(len(g["a"])))
+    out = _fp(sim, 6, a, b)      # sqrt candidate: squares back when a is a residue
+    for i, qr in enumerate(g["sqrt_is_qr"]):
+        if qr:
+            assert pow(int.from_bytes(out[48 * i:48 * i + 48], "big"), 2, P) == int(g["a"][i], 16) % P
+
+
+def test_sim_glv_split(sim):
+    x2 = 0xd201000000010000 ** 2
+    ks = [0, 1, R - 1, R, R + 5, (1 << 256) - 1, x2, x2 - 1, x2 + 1, 3 * x2 - 1] + \
+         [int.from_bytes(scalars(77, 20, 1 << 256)[32 * i:32 * i + 32], "big") for i in range(20)]
+    for k in ks:
+        k0 = (ctypes.c_uint32 * 4)()
+        k1 = (ctypes.c_uint32 * 4)()
+        sim.sim_glv_split((k % (1 << 256)).to_bytes(32, "big"), k0, k1)
+        a0 = sum(k0[i] << (32 * i) for i in range(4))
+        a1 = sum(k1[i] << (32 * i) for i in range(4))
+        assert a0 + a1 * x2 == (k % (1 << 256)) % R and a0 < x2
+
+
+def test_sim_g1_mul_golden(sim):
+    g = golden("g1")
+    pts, sc = cat(g["points"]), cat(g["scalars"])
+    n = len(pts) // 96
+    for fmt, key in ((49, "mul49"), (96, "mul96")):
+        out = ctypes.create_string_buffer(fmt * n)
+        assert sim.sim_g1_mul_batch(sz(n), pts, sc, out, fmt) == 0
+        assert out.raw == cat(g[key])
+
+
+def test_sim_g1_mul_random_vs_oracle(sim, oracle_port):
+    n = 24
+    g1 = bytes.fromhex(golden("g1")["generator"])
+    pts = oracle_port.g1_mul(g1 * n, scalars(501, n), 96, 4)
+    sc = scalars(502, n, 1 << 256)
+    out = ctypes.create_string_buffer(49 * n)
+    assert sim.sim_g1_mul_batch(sz(n), pts, sc, out, 49) == 0
+    assert out.raw == oracle_port.g1_mul(pts, sc, 49, 4)
