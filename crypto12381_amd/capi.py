@@ -48,6 +48,12 @@ def load_library() -> ctypes.CDLL:
         for name in ("c12381_g1_mul_batch", "c12381_g1_mul_batch_dev", "c12381_g1_add_batch", "c12381_g1_msm",
                      "c12381_g1_msm_dev"):
             getattr(lib, name).argtypes = [vp, sz, vp, vp, vp, ci]
+        for name in ("c12381_g2_mul_batch", "c12381_g2_mul_batch_dev", "c12381_g2_add_batch"):
+            getattr(lib, name).argtypes = [vp, sz, vp, vp, vp, ci]
+        for name in ("c12381_pair_batch", "c12381_pair_batch_dev"):
+            getattr(lib, name).argtypes = [vp, sz, vp, vp, vp]
+        for name in ("c12381_pair_eq_batch", "c12381_pair_eq_batch_dev"):
+            getattr(lib, name).argtypes = [vp, sz, vp, vp, vp, vp, vp]
         _lib = lib
     return _lib
 
@@ -131,7 +137,40 @@ class Context:
         self._ck(self.lib.c12381_g1_msm(self.h, n, _p(pts), _p(scalars), _p(out), fmt))
         return out.raw[:fmt]
 
+    def g2_mul(self, pts: bytes, scalars: bytes, fmt: int = 97, strict: bool = True) -> bytes:
+        n = len(pts) // 192
+        out = ctypes.create_string_buffer(max(fmt * n, 1))
+        self._ck(self.lib.c12381_g2_mul_batch(self.h, n, _p(pts), _p(scalars), _p(out), fmt), allow_point=not strict)
+        return out.raw[:fmt * n]
+
+    def g2_add(self, a: bytes, b: bytes, fmt: int = 192, strict: bool = True) -> bytes:
+        n = len(a) // 192
+        out = ctypes.create_string_buffer(max(fmt * n, 1))
+        self._ck(self.lib.c12381_g2_add_batch(self.h, n, _p(a), _p(b), _p(out), fmt), allow_point=not strict)
+        return out.raw[:fmt * n]
+
+    def pair(self, g1: bytes, g2: bytes, strict: bool = True) -> bytes:
+        n = len(g1) // 96
+        out = ctypes.create_string_buffer(max(576 * n, 1))
+        self._ck(self.lib.c12381_pair_batch(self.h, n, _p(g1), _p(g2), _p(out)), allow_point=not strict)
+        return out.raw[:576 * n]
+
+    def pair_eq(self, a1: bytes, a2: bytes, b1: bytes, b2: bytes, strict: bool = True) -> bytes:
+        n = len(a1) // 96
+        out = ctypes.create_string_buffer(max(n, 1))
+        self._ck(self.lib.c12381_pair_eq_batch(self.h, n, _p(a1), _p(a2), _p(b1), _p(b2), _p(out)), allow_point=not strict)
+        return out.raw[:n]
+
     # ---- device-pointer entry points (ints = device addresses, e.g. torch tensor.data_ptr())
+    def g2_mul_dev(self, n, pts_ptr, sc_ptr, out_ptr, fmt=97):
+        self._ck(self.lib.c12381_g2_mul_batch_dev(self.h, n, _p(pts_ptr), _p(sc_ptr), _p(out_ptr), fmt))
+
+    def pair_dev(self, n, g1_ptr, g2_ptr, gt_ptr):
+        self._ck(self.lib.c12381_pair_batch_dev(self.h, n, _p(g1_ptr), _p(g2_ptr), _p(gt_ptr)))
+
+    def pair_eq_dev(self, n, a1, a2, b1, b2, ok_ptr):
+        self._ck(self.lib.c12381_pair_eq_batch_dev(self.h, n, _p(a1), _p(a2), _p(b1), _p(b2), _p(ok_ptr)))
+
     def fp_mulchain_dev(self, n, iters, a_ptr, b_ptr, out_ptr):
         self._ck(self.lib.c12381_fp_mulchain_dev(self.h, n, iters, _p(a_ptr), _p(b_ptr), _p(out_ptr)))
 

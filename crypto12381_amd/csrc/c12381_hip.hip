@@ -8,6 +8,10 @@
 //   g1_finish_kernel   Montgomery's simultaneous inversion over a strided chunk per lane,
 //                      affine conversion, canonical encoding (49 B / 96 B)
 //   g1_reduce_kernel   tree sum of projective points (MSM combine)
+//   g2_mul_kernel      bytes -> on-twist check -> windowed [k]Q -> affine -> 97 B / 192 B
+//   g2_add_kernel      complete addition of two affine G2 inputs
+//   pair_kernel        Miller loop + final exponentiation -> 576-byte GT
+//   pair_eq_kernel     e(a1,a2) == e(b1,b2): two Miller loops, ONE final exponentiation, is-unity
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -20,6 +24,8 @@
 #include "codec.hpp"
 #include "fp.hpp"
 #include "g1.hpp"
+#include "g2.hpp"
+#include "pairing.hpp"
 
 using namespace c12381;
 
@@ -27,6 +33,7 @@ namespace {
 
 constexpr int BLOCK = 256;
 constexpr size_t G1_CHUNK = (size_t)1 << 18;     // elements per scalar-mul launch (table slab = 704 MiB)
+constexpr size_t G2_CHUNK = (size_t)1 << 17;     // G2 table slab = 704 MiB
 constexpr int FINISH_M = 16;                     // elements per lane in the simultaneous inversion
 
 // ------------------------------------------------------------------ device helpers
@@ -226,6 +233,140 @@ __global__ void __launch_bounds__(BLOCK) g1_reduce_kernel(size_t n, const int32_
         acc = nn;
     }
     soa_store_g1(outp, out_stride, j, acc);
+}
+
+// ------------------------------------------------------------------ G2 / pairing kernels
+__device__ __forceinline__ void fp2_load_raw96(fp2& r, const uint8_t* p) {       // b || a
+    uint32_t raw[24];
+    load_raw48(raw, p); load_raw48(raw + 12, p + 48);
+    fp_from_raw48(r.b, raw); fp_from_raw48(r.a, raw + 12);
+}
+__device__ __forceinline__ void fp2_store_raw96(uint8_t* p, const fp2& x) {
+    uint32_t raw[12];
+    fp_to_raw48(raw, x.b); store_raw48(p, raw);
+    fp_to_raw48(raw, x.a); store_raw48(p + 48, raw);
+}
+// y^2 == x^3 + 4(1+i)  (ECP2_set ecp2_BLS12381.cpp:299, ECP2_rhs :270-296)
+__device__ __noinline__ bool g2_on_curve(const fp2& x, const fp2& y) {
+    fp2 x2, x3, y2, b, d;
+    fp2_sqr(x2, x); fp2_mul(x3, x2, x);
+    fp_set_const(b.a, FP_FOUR); fp_set_const(b.b, FP_FOUR);        // 4(1+i) = 4 + 4i
+    fp2_add(x3, x3, b);
+    fp2_sqr(y2, y);
+    fp2_sub(d, y2, x3);
+    return fp2_is_zero(d);
+}
+__device__ __forceinline__ void g2_parse192(fp2& x, fp2& y, bool& inf, bool& ok, const uint8_t* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { uint4 v = q[i]; o |= v.x | v.y | v.z | v.w; }
+    inf = o == 0;
+    fp2_load_raw96(x, p); fp2_load_raw96(y, p + 96);
+    ok = inf || g2_on_curve(x, y);
+}
+// affine + canonical encoding of one projective G2 point (per-lane inversion)
+__device__ __noinline__ void g2_store_affine(uint8_t* o, const g2p& acc, int fmt, bool invalid) {
+    const bool inf = fp2_is_zero(acc.z);
+    fp2 zn, zi, ax, ay, one;
+    fp2_one(one);
+    fp2_norm1(zn, acc.z);
+    fp2_select(zn, inf, one, zn);
+    fp2_inv(zi, zn);
+    fp2_mul(ax, acc.x, zi); fp2_mul(ay, acc.y, zi);
+    if (inf || invalid) {
+        const uint32_t fill = invalid ? 0xffffffffu : 0u;
+        if (fmt == 192) { uint4* q = reinterpret_cast<uint4*>(o); for (int i = 0; i < 12; ++i) q[i] = make_uint4(fill, fill, fill, fill); }
+        else { for (int i = 0; i < 97; ++i) o[i] = (uint8_t)fill; }
+        return;
+    }
+    if (fmt == 192) { fp2_store_raw96(o, ax); fp2_store_raw96(o + 96, ay); }
+    else {
+        o[0] = (uint8_t)(0x02 | fp2_sign(ay));
+        uint32_t raw[24];
+        fp_to_raw48(raw, ax.b); fp_to_raw48(raw + 12, ax.a);
+        for (int j = 0; j < 24; ++j) { const uint32_t v = raw[j]; o[1 + 4 * j] = (uint8_t)v; o[2 + 4 * j] = (uint8_t)(v >> 8); o[3 + 4 * j] = (uint8_t)(v >> 16); o[4 + 4 * j] = (uint8_t)(v >> 24); }
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK) g2_mul_kernel(size_t n, const uint8_t* pts, const uint8_t* scalars, int32_t* tab, size_t tab_stride,
+                                                       uint8_t* out, int fmt, int* bad_flag) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    fp2 qx, qy;
+    bool inf, ok;
+    g2_parse192(qx, qy, inf, ok, pts + 192 * i);
+    uint32_t raw[8], k[8];
+    load_raw32(raw, scalars + 32 * i);
+    scalar_from_raw32(k, raw);
+    g2p acc;
+    g2_scalar_mul(acc, qx, qy, inf || !ok, k, tab, tab_stride, i);
+    if (!ok) *bad_flag = 1;
+    g2_store_affine(out + (size_t)fmt * i, acc, fmt, !ok);
+}
+
+__global__ void __launch_bounds__(BLOCK) g2_add_kernel(size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out, int fmt, int* bad_flag) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    g2p p, q, inf_pt;
+    bool ia, oa, ib, ob;
+    g2_parse192(p.x, p.y, ia, oa, a + 192 * i); fp2_one(p.z);
+    g2_parse192(q.x, q.y, ib, ob, b + 192 * i); fp2_one(q.z);
+    g2_set_inf(inf_pt);
+    fp2_select(p.x, ia, inf_pt.x, p.x); fp2_select(p.y, ia, inf_pt.y, p.y); fp2_select(p.z, ia, inf_pt.z, p.z);
+    fp2_select(q.x, ib, inf_pt.x, q.x); fp2_select(q.y, ib, inf_pt.y, q.y); fp2_select(q.z, ib, inf_pt.z, q.z);
+    g2_add(p, q);
+    const bool ok = oa && ob;
+    if (!ok) *bad_flag = 1;
+    g2_store_affine(out + (size_t)fmt * i, p, fmt, !ok);
+}
+
+__device__ __forceinline__ void gt_store576(uint8_t* o, const fp12& f, bool invalid) {
+#pragma unroll 1
+    for (int j = 0; j < 12; ++j) {
+        uint32_t raw[12];
+        fp_to_raw48(raw, fp12_coord(f, j));
+        if (invalid) { for (int t = 0; t < 12; ++t) raw[t] = 0xffffffffu; }
+        store_raw48(o + 48 * j, raw);
+    }
+}
+__device__ __noinline__ void pair_inputs(fp& px, fp& py, bool& pinf, fp2& qx, fp2& qy, bool& qinf, bool& ok, const uint8_t* g1, const uint8_t* g2) {
+    bool ok1, ok2;
+    g1_parse96(px, py, pinf, ok1, g1);
+    g2_parse192(qx, qy, qinf, ok2, g2);
+    ok = ok1 && ok2;
+}
+
+__global__ void __launch_bounds__(BLOCK) pair_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    fp px, py; fp2 qx, qy; bool pinf, qinf, ok;
+    pair_inputs(px, py, pinf, qx, qy, qinf, ok, g1 + 96 * i, g2 + 192 * i);
+    if (!ok) { *bad_flag = 1; pinf = true; qinf = true; }
+    fp12 f;
+    miller_loop(f, px, py, pinf, qx, qy, qinf);
+    final_exp(f);
+    gt_store576(gt + 576 * i, f, !ok);
+}
+
+__global__ void __launch_bounds__(BLOCK) pair_eq_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2,
+                                                        uint8_t* out, int* bad_flag) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    fp px, py; fp2 qx, qy; bool pinf, qinf, ok, okb;
+    fp12 f, g, t;
+    pair_inputs(px, py, pinf, qx, qy, qinf, ok, a1 + 96 * i, a2 + 192 * i);
+    if (!ok) { pinf = true; qinf = true; }
+    miller_loop(f, px, py, pinf, qx, qy, qinf);
+    pair_inputs(px, py, pinf, qx, qy, qinf, okb, b1 + 96 * i, b2 + 192 * i);
+    if (!okb) { pinf = true; qinf = true; }
+    miller_loop(g, px, py, pinf, qx, qy, qinf);
+    fp12_conj(t, g);
+    fp12_mul(g, f, t);
+    final_exp(g);
+    const bool valid = ok && okb;
+    if (!valid) *bad_flag = 1;
+    out[i] = valid ? (fp12_is_one(g) ? 1 : 0) : 0xff;
 }
 
 }  // namespace
@@ -503,6 +644,95 @@ int c12381_g1_msm(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc
     if ((rc = stage_in(c, s, pts, 96 * n, sc, 32 * n, (size_t)fmt))) return rc;
     if ((rc = c12381_g1_msm_dev(c, n, s.in0, s.in1, s.out, fmt))) return rc;
     if ((rc = stage_out(c, s, out, (size_t)fmt))) return rc;
+    return read_flag(c);
+}
+
+// ---------------------------------------------------------------- G2
+int c12381_g2_mul_batch_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
+    int rc = bind(c); if (rc) return rc;
+    if (!pts || !sc || !out || (fmt != 97 && fmt != 192)) return C12381_E_ARG;
+    if (n == 0) return 0;
+    const size_t chunk = n < G2_CHUNK ? round_up(n, 64) : G2_CHUNK;
+    if ((rc = ensure(c, c12381_ctx::WS_TAB, (size_t)G2_TAB_DWORDS * chunk * 4))) return rc;
+    for (size_t off = 0; off < n; off += chunk) {
+        const size_t m = n - off < chunk ? n - off : chunk;
+        timed tm(c, 2);
+        hipLaunchKernelGGL(g2_mul_kernel, dim3(grid_for(m)), dim3(BLOCK), 0, c->stream, m, pts + 192 * off, sc + 32 * off,
+                           (int32_t*)c->ws[c12381_ctx::WS_TAB], chunk, out + (size_t)fmt * off, fmt, c->d_flag);
+        HIPCK(c, hipGetLastError());
+    }
+    return 0;
+}
+int c12381_g2_mul_batch(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
+    int rc = bind(c); if (rc) return rc;
+    if (!pts || !sc || !out || (fmt != 97 && fmt != 192)) return C12381_E_ARG;
+    if (n == 0) return 0;
+    staged s;
+    if ((rc = stage_in(c, s, pts, 192 * n, sc, 32 * n, (size_t)fmt * n))) return rc;
+    if ((rc = c12381_g2_mul_batch_dev(c, n, s.in0, s.in1, s.out, fmt))) return rc;
+    if ((rc = stage_out(c, s, out, (size_t)fmt * n))) return rc;
+    return read_flag(c);
+}
+int c12381_g2_add_batch(c12381_ctx* c, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out, int fmt) {
+    int rc = bind(c); if (rc) return rc;
+    if (!a || !b || !out || (fmt != 97 && fmt != 192)) return C12381_E_ARG;
+    if (n == 0) return 0;
+    staged s;
+    if ((rc = stage_in(c, s, a, 192 * n, b, 192 * n, (size_t)fmt * n))) return rc;
+    hipLaunchKernelGGL(g2_add_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, s.in0, s.in1, s.out, fmt, c->d_flag);
+    HIPCK(c, hipGetLastError());
+    if ((rc = stage_out(c, s, out, (size_t)fmt * n))) return rc;
+    return read_flag(c);
+}
+
+// ---------------------------------------------------------------- pairing
+int c12381_pair_batch_dev(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt) {
+    int rc = bind(c); if (rc) return rc;
+    if (!g1 || !g2 || !gt) return C12381_E_ARG;
+    if (n == 0) return 0;
+    timed tm(c, 3);
+    hipLaunchKernelGGL(pair_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+int c12381_pair_batch(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt) {
+    int rc = bind(c); if (rc) return rc;
+    if (!g1 || !g2 || !gt) return C12381_E_ARG;
+    if (n == 0) return 0;
+    staged s;
+    if ((rc = stage_in(c, s, g1, 96 * n, g2, 192 * n, 576 * n))) return rc;
+    if ((rc = c12381_pair_batch_dev(c, n, s.in0, s.in1, s.out))) return rc;
+    if ((rc = stage_out(c, s, gt, 576 * n))) return rc;
+    return read_flag(c);
+}
+int c12381_pair_eq_batch_dev(c12381_ctx* c, size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, uint8_t* ok) {
+    int rc = bind(c); if (rc) return rc;
+    if (!a1 || !a2 || !b1 || !b2 || !ok) return C12381_E_ARG;
+    if (n == 0) return 0;
+    timed tm(c, 4);
+    hipLaunchKernelGGL(pair_eq_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, a1, a2, b1, b2, ok, c->d_flag);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+int c12381_pair_eq_batch(c12381_ctx* c, size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, uint8_t* ok) {
+    int rc = bind(c); if (rc) return rc;
+    if (!a1 || !a2 || !b1 || !b2 || !ok) return C12381_E_ARG;
+    if (n == 0) return 0;
+    int r2;
+    if ((r2 = ensure(c, c12381_ctx::WS_IN0, round_up(96 * n, 256)))) return r2;
+    if ((r2 = ensure(c, c12381_ctx::WS_IN1, round_up(192 * n, 256)))) return r2;
+    if ((r2 = ensure(c, c12381_ctx::WS_RED0, round_up(96 * n, 256)))) return r2;
+    if ((r2 = ensure(c, c12381_ctx::WS_RED1, round_up(192 * n, 256)))) return r2;
+    if ((r2 = ensure(c, c12381_ctx::WS_OUT, round_up(n, 256)))) return r2;
+    uint8_t* d_a1 = (uint8_t*)c->ws[c12381_ctx::WS_IN0]; uint8_t* d_a2 = (uint8_t*)c->ws[c12381_ctx::WS_IN1];
+    uint8_t* d_b1 = (uint8_t*)c->ws[c12381_ctx::WS_RED0]; uint8_t* d_b2 = (uint8_t*)c->ws[c12381_ctx::WS_RED1];
+    uint8_t* d_ok = (uint8_t*)c->ws[c12381_ctx::WS_OUT];
+    HIPCK(c, hipMemcpyAsync(d_a1, a1, 96 * n, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d_a2, a2, 192 * n, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d_b1, b1, 96 * n, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d_b2, b2, 192 * n, hipMemcpyHostToDevice, c->stream));
+    if ((rc = c12381_pair_eq_batch_dev(c, n, d_a1, d_a2, d_b1, d_b2, d_ok))) return rc;
+    HIPCK(c, hipMemcpyAsync(ok, d_ok, n, hipMemcpyDeviceToHost, c->stream));
     return read_flag(c);
 }
 

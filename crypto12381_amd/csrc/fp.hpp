@@ -10,8 +10,8 @@
 //     v_mad_i64_i32 (measured on MI355X at ~the v_add rate, profiles/r01_valu_rates.txt),
 //     Montgomery reduction interleaved in the same columns — no carry flags anywhere.
 //   * invariants are tracked as two bounds per element: LB = max |limb| and VB = |value|/p.
-//     fp_mul needs 14*LBa*LBb + 14*2^56 + 2^40 < 2^63 and VBa*VBb <= 2^11 and returns
-//     limbs 0..12 in [0,2^28), value in (-p, 2p).  Builds with C12381_CHECK_BOUNDS (host
+//     fp_mul needs 14*LBa*LBb + 14*2^56 + 2^40 < 2^63 and returns limbs 0..12 in [0,2^28) with
+//     |value| < (VBa*VBb*p/R + 1) p, i.e. within (-p, 2p) whenever VBa*VBb <= 2^11.  Builds with C12381_CHECK_BOUNDS (host
 //     simulation used by the CPU tests) carry the bounds at run time and assert them; the
 //     bounds depend only on the operation sequence, never on the data.
 #pragma once
@@ -20,9 +20,11 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define C12381_HD __host__ __device__ __forceinline__
+#define C12381_HDN __host__ __device__ __noinline__ inline      // big tower/curve routines: real calls, operands in scratch
 #define C12381_CONST __device__ constexpr
 #else
 #define C12381_HD inline
+#define C12381_HDN inline
 #define C12381_CONST constexpr
 #endif
 
@@ -32,6 +34,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
+#include <execinfo.h>
 #define C12381_BOUNDS(...) __VA_ARGS__
 #else
 #define C12381_BOUNDS(...)
@@ -49,6 +52,9 @@ struct fp {
 #ifdef C12381_CHECK_BOUNDS
 inline void bounds_fail(const char* what, double a, double b) {
     std::fprintf(stderr, "C12381 bound violation: %s (%.4g, %.4g)\n", what, a, b);
+    void* frames[48];
+    int nf = backtrace(frames, 48);
+    backtrace_symbols_fd(frames, nf, 2);      // resolve with addr2line -e libsim.so <offsets> (build with -g)
     std::abort();
 }
 constexpr double P_OVER_R = 0.000396;          // p / 2^392 < this
@@ -131,13 +137,35 @@ C12381_HD void fp_mul_small(fp& r, const fp& a, int32_t k) {
                     set_bounds(r, top > 268435456.0 ? top : 268435456.0, a.vb * k, "fp_mul_small"); })
 }
 
+// Weak reduction: subtract the multiple q*p suggested by the top limb so that |value| drops to
+// about p/2 + 2^365, and renormalise all limbs exactly (sequential carries).  ~90 simple ops — used
+// where a value is carried through additions only (no product to re-bound it), e.g. the linear
+// terms of the cyclotomic squaring.  Plays the role of FP_reduce fp_BLS12381.cpp:549-579.
+C12381_HD void fp_weak_reduce(fp& r, const fp& a) {
+    fp n;
+    fp_norm1(n, a);
+    // q ~ value / p ~ top / 106513.08  (2^32 / 106513.08 = 40323.6); off-by-one is harmless
+    const int32_t q = (int32_t)(((int64_t)n.l[NL - 1] * 40324 + ((int64_t)1 << 31)) >> 32);
+    int64_t t = 0;
+#pragma unroll
+    for (int i = 0; i < NL - 1; ++i) {
+        t += (int64_t)n.l[i] - (int64_t)q * FP_P[i];
+        r.l[i] = (int32_t)((uint32_t)t & LMASK);
+        t >>= LB;
+    }
+    t += (int64_t)n.l[NL - 1] - (int64_t)q * FP_P[NL - 1];
+    r.l[NL - 1] = (int32_t)t;
+    C12381_BOUNDS({ if (a.vb > 2400.0) bounds_fail("fp_weak_reduce input value bound", a.vb, 0);
+                    set_bounds(r, 268435456.0, 1.6, "fp_weak_reduce"); })
+}
+
 // ------------------------------------------------------------------ Montgomery multiply / square
 #ifdef C12381_CHECK_BOUNDS
 inline void check_mul_operands(const fp& a, const fp& b, const char* where) {
     check_actual(a, where); check_actual(b, where);
     double col = 14.0 * a.lb * b.lb + 14.0 * 72057594037927936.0 + 1099511627776.0;
     if (col >= 9223372036854775808.0) bounds_fail(where, a.lb, b.lb);
-    if (a.vb * b.vb > 2048.0) bounds_fail("fp_mul value bound", a.vb, b.vb);
+    if (a.vb * b.vb > 1.0e6) bounds_fail("fp_mul value bound", a.vb, b.vb);   // keeps |result| < 400 p; the exact bound is tracked in vb
 }
 #endif
 
@@ -213,6 +241,70 @@ C12381_HD void fp_sqr(fp& r, const fp& a) {
                     double top = vb * TOP_PER_P + 2.0;
                     set_bounds(r, top > 268435456.0 ? top : 268435456.0, vb, "fp_sqr"); })
 }
+
+// ------------------------------------------------------------------ lazy reduction: sums of products
+// One Montgomery reduction for a whole bilinear form  r = (sum_t +-A_t*B_t) / R mod p
+// (the reference's FP2_mul does the same trick with double-length BIGs, fp2_BLS12381.cpp:266-302).
+// `col(k)` returns the k-th column  sum_{i+j=k} (...)  of the un-reduced form, k = 0..26; the
+// engine interleaves the reduction exactly like fp_mul.  Column sums must stay below 2^63:
+// with |limbs| <= LBa, LBb that is  14 * T * LBa * LBb + 14 * 2^56 + 2^40 < 2^63  for T products.
+C12381_HD int64_t fp_col(const fp& a, const fp& b, int k) {
+    int64_t x = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int j = k - i;
+        if (j >= 0 && j < NL) x += (int64_t)a.l[i] * b.l[j];
+    }
+    return x;
+}
+C12381_HD int64_t fp_col_sqr(const fp& a, int k) {
+    int64_t x = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int j = k - i;
+        if (j > i && j < NL) x += (int64_t)a.l[i] * a.l[j];
+    }
+    x *= 2;
+    if ((k & 1) == 0 && k / 2 < NL) x += (int64_t)a.l[k / 2] * a.l[k / 2];
+    return x;
+}
+template <class ColFn>
+C12381_HD void fp_reduce_cols(fp& r, ColFn col) {
+    int32_t m[NL];
+    int32_t out[NL];
+    int64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        acc += col(k);
+#pragma unroll
+        for (int i = 0; i < k; ++i) acc += (int64_t)m[i] * FP_P[k - i];
+        m[k] = (int32_t)(((uint32_t)acc * FP_N0) & LMASK);
+        acc += (int64_t)m[k] * FP_P[0];
+        acc >>= LB;
+    }
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; ++k) {
+        acc += col(k);
+#pragma unroll
+        for (int i = k - NL + 1; i < NL; ++i) acc += (int64_t)m[i] * FP_P[k - i];
+        out[k - NL] = (int32_t)((uint32_t)acc & LMASK);
+        acc >>= LB;
+    }
+    out[NL - 1] = (int32_t)acc;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = out[i];
+}
+#ifdef C12381_CHECK_BOUNDS
+// declare the bounds of a lazily reduced form: sum_lblb = sum over products of LBa*LBb, sum_vbvb likewise
+inline void set_lazy_bounds(fp& r, double sum_lblb, double sum_vbvb, const char* where) {
+    double col = 14.0 * sum_lblb + 14.0 * 72057594037927936.0 + 1099511627776.0;
+    if (col >= 9223372036854775808.0) bounds_fail(where, sum_lblb, sum_vbvb);
+    if (sum_vbvb > 1.0e6) bounds_fail("lazy form value bound", sum_vbvb, 0);
+    double vb = sum_vbvb * P_OVER_R + 1.0;
+    double top = vb * TOP_PER_P + 2.0;
+    set_bounds(r, top > 268435456.0 ? top : 268435456.0, vb, where);
+}
+#endif
 
 // ------------------------------------------------------------------ canonical form, tests
 // Leaves Montgomery form and fully reduces: r = a / R mod p as canonical limbs in [0, p).
@@ -290,7 +382,7 @@ C12381_HD int fp_sign(const fp& a) {
 // ------------------------------------------------------------------ fixed exponentiations
 // r = a^e for a public 384-bit exponent, 4-bit fixed window (exponent is a compile-time
 // table in constant memory, so the schedule is identical in every lane).
-C12381_HD void fp_pow_fixed(fp& r, const fp& a, const uint32_t (&e)[12]) {
+C12381_HDN void fp_pow_fixed(fp& r, const fp& a, const uint32_t (&e)[12]) {
     fp tab[16];
     fp_one(tab[0]);
     {

@@ -1,0 +1,213 @@
+// Fp4 = Fp2[s]/(s^2 - (1+i)) and Fp12 = Fp4[w]/(w^3 - s): the reference's 2-2-3 tower
+// (config_field_BLS12381.h:32,36; fp4_BLS12381.cpp:243-364; fp12_BLS12381.cpp:117-939), kept on the
+// device so that GT values need no basis change before their canonical 576-byte encoding.
+//
+// Bound contract of this layer (asserted by the host simulation): every fp4/fp12 function takes
+// NORMALISED components (limb bound ~2^28) and returns normalised components; inside a function
+// additions are lazy and one parallel carry round (fp_norm1) is inserted exactly where a sum feeds
+// a multiplication.  Fp2 products are lazily reduced (fp2.hpp).
+#pragma once
+#include "fp2.hpp"
+
+namespace c12381 {
+
+struct fp4 { fp2 a, b; };            // a + b*s
+struct fp12 { fp4 a, b, c; };        // a + b*w + c*w^2
+
+// ------------------------------------------------------------------ Fp4
+C12381_HD void fp4_add(fp4& r, const fp4& x, const fp4& y) { fp2_add(r.a, x.a, y.a); fp2_add(r.b, x.b, y.b); }
+C12381_HD void fp4_sub(fp4& r, const fp4& x, const fp4& y) { fp2_sub(r.a, x.a, y.a); fp2_sub(r.b, x.b, y.b); }
+C12381_HD void fp4_neg(fp4& r, const fp4& x) { fp2_neg(r.a, x.a); fp2_neg(r.b, x.b); }
+C12381_HD void fp4_norm1(fp4& r, const fp4& x) { fp2_norm1(r.a, x.a); fp2_norm1(r.b, x.b); }
+C12381_HD void fp4_conj(fp4& r, const fp4& x) { r.a = x.a; fp2_neg(r.b, x.b); }            // FP4_conj :162
+C12381_HD void fp4_nconj(fp4& r, const fp4& x) { fp2_neg(r.a, x.a); r.b = x.b; }           // FP4_nconj :171
+C12381_HD void fp4_zero(fp4& r) { fp2_zero(r.a); fp2_zero(r.b); }
+C12381_HD void fp4_select(fp4& r, bool c, const fp4& x, const fp4& y) { fp2_select(r.a, c, x.a, y.a); fp2_select(r.b, c, x.b, y.b); }
+// multiply by s (FP4_times_i :343): (a + b s) s = (1+i) b + a s      — lazy (limb bound of .a doubles)
+C12381_HD void fp4_times_i(fp4& r, const fp4& x) {
+    fp2 t;
+    fp2_mul_ip(t, x.b);
+    r.b = x.a;
+    r.a = t;
+}
+// FP4_mul :274-304.  3 Fp2 products.
+C12381_HDN void fp4_mul(fp4& w, const fp4& x, const fp4& y) {
+    fp2 t1, t2, t3, t4;
+    fp2_mul(t1, x.a, y.a);
+    fp2_mul(t2, x.b, y.b);
+    fp2_add(t3, y.b, y.a);
+    fp2_add(t4, x.b, x.a);
+    fp2_mul(t4, t4, t3);
+    fp2_sub(t4, t4, t1);
+    fp2_sub(t4, t4, t2);
+    fp2_mul_ip(t3, t2);
+    fp2_add(t3, t3, t1);
+    fp2_norm1(w.b, t4);
+    fp2_norm1(w.a, t3);
+}
+// FP4_sqr :243-271.  2 Fp2 products.
+C12381_HDN void fp4_sqr(fp4& w, const fp4& x) {
+    fp2 t1, t2, t3, wa;
+    fp2_mul(t3, x.a, x.b);
+    fp2_add(t1, x.a, x.b);
+    fp2_mul_ip(t2, x.b);
+    fp2_add(t2, x.a, t2);
+    fp2_norm1(t2, t2);
+    fp2_mul(wa, t1, t2);
+    fp2_mul_ip(t2, t3);
+    fp2_add(t2, t2, t3);
+    fp2_sub(wa, wa, t2);
+    fp2_dbl(t3, t3);
+    fp2_norm1(w.a, wa);
+    fp2_norm1(w.b, t3);
+}
+// FP4_inv :326-340
+C12381_HDN void fp4_inv(fp4& w, const fp4& x) {
+    fp2 t1, t2;
+    fp2_sqr(t1, x.a);
+    fp2_sqr(t2, x.b);
+    fp2_mul_ip(t2, t2);
+    fp2_sub(t1, t1, t2);
+    fp2_norm1(t1, t1);
+    fp2_inv(t1, t1);
+    fp2_mul(w.a, t1, x.a);
+    fp2_neg(t1, t1);
+    fp2_mul(w.b, t1, x.b);
+}
+// FP4_frob :359-364 with f = FROB_F3 supplied by the caller
+C12381_HD void fp4_frob(fp4& w, const fp4& x, const fp2& f) {
+    fp2_conj(w.a, x.a);
+    fp2 t;
+    fp2_conj(t, x.b);
+    fp2_mul(w.b, f, t);
+}
+C12381_HD void fp4_pmul(fp4& w, const fp4& x, const fp2& s) { fp2_mul(w.a, x.a, s); fp2_mul(w.b, x.b, s); }   // FP4_pmul :210
+
+// ------------------------------------------------------------------ Fp12
+C12381_HD void fp12_one(fp12& w) { fp4_zero(w.a); fp4_zero(w.b); fp4_zero(w.c); fp_one(w.a.a.a); }
+C12381_HD void fp12_conj(fp12& w, const fp12& x) { fp4_conj(w.a, x.a); fp4_nconj(w.b, x.b); fp4_conj(w.c, x.c); }   // FP12_conj :117
+C12381_HD void fp12_select(fp12& r, bool c, const fp12& x, const fp12& y) {
+    fp4_select(r.a, c, x.a, y.a); fp4_select(r.b, c, x.b, y.b); fp4_select(r.c, c, x.c, y.c);
+}
+C12381_HD void fp4_addn(fp4& r, const fp4& x, const fp4& y) { fp4 t; fp4_add(t, x, y); fp4_norm1(r, t); }
+C12381_HD void fp2_weak_reduce(fp2& r, const fp2& x) { fp_weak_reduce(r.a, x.a); fp_weak_reduce(r.b, x.b); }
+C12381_HD void fp4_weak_reduce(fp4& r, const fp4& x) { fp2_weak_reduce(r.a, x.a); fp2_weak_reduce(r.b, x.b); }
+C12381_HDN void fp12_weak_reduce(fp12& r, const fp12& x) { fp4_weak_reduce(r.a, x.a); fp4_weak_reduce(r.b, x.b); fp4_weak_reduce(r.c, x.c); }
+
+// FP12_mul :246-299 (Karatsuba over Fp4: 6 Fp4 products = 18 Fp2 products)
+C12381_HDN void fp12_mul(fp12& w, const fp12& x, const fp12& y) {
+    fp4 z0, z1, z2, z3, t0, t1, wb;
+    fp4_mul(z0, x.a, y.a);
+    fp4_mul(z2, x.b, y.b);
+    fp4_addn(t0, x.a, x.b); fp4_addn(t1, y.a, y.b); fp4_mul(z1, t0, t1);
+    fp4_addn(t0, x.b, x.c); fp4_addn(t1, y.b, y.c); fp4_mul(z3, t0, t1);
+    fp4_sub(z1, z1, z0); fp4_sub(wb, z1, z2);
+    fp4_sub(z3, z3, z2);
+    fp4_sub(z2, z2, z0);
+    fp4_addn(t0, x.a, x.c); fp4_addn(t1, y.a, y.c); fp4_mul(t0, t1, t0);
+    fp4_add(z2, z2, t0);
+    fp4_mul(t0, x.c, y.c);
+    fp4_sub(z2, z2, t0);
+    fp4_sub(z3, z3, t0);
+    fp4_times_i(t1, t0); fp4_add(wb, wb, t1);
+    fp4_norm1(z3, z3); fp4_times_i(t1, z3); fp4_add(z0, z0, t1);
+    fp4_norm1(w.a, z0); fp4_norm1(w.b, wb); fp4_norm1(w.c, z2);
+}
+// FP12_sqr :190-238 (Chung-Hasan SQR2: 3 Fp4 squarings + 2 Fp4 products)
+C12381_HDN void fp12_sqr(fp12& w, const fp12& x) {
+    fp4 A, B, C, D, S, t;
+    fp4_sqr(A, x.a);
+    fp4_mul(B, x.b, x.c);
+    fp4_sqr(C, x.c);
+    fp4_mul(D, x.a, x.b);
+    fp4_add(t, x.a, x.c); fp4_add(t, t, x.b); fp4_norm1(t, t);
+    fp4_sqr(S, t);
+    fp4_add(B, B, B); fp4_add(D, D, D);
+    // wc = S - (A + B + C + D)
+    fp4_add(t, A, B); fp4_add(t, t, C); fp4_add(t, t, D);
+    fp4_sub(S, S, t);
+    fp4 sB, sC;
+    fp4_times_i(sB, B); fp4_times_i(sC, C);
+    fp4_add(A, A, sB);
+    fp4_add(D, D, sC);
+    fp4_norm1(w.a, A); fp4_norm1(w.b, D); fp4_norm1(w.c, S);
+}
+// FP12_usqr :147-186 (Granger-Scott; equals sqr only for unitary elements)
+C12381_HDN void fp12_usqr(fp12& w, const fp12& x) {
+    fp4 A, B, C, t, wa, wb, wc;
+    fp4_sqr(wa, x.a);
+    fp4_add(t, wa, wa); fp4_add(wa, t, wa);                    // 3 xa^2
+    fp4_nconj(A, x.a); fp4_add(A, A, A); fp4_add(wa, wa, A);   // - 2 conj(xa)
+    fp4_sqr(B, x.c); fp4_times_i(t, B); fp4_norm1(t, t); fp4_add(B, t, t); fp4_add(B, B, t);      // 3 s xc^2
+    fp4_sqr(C, x.b); fp4_add(t, C, C); fp4_add(C, C, t);                         // 3 xb^2
+    fp4_conj(wb, x.b); fp4_add(wb, wb, wb);
+    fp4_nconj(wc, x.c); fp4_add(wc, wc, wc);
+    fp4_add(wb, B, wb); fp4_add(wc, C, wc);
+    fp4_norm1(w.a, wa); fp4_norm1(w.b, wb); fp4_norm1(w.c, wc);
+}
+// FP12_inv :627-664
+C12381_HDN void fp12_inv(fp12& w, const fp12& x) {
+    fp4 f0, f1, f2, f3, t;
+    fp4_sqr(f0, x.a); fp4_mul(f1, x.b, x.c); fp4_times_i(t, f1); fp4_sub(f0, f0, t); fp4_norm1(f0, f0);
+    fp4_sqr(f1, x.c); fp4_times_i(t, f1); fp4_mul(f2, x.a, x.b); fp4_sub(f1, t, f2); fp4_norm1(f1, f1);
+    fp4_sqr(f2, x.b); fp4_mul(f3, x.a, x.c); fp4_sub(f2, f2, f3); fp4_norm1(f2, f2);
+    fp4_mul(f3, x.b, f2); fp4_times_i(f3, f3);
+    fp4_mul(t, f0, x.a); fp4_add(f3, t, f3);
+    fp4_mul(t, f1, x.c); fp4_times_i(t, t); fp4_add(f3, t, f3);
+    fp4_norm1(f3, f3);
+    fp4_inv(f3, f3);
+    fp4_norm1(f3, f3);
+    fp4_mul(w.a, f0, f3); fp4_mul(w.b, f1, f3); fp4_mul(w.c, f2, f3);
+}
+// FP12_frob :867-880 (f, f^2, f^3 are compile-time constants)
+C12381_HDN void fp12_frob(fp12& w, const fp12& x) {
+    fp2 f, f2, f3;
+    fp2_set_const(f, FROB_F_A, FROB_F_B);
+    fp2_set_const(f2, FROB_F2_A, FROB_F2_B);
+    fp2_set_const(f3, FROB_F3_A, FROB_F3_B);
+    fp4 a, b, c;
+    fp4_frob(a, x.a, f3); fp4_frob(b, x.b, f3); fp4_frob(c, x.c, f3);
+    fp4_pmul(b, b, f); fp4_pmul(c, c, f2);
+    // conj leaves .a lazily negated only: still normalised
+    w.a = a; w.b = b; w.c = c;
+}
+// f *= line, line = [l0, l1] + [0, l2] w^2  (the M-type sparse element of PAIR_line pair_BLS12381.cpp:129-143;
+// replaces FP12_ssmul's dense x sparser branch fp12_BLS12381.cpp:440-487).  15 Fp2 products.
+C12381_HDN void fp12_mul_line(fp12& f, const fp2& l0, const fp2& l1, const fp2& l2) {
+    fp4 la; la.a = l0; la.b = l1;
+    fp4 pa, pb, pc;
+    fp4_mul(pa, f.a, la); fp4_mul(pb, f.b, la); fp4_mul(pc, f.c, la);
+    fp2 a0, a1, b0, b1, c0, c1;
+    fp2_mul(a0, f.a.a, l2); fp2_mul(a1, f.a.b, l2);
+    fp2_mul(b0, f.b.a, l2); fp2_mul(b1, f.b.b, l2);
+    fp2_mul(c0, f.c.a, l2); fp2_mul(c1, f.c.b, l2);
+    fp2 t;
+    // wa = fa*la + s*(fb*lc),  s*(X*lc) = ((1+i) x0 l2, (1+i) x1 l2)
+    fp2_mul_ip(t, b0); fp2_add(pa.a, pa.a, t);
+    fp2_mul_ip(t, b1); fp2_add(pa.b, pa.b, t);
+    // wb = fb*la + s*(fc*lc)
+    fp2_mul_ip(t, c0); fp2_add(pb.a, pb.a, t);
+    fp2_mul_ip(t, c1); fp2_add(pb.b, pb.b, t);
+    // wc = fc*la + fa*lc,  X*lc = ((1+i) x1 l2, x0 l2)
+    fp2_mul_ip(t, a1); fp2_add(pc.a, pc.a, t);
+    fp2_add(pc.b, pc.b, a0);
+    fp4_norm1(f.a, pa); fp4_norm1(f.b, pb); fp4_norm1(f.c, pc);
+}
+// r = a^|x| for the curve parameter |x| = 0xd201000000010000 (FP12_pow :736-774 specialised to the
+// one exponent the final exponentiation uses; unitary input, so plain square-and-multiply with
+// Granger-Scott squarings gives the same element as the reference's signed-digit ladder).
+C12381_HDN void fp12_pow_x_unitary(fp12& r, const fp12& a) {
+    fp12 w = a;
+#pragma unroll 1
+    for (int i = 62; i >= 0; --i) {
+        fp12 t;
+        fp12_usqr(t, w);
+        // the squaring carries the linear term -2 conj(w): the integer representative doubles each
+        // step, so re-bound it every 2nd step (data-independent schedule)
+        if ((i & 1) == 0) fp12_weak_reduce(w, t); else w = t;
+        if ((BLS_X >> i) & 1ull) { fp12_mul(t, w, a); w = t; }
+    }
+    r = w;
+}
+
+}  // namespace c12381

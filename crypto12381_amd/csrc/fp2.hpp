@@ -1,0 +1,79 @@
+// Fp2 = Fp[i]/(i^2 + 1)  (replaces FP2_mul/FP2_sqr/FP2_inv/FP2_mul_ip/... of the reference's
+// fp2_BLS12381.cpp:185-396).  Element a + b*i.
+//
+// Multiplication and squaring are lazily reduced: each output coordinate is ONE column scan over
+// the sum of its products followed by ONE Montgomery reduction (fp_reduce_cols), so an Fp2 product
+// costs 4 x 196 multiply-adds + 2 reductions and — more important on this machine — its outputs are
+// already normalised (limb bound 2^28) while its inputs may carry limb bound 2^29 (e.g. one lazy
+// add/sub of normalised values) with no carry propagation anywhere in between.
+#pragma once
+#include "fp.hpp"
+
+namespace c12381 {
+
+struct fp2 { fp a, b; };
+
+C12381_HD void fp2_add(fp2& r, const fp2& x, const fp2& y) { fp_add(r.a, x.a, y.a); fp_add(r.b, x.b, y.b); }
+C12381_HD void fp2_sub(fp2& r, const fp2& x, const fp2& y) { fp_sub(r.a, x.a, y.a); fp_sub(r.b, x.b, y.b); }
+C12381_HD void fp2_neg(fp2& r, const fp2& x) { fp_neg(r.a, x.a); fp_neg(r.b, x.b); }
+C12381_HD void fp2_dbl(fp2& r, const fp2& x) { fp_dbl(r.a, x.a); fp_dbl(r.b, x.b); }
+C12381_HD void fp2_conj(fp2& r, const fp2& x) { r.a = x.a; fp_neg(r.b, x.b); }
+C12381_HD void fp2_zero(fp2& r) { fp_zero(r.a); fp_zero(r.b); }
+C12381_HD void fp2_one(fp2& r) { fp_one(r.a); fp_zero(r.b); }
+C12381_HD void fp2_norm1(fp2& r, const fp2& x) { fp_norm1(r.a, x.a); fp_norm1(r.b, x.b); }
+C12381_HD void fp2_select(fp2& r, bool c, const fp2& x, const fp2& y) { fp_select(r.a, c, x.a, y.a); fp_select(r.b, c, x.b, y.b); }
+C12381_HD void fp2_mul_small(fp2& r, const fp2& x, int32_t k) { fp_mul_small(r.a, x.a, k); fp_mul_small(r.b, x.b, k); }
+// multiply by (1 + i)  (FP2_mul_ip :373, QNRI = 0): (a - b) + (a + b) i   — lazy, limb bound doubles
+C12381_HD void fp2_mul_ip(fp2& r, const fp2& x) {
+    fp ta, tb;
+    fp_sub(ta, x.a, x.b);
+    fp_add(tb, x.a, x.b);
+    r.a = ta; r.b = tb;
+}
+C12381_HD bool fp2_is_zero(const fp2& x) { return fp_is_zero(x.a) & fp_is_zero(x.b); }
+
+// r = x * y.  Operand limb bounds: LBx * LBy <= 2^58 (e.g. 2^29 each).  Output normalised.
+C12381_HD void fp2_mul(fp2& r, const fp2& x, const fp2& y) {
+    fp ra, rb;
+    fp_reduce_cols(ra, [&](int k) { return fp_col(x.a, y.a, k) - fp_col(x.b, y.b, k); });
+    fp_reduce_cols(rb, [&](int k) { return fp_col(x.a, y.b, k) + fp_col(x.b, y.a, k); });
+    C12381_BOUNDS({ check_actual(x.a, "fp2_mul"); check_actual(x.b, "fp2_mul"); check_actual(y.a, "fp2_mul"); check_actual(y.b, "fp2_mul");
+                    set_lazy_bounds(ra, x.a.lb * y.a.lb + x.b.lb * y.b.lb, x.a.vb * y.a.vb + x.b.vb * y.b.vb, "fp2_mul.a");
+                    set_lazy_bounds(rb, x.a.lb * y.b.lb + x.b.lb * y.a.lb, x.a.vb * y.b.vb + x.b.vb * y.a.vb, "fp2_mul.b"); })
+    r.a = ra; r.b = rb;
+}
+// r = x^2 = (a^2 - b^2) + 2ab i.  Operand limb bound <= 2^29.
+C12381_HD void fp2_sqr(fp2& r, const fp2& x) {
+    fp ra, rb;
+    fp_reduce_cols(ra, [&](int k) { return fp_col_sqr(x.a, k) - fp_col_sqr(x.b, k); });
+    fp_reduce_cols(rb, [&](int k) { return 2 * fp_col(x.a, x.b, k); });
+    C12381_BOUNDS({ check_actual(x.a, "fp2_sqr"); check_actual(x.b, "fp2_sqr");
+                    set_lazy_bounds(ra, x.a.lb * x.a.lb + x.b.lb * x.b.lb, x.a.vb * x.a.vb + x.b.vb * x.b.vb, "fp2_sqr.a");
+                    set_lazy_bounds(rb, 2 * x.a.lb * x.b.lb, 2 * x.a.vb * x.b.vb, "fp2_sqr.b"); })
+    r.a = ra; r.b = rb;
+}
+// r = x * s for s in Fp  (FP2_pmul :231)
+C12381_HD void fp2_mul_fp(fp2& r, const fp2& x, const fp& s) { fp_mul(r.a, x.a, s); fp_mul(r.b, x.b, s); }
+// r = 1/x  (FP2_inv :334): conj(x) / (a^2 + b^2)
+C12381_HDN void fp2_inv(fp2& r, const fp2& x) {
+    fp n, ni, nb;
+    fp_reduce_cols(n, [&](int k) { return fp_col_sqr(x.a, k) + fp_col_sqr(x.b, k); });
+    C12381_BOUNDS(set_lazy_bounds(n, x.a.lb * x.a.lb + x.b.lb * x.b.lb, x.a.vb * x.a.vb + x.b.vb * x.b.vb, "fp2_inv");)
+    fp_inv(ni, n);
+    fp_mul(r.a, x.a, ni);
+    fp_neg(nb, x.b);
+    fp_mul(r.b, nb, ni);
+}
+// FP2_sign :168-181: parity of a, or of b when a == 0
+C12381_HD int fp2_sign(const fp2& x) {
+    fp ca, cb;
+    fp_from_mont_canonical(ca, x.a);
+    fp_from_mont_canonical(cb, x.b);
+    int32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) o |= ca.l[i];
+    return o == 0 ? (cb.l[0] & 1) : (ca.l[0] & 1);
+}
+C12381_HD void fp2_set_const(fp2& r, const int32_t (&ca)[NL], const int32_t (&cb)[NL]) { fp_set_const(r.a, ca); fp_set_const(r.b, cb); }
+
+}  // namespace c12381

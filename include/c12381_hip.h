@@ -57,7 +57,7 @@ int c12381_set_stream(c12381_ctx* ctx, void* hip_stream);
 int c12381_sync(c12381_ctx* ctx);
 /* Per-kernel timing with HIP events on the context's stream (used by bench.py for the roofline
  * figure).  enable != 0 starts a fresh recording; kind: 0 = G1 scalar-mul kernel, 1 = G1 finish
- * (inversion + encode) kernel.  c12381_profile_read synchronises the stream. */
+ * (inversion + encode) kernel, 2 = G2 scalar-mul kernel, 3 = pairing kernel, 4 = pairing-equality kernel.  c12381_profile_read synchronises the stream. */
 int c12381_profile(c12381_ctx* ctx, int enable);
 int c12381_profile_read(c12381_ctx* ctx, int kind, double* total_ms, uint64_t* launches);
 /* ABI version: major << 16 | minor */
@@ -85,6 +85,29 @@ int c12381_g1_add_batch(c12381_ctx* ctx, size_t n, const uint8_t* a96, const uin
  * sum_of_products(point1&, int, point1*, const big*) :134-137 -> ECP_muln). */
 int c12381_g1_msm(c12381_ctx* ctx, size_t n, const uint8_t* pts96, const uint8_t* scalars32, uint8_t* out, int out_fmt);
 int c12381_g1_msm_dev(c12381_ctx* ctx, size_t n, const uint8_t* pts96, const uint8_t* scalars32, uint8_t* out, int out_fmt);
+
+/* G2 ------------------------------------------------------------------------------------- */
+/* out[i] = scalars[i] * pts[i].  Batched multiply(point2&, const big&) (miracl_core_interface.hpp:152,
+ * src/miracl_core_interface.cpp:202-205 -> PAIR_G2mul) + to_bytes(bytes_view&, point2&, compressed)
+ * (:192-195 -> ECP2_toOctet).  out_fmt = 97 or 192. */
+int c12381_g2_mul_batch(c12381_ctx* ctx, size_t n, const uint8_t* pts192, const uint8_t* scalars32, uint8_t* out, int out_fmt);
+int c12381_g2_mul_batch_dev(c12381_ctx* ctx, size_t n, const uint8_t* pts192, const uint8_t* scalars32, uint8_t* out, int out_fmt);
+/* out[i] = a[i] + b[i].  Batched add(point2&, point2&) (:212-215 -> ECP2_add). */
+int c12381_g2_add_batch(c12381_ctx* ctx, size_t n, const uint8_t* a192, const uint8_t* b192, uint8_t* out, int out_fmt);
+
+/* pairing -------------------------------------------------------------------------------- */
+/* gt[i] = e(g1[i], g2[i]): pair_ate(fp12&, point2&, point1&) + pair_final_exponentiation(fp12&) +
+ * to_bytes(bytes_view&, fp12&) (miracl_core_interface.hpp:199-201,189; src/miracl_core_interface.cpp:
+ * 276-284, 246-249 -> PAIR_ate, PAIR_fexp, FP12_toOctet). */
+int c12381_pair_batch(c12381_ctx* ctx, size_t n, const uint8_t* g1_96, const uint8_t* g2_192, uint8_t* gt576);
+int c12381_pair_batch_dev(c12381_ctx* ctx, size_t n, const uint8_t* g1_96, const uint8_t* g2_192, uint8_t* gt576);
+/* ok[i] = (e(a1[i], a2[i]) == e(b1[i], b2[i])) as the reference's header evaluates it
+ * (liner_pair.hpp:339-350): two pair_ate, conjugate, multiply, ONE pair_final_exponentiation, is_unity.
+ * ok[i] is 1 / 0, or 0xff when an input point of lane i is not on its curve. */
+int c12381_pair_eq_batch(c12381_ctx* ctx, size_t n, const uint8_t* a1_96, const uint8_t* a2_192, const uint8_t* b1_96,
+                         const uint8_t* b2_192, uint8_t* ok);
+int c12381_pair_eq_batch_dev(c12381_ctx* ctx, size_t n, const uint8_t* a1_96, const uint8_t* a2_192, const uint8_t* b1_96,
+                             const uint8_t* b2_192, uint8_t* ok);
 
 #ifdef __cplusplus
 }

@@ -81,3 +81,90 @@ int sim_glv_split(const uint8_t* scalar32, uint32_t* k0, uint32_t* k1) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------- G2 / pairing
+#include "../../crypto12381_amd/csrc/fp2.hpp"
+#include "../../crypto12381_amd/csrc/fp12.hpp"
+#include "../../crypto12381_amd/csrc/g2.hpp"
+#include "../../crypto12381_amd/csrc/pairing.hpp"
+
+static void fp2_from_bytes96(fp2& r, const uint8_t* p) {      // b || a
+    uint32_t raw[24];
+    load_raw(raw, p, 24);
+    fp_from_raw48(r.b, raw); fp_from_raw48(r.a, raw + 12);
+}
+static void fp2_to_bytes96(uint8_t* p, const fp2& x) {
+    uint32_t raw[24];
+    fp_to_raw48(raw, x.b); fp_to_raw48(raw + 12, x.a);
+    std::memcpy(p, raw, 96);
+}
+
+extern "C" {
+
+int sim_g2_mul_batch(size_t n, const uint8_t* pts192, const uint8_t* scalars32, uint8_t* out, int fmt) {
+    std::vector<int32_t> tab(G2_TAB_DWORDS);
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t rp[48], rs[8], k[8];
+        load_raw(rp, pts192 + 192 * i, 48); load_raw(rs, scalars32 + 32 * i, 8);
+        const bool inf = raw_all_zero(rp, 48);
+        fp2 qx, qy;
+        fp2_from_bytes96(qx, pts192 + 192 * i); fp2_from_bytes96(qy, pts192 + 192 * i + 96);
+        scalar_from_raw32(k, rs);
+        g2p acc;
+        g2_scalar_mul(acc, qx, qy, inf, k, tab.data(), 1, 0);
+        uint8_t* o = out + (size_t)fmt * i;
+        if (fp2_is_zero(acc.z)) { std::memset(o, 0, fmt); continue; }
+        fp2 zn, zi, ax, ay;
+        fp2_norm1(zn, acc.z);
+        fp2_inv(zi, zn);
+        fp2_mul(ax, acc.x, zi); fp2_mul(ay, acc.y, zi);
+        if (fmt == 192) { fp2_to_bytes96(o, ax); fp2_to_bytes96(o + 96, ay); }
+        else { o[0] = (uint8_t)(0x02 | fp2_sign(ay)); fp2_to_bytes96(o + 1, ax); }
+    }
+    return 0;
+}
+
+static void pair_load(fp& px, fp& py, bool& pinf, fp2& qx, fp2& qy, bool& qinf, const uint8_t* g1, const uint8_t* g2) {
+    uint32_t rp[24], rq[48];
+    load_raw(rp, g1, 24); load_raw(rq, g2, 48);
+    pinf = raw_all_zero(rp, 24); qinf = raw_all_zero(rq, 48);
+    fp_from_raw48(px, rp); fp_from_raw48(py, rp + 12);
+    fp2_from_bytes96(qx, g2); fp2_from_bytes96(qy, g2 + 96);
+}
+static void gt_store(uint8_t* o, const fp12& f) {
+    for (int j = 0; j < 12; ++j) {
+        uint32_t raw[12];
+        fp_to_raw48(raw, fp12_coord(f, j));
+        std::memcpy(o + 48 * j, raw, 48);
+    }
+}
+
+int sim_pair_batch(size_t n, const uint8_t* g1_96, const uint8_t* g2_192, uint8_t* gt576) {
+    for (size_t i = 0; i < n; ++i) {
+        fp px, py; fp2 qx, qy; bool pinf, qinf;
+        pair_load(px, py, pinf, qx, qy, qinf, g1_96 + 96 * i, g2_192 + 192 * i);
+        fp12 f;
+        miller_loop(f, px, py, pinf, qx, qy, qinf);
+        final_exp(f);
+        gt_store(gt576 + 576 * i, f);
+    }
+    return 0;
+}
+
+int sim_pair_eq_batch(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, uint8_t* ok) {
+    for (size_t i = 0; i < n; ++i) {
+        fp px, py; fp2 qx, qy; bool pinf, qinf;
+        fp12 f, g, gc, t;
+        pair_load(px, py, pinf, qx, qy, qinf, a1 + 96 * i, a2 + 192 * i);
+        miller_loop(f, px, py, pinf, qx, qy, qinf);
+        pair_load(px, py, pinf, qx, qy, qinf, b1 + 96 * i, b2 + 192 * i);
+        miller_loop(g, px, py, pinf, qx, qy, qinf);
+        fp12_conj(gc, g);
+        fp12_mul(t, f, gc);
+        final_exp(t);
+        ok[i] = fp12_is_one(t) ? 1 : 0;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,90 @@
+"""GPU parity tests for G2 and the pairing (run with -m gpu): HIP path through the C ABI vs golden
+vectors from the reference and vs the CPU oracle on fresh inputs."""
+import time
+
+import pytest
+
+from util import R, cat, golden, prng, scalars
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from crypto12381_amd import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def test_g2_golden(ctx):
+    g = golden("g2")
+    pts, sc = cat(g["points"]), cat(g["scalars"])
+    assert ctx.g2_mul(pts, sc, 97) == cat(g["mul97"])
+    assert ctx.g2_mul(pts, sc, 192) == cat(g["mul192"])
+    assert ctx.g2_add(cat(g["add_a"]), cat(g["add_b"]), 192) == cat(g["add192"])
+
+
+def test_g2_mul_vs_oracle_random(ctx, oracle_port):
+    n = 300
+    g2 = bytes.fromhex(golden("g2")["generator"])
+    pts = ctx.g2_mul(g2 * n, scalars(401, n), 192)
+    sc = scalars(402, n, 1 << 256)
+    assert ctx.g2_mul(pts, sc, 97) == oracle_port.g2_mul(pts, sc, 97, 16)
+
+
+def test_pairing_golden(ctx):
+    g = golden("pairing")
+    g1, g2 = cat(g["g1"]), cat(g["g2"])
+    gt = ctx.pair(g1, g2)
+    assert gt == cat(g["gt"])
+    assert list(ctx.pair_eq(cat(g["eq_a1"]), cat(g["eq_a2"]), cat(g["eq_b1"]), cat(g["eq_b2"]))) == g["eq"]
+
+
+def test_config1_bilinearity_on_gpu(ctx):
+    """BASELINE configs[0] with the reference's own seeded inputs: e(P^x, Q^y) computed on the GPU."""
+    g = golden("config1_bilinearity")
+    sc = cat(g["scalars"])
+    x, y = sc[64:96], sc[96:128]
+    Pp, Qq = bytes.fromhex(g["P"]), bytes.fromhex(g["Q"])
+    lhs = ctx.pair(ctx.g1_mul(Pp, x, 96), ctx.g2_mul(Qq, y, 192))
+    assert lhs.hex() == g["pair_Px_Qy"]
+
+
+def test_pairing_vs_oracle_and_bilinearity(ctx, oracle_port):
+    n = 512
+    g1 = bytes.fromhex(golden("g1")["generator"])
+    g2 = bytes.fromhex(golden("g2")["generator"])
+    P = ctx.g1_mul(g1 * n, scalars(411, n), 96)
+    Q = ctx.g2_mul(g2 * n, scalars(412, n), 192)
+    gt = ctx.pair(P, Q)
+    m = 48
+    assert gt[:576 * m] == oracle_port.pair(P[:96 * m], Q[:192 * m], 16)
+    # bilinearity over the whole batch: e(xP, Q) == e(P, xQ)
+    xs = scalars(413, n)
+    ok = ctx.pair_eq(ctx.g1_mul(P, xs, 96), Q, P, ctx.g2_mul(Q, xs, 192))
+    assert ok == b"\x01" * n
+    # and a perturbed batch is rejected everywhere
+    ok = ctx.pair_eq(ctx.g1_mul(P, xs, 96), Q, P, ctx.g2_mul(Q, scalars(414, n), 192))
+    assert ok == b"\x00" * n
+
+
+def test_pairing_full_size_2_16(ctx, oracle_port):
+    """BASELINE configs[2] size: 2^16 pairings; sampled lanes vs the oracle + the pairing-product check
+    prod e(P_i, Q)^(k_i) == e(sum k_i P_i, Q) evaluated through the equality kernel on a folded batch."""
+    n = 1 << 16
+    g1 = bytes.fromhex(golden("g1")["generator"])
+    g2 = bytes.fromhex(golden("g2")["generator"])
+    m = 1 << 10
+    P = ctx.g1_mul(g1 * m, scalars(421, m), 96) * (n // m)
+    Q = ctx.g2_mul(g2 * m, scalars(422, m), 192)
+    Q = b"".join(Q[192 * ((7 * i) % m):192 * ((7 * i) % m) + 192] for i in range(n))
+    t0 = time.time()
+    gt = ctx.pair(P, Q)
+    dt = time.time() - t0
+    print("2^16 pairings incl. PCIe: %.3f s" % dt)
+    idx = [0, 1, n - 1] + [prng(423, i, 4) % n for i in range(29)]
+    sp = b"".join(P[96 * i:96 * i + 96] for i in idx)
+    sq = b"".join(Q[192 * i:192 * i + 192] for i in idx)
+    exp = oracle_port.pair(sp, sq, 16)
+    assert b"".join(gt[576 * i:576 * i + 576] for i in idx) == exp
