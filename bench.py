@@ -40,6 +40,13 @@ G1_GEN = bytes.fromhex(
 # algorithmic work per G1 scalar-mul: reference operation counts
 MAC32_PER_G1_MUL = 579_456
 BYTES_PER_G1_MUL = 224           # 96 in + 32 scalar + 96 out (canonical affine)
+MAC32_PER_PAIRING = 4_275_240    # Miller loop + final exponentiation, reference operation counts
+BYTES_PER_PAIRING = 864          # 96 + 192 in, 576 out
+G2_GEN = bytes.fromhex(
+    "13e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7e"
+    "024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8"
+    "0606c4a02ea734cc32acd2b02bc28b99cb3e287e85a763af267492ab572e99ab3f370d275cec1da1aaa9075ff05f79be"
+    "0ce5d527727d6e118cc9cdc6da2e351aadfd9baa8cbdd3a76d429a695160d12c923ac9cc3baca289e193548608b82801")
 HBM_PEAK_GBS = 8000.0
 VALU_PEAK_MAC32 = 3.10e13        # measured v_mad_u64_u32 lane-ops/s, profiles/r01_valu_rates.txt
 
@@ -61,6 +68,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log2-batch", type=int, default=20)
+    ap.add_argument("--log2-pairings", type=int, default=16)
+    ap.add_argument("--no-pairing", action="store_true", help="skip the secondary (pairings/s) measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -121,6 +130,43 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- second half of the metric: ate pairings/s on a batch of 2^16 (BASELINE configs[2]), same protocol
+    pair = None
+    if not args.no_pairing:
+        npair = 1 << args.log2_pairings
+        t_sc = torch.from_numpy(make_scalars(3000 + rank, npair)).to(dev)
+        g2gen = torch.from_numpy(np.frombuffer(G2_GEN, dtype=np.uint8).copy()).to(dev).repeat(npair).contiguous()
+        q2 = torch.empty(npair * 192, dtype=torch.uint8, device=dev)
+        gt = torch.empty(npair * 576, dtype=torch.uint8, device=dev)
+        p1 = pts[: npair * 96] if npair <= n else pts.repeat((npair + n - 1) // n)[: npair * 96].contiguous()
+        torch.cuda.synchronize(dev)
+        ctx.g2_mul_dev(npair, g2gen.data_ptr(), t_sc.data_ptr(), q2.data_ptr(), 192)   # Q_i = G2^{t_i} (untimed)
+        ctx.sync()
+        del g2gen
+        psteps = max(1, args.steps)
+        for _ in range(max(1, args.warmup)):
+            ctx.pair_dev(npair, p1.data_ptr(), q2.data_ptr(), gt.data_ptr())
+        torch.cuda.synchronize(dev)
+        if dist:
+            dist.barrier()
+        ctx.profile(True)
+        torch.cuda.synchronize(dev)
+        tp0 = time.perf_counter()
+        for _ in range(psteps):
+            ctx.pair_dev(npair, p1.data_ptr(), q2.data_ptr(), gt.data_ptr())
+        torch.cuda.synchronize(dev)
+        if dist:
+            dist.barrier()
+        pel = time.perf_counter() - tp0
+        pk_ms, pk_launches = ctx.profile_read(3)
+        ctx.profile(False)
+        if dist:
+            t = torch.tensor([pel], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            pel = float(t.item())
+        pair = {"npair": npair, "steps": psteps, "elapsed": pel, "kernel_ms": pk_ms, "launches": pk_launches,
+                "p1": p1, "q2": q2, "gt": gt}
 
     # ---- parity (outside the timed region): sampled lanes vs the CPU oracle, all edge lanes included
     from oracle.bindings import Oracle, have_reference
@@ -183,6 +229,36 @@ def main():
                                       "sample": "first %d lanes of the same batch, %d threads; full compare with GPU output bit-exact"
                                                 % (sample, cores),
                                       "single_thread_value": 2048 / cpu1_s}
+        if pair is not None:
+            npair = pair["npair"]
+            pidx = list(range(4)) + [int(x) for x in np.random.Generator(np.random.PCG64(9)).integers(0, npair, size=12)]
+            p1_h = pair["p1"].cpu().numpy().reshape(npair, 96)
+            q2_h = pair["q2"].cpu().numpy().reshape(npair, 192)
+            gt_h = pair["gt"].cpu().numpy().reshape(npair, 576)
+            if orc.pair(p1_h[pidx].tobytes(), q2_h[pidx].tobytes(), 8) != gt_h[pidx].tobytes():
+                raise SystemExit("bench: GPU pairing results differ from the CPU oracle — number withheld")
+            avg_s = pair["kernel_ms"] / max(pair["launches"], 1) * 1e-3
+            result["pairing"] = {
+                "metric": "ate pairings/s per MI355X (batch 2^%d per GPU), bit-exact vs CPU" % args.log2_pairings,
+                "value": world * npair * pair["steps"] / pair["elapsed"], "unit": "pairings/s",
+                "ms_per_step": pair["elapsed"] / pair["steps"] * 1e3,
+                "parity": {"checked_lanes": len(pidx), "oracle": kind, "bit_exact": True},
+                "roofline": {"bound": "hbm", "achieved": BYTES_PER_PAIRING * npair / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": BYTES_PER_PAIRING * npair / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "pair_kernel",
+                             "avg_launch_ms": avg_s * 1e3},
+                "valu_roofline": {"bound": "int-valu", "achieved": MAC32_PER_PAIRING * npair / avg_s / 1e9, "peak": VALU_PEAK_MAC32 / 1e9,
+                                  "unit": "GMAC32/s", "frac": MAC32_PER_PAIRING * npair / avg_s / VALU_PEAK_MAC32,
+                                  "algorithmic_mac32_per_unit": MAC32_PER_PAIRING},
+            }
+            if world == 1 and not args.no_cpu_baseline:
+                ps = min(npair, 1 << 11)
+                t3 = time.perf_counter()
+                cpu_gt = orc.pair(p1_h[:ps].tobytes(), q2_h[:ps].tobytes(), cores)
+                cpu_ps = time.perf_counter() - t3
+                if cpu_gt != gt_h[:ps].tobytes():
+                    raise SystemExit("bench: CPU pairing baseline differs from the GPU output")
+                result["pairing"]["cpu_baseline"] = {"value": ps / cpu_ps, "unit": "pairings/s", "cores": cores, "kind": kind,
+                                                     "sample": "first %d lanes of the same batch, %d threads; bit-exact vs GPU" % (ps, cores)}
         print(json.dumps(result), flush=True)
     ctx.close()
     if dist:
