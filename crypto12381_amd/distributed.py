@@ -1,0 +1,46 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over
+xGMI on the GPU box, "gloo" in the CPU tests).
+
+* Independent units (G1/G2 scalar-mul batches, pairings, BBS+ verifies): contiguous shards, NO collective.
+* MSM  Π g_i^{x_i}: shard by terms, local MSM per rank, then ONE exchange — an all-gather of the partial
+  points (96 B each) and a local sum on every rank.  The combine operator is elliptic-curve addition, which
+  no RCCL reduce op implements, so "all-reduce" is realised as all-gather + local N-term sum.
+
+The arithmetic itself is injected (`local_msm`): on the GPU box it is `Context.g1_msm`; the CPU tests inject
+the oracle to exercise exactly this sharding/exchange logic without a GPU.
+"""
+from __future__ import annotations
+
+from typing import Callable
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous shard [lo, hi) of n units for `rank` (sizes differ by at most one)."""
+    return n * rank // world, n * (rank + 1) // world
+
+
+def shard_bytes(buf: bytes, record: int, rank: int, world: int) -> bytes:
+    lo, hi = shard_bounds(len(buf) // record, rank, world)
+    return buf[record * lo:record * hi]
+
+
+def msm_sharded(local_msm: Callable[[bytes, bytes, int], bytes], pts_shard: bytes, scalars_shard: bytes,
+                out_fmt: int = 49, group=None, device: torch.device | str = "cpu") -> bytes:
+    """Every rank passes ITS shard of (points, scalars); every rank returns the full product.
+
+    local_msm(points96, scalars32, fmt) -> fmt bytes  (fmt 96 = affine, all-zero = infinity).
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    partial = local_msm(pts_shard, scalars_shard, 96) if len(pts_shard) else bytes(96)
+    if world == 1:
+        gathered = partial
+    else:
+        mine = torch.frombuffer(bytearray(partial), dtype=torch.uint8).to(device)
+        parts = [torch.empty(96, dtype=torch.uint8, device=device) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)                 # 96 B per rank: latency-bound, one exchange
+        gathered = b"".join(bytes(p.cpu().numpy().tobytes()) for p in parts)
+    one = (1).to_bytes(32, "big")
+    return local_msm(gathered, one * (len(gathered) // 96), out_fmt)
