@@ -337,7 +337,7 @@ __device__ __noinline__ void pair_inputs(fp& px, fp& py, bool& pinf, fp2& qx, fp
     ok = ok1 && ok2;
 }
 
-__global__ void __launch_bounds__(BLOCK) pair_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag) {
+__global__ void __launch_bounds__(BLOCK, 2) pair_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     fp px, py; fp2 qx, qy; bool pinf, qinf, ok;
@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(BLOCK) pair_kernel(size_t n, const uint8_t* g1
     gt_store576(gt + 576 * i, f, !ok);
 }
 
-__global__ void __launch_bounds__(BLOCK) pair_eq_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2,
+__global__ void __launch_bounds__(BLOCK, 2) pair_eq_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2,
                                                         uint8_t* out, int* bad_flag) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
