@@ -32,7 +32,7 @@ using namespace c12381;
 namespace {
 
 constexpr int BLOCK = 256;
-constexpr size_t G1_CHUNK = (size_t)1 << 18;     // elements per scalar-mul launch (table slab = 704 MiB)
+constexpr size_t G1_CHUNK = (size_t)1 << 17;     // elements per scalar-mul launch = resident lanes at 2 waves/SIMD; table slab 176 MiB (fits the 256 MiB Infinity Cache)
 constexpr size_t G2_CHUNK = (size_t)1 << 17;     // G2 table slab = 704 MiB
 constexpr int FINISH_M = 16;                     // elements per lane in the simultaneous inversion
 
@@ -109,9 +109,8 @@ __global__ void __launch_bounds__(BLOCK) fp_mulchain_kernel(size_t n, int iters,
 
 // ------------------------------------------------------------------ G1 kernels
 // proj layout: coordinate-major, limb-major SoA: proj[(c*NL + limb) * stride + element]
-__global__ void __launch_bounds__(BLOCK) g1_mul_kernel(size_t n, const uint8_t* pts, const uint8_t* scalars, int32_t* tab,
-                                                       size_t tab_stride, int32_t* proj, size_t proj_stride, size_t proj_off,
-                                                       int* bad_flag) {
+__global__ void __launch_bounds__(BLOCK, 2) g1_mul_kernel(size_t n, const uint8_t* pts, const uint8_t* scalars, int32_t* tab,
+                                                       int32_t* proj, size_t proj_stride, size_t proj_off, int* bad_flag) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     fp px, py;
@@ -121,7 +120,7 @@ __global__ void __launch_bounds__(BLOCK) g1_mul_kernel(size_t n, const uint8_t* 
     load_raw32(raw, scalars + 32 * i);
     scalar_from_raw32(k, raw);
     g1p acc;
-    g1_scalar_mul(acc, px, py, inf || !ok, k, tab, tab_stride, i);
+    g1_scalar_mul(acc, px, py, inf || !ok, k, tab + i * (size_t)G1_TAB_DWORDS);
     if (!ok) {
         *bad_flag = 1;
         // poison: Z = 0, X = 1 marks "invalid" for the finish kernel
@@ -436,7 +435,7 @@ int g1_mul_to_proj(c12381_ctx* c, size_t n, const uint8_t* d_pts, const uint8_t*
         const size_t m = n - off < chunk ? n - off : chunk;
         timed tm(c, 0);
         hipLaunchKernelGGL(g1_mul_kernel, dim3(grid_for(m)), dim3(BLOCK), 0, c->stream, m, d_pts + 96 * off, d_sc + 32 * off,
-                           (int32_t*)c->ws[c12381_ctx::WS_TAB], chunk, (int32_t*)c->ws[c12381_ctx::WS_PROJ], stride, off, c->d_flag);
+                           (int32_t*)c->ws[c12381_ctx::WS_TAB], (int32_t*)c->ws[c12381_ctx::WS_PROJ], stride, off, c->d_flag);
         HIPCK(c, hipGetLastError());
     }
     return 0;

@@ -294,6 +294,11 @@ C12381_HD void fp_reduce_cols(fp& r, ColFn col) {
 #pragma unroll
     for (int i = 0; i < NL; ++i) r.l[i] = out[i];
 }
+// r = (a*b + c*d) / R  or  (a*b - c*d) / R  with ONE reduction (saves 196 + 14 multiply-adds over two
+// fp_mul).  Needs 14*(LBa*LBb + LBc*LBd) + 14*2^56 + 2^40 < 2^63.
+template <bool SUB>
+C12381_HD void fp_mul2(fp& r, const fp& a, const fp& b, const fp& c, const fp& d);
+
 #ifdef C12381_CHECK_BOUNDS
 // declare the bounds of a lazily reduced form: sum_lblb = sum over products of LBa*LBb, sum_vbvb likewise
 inline void set_lazy_bounds(fp& r, double sum_lblb, double sum_vbvb, const char* where) {
@@ -305,6 +310,15 @@ inline void set_lazy_bounds(fp& r, double sum_lblb, double sum_vbvb, const char*
     set_bounds(r, top > 268435456.0 ? top : 268435456.0, vb, where);
 }
 #endif
+
+template <bool SUB>
+C12381_HD void fp_mul2(fp& r, const fp& a, const fp& b, const fp& c, const fp& d) {
+    fp t;
+    fp_reduce_cols(t, [&](int k) { return SUB ? fp_col(a, b, k) - fp_col(c, d, k) : fp_col(a, b, k) + fp_col(c, d, k); });
+    C12381_BOUNDS({ check_actual(a, "fp_mul2"); check_actual(b, "fp_mul2"); check_actual(c, "fp_mul2"); check_actual(d, "fp_mul2");
+                    set_lazy_bounds(t, a.lb * b.lb + c.lb * d.lb, a.vb * b.vb + c.vb * d.vb, "fp_mul2"); })
+    r = t;
+}
 
 // ------------------------------------------------------------------ canonical form, tests
 // Leaves Montgomery form and fully reduces: r = a / R mod p as canonical limbs in [0, p).

@@ -7,8 +7,8 @@
 // the Renes–Costello–Batina COMPLETE formulas for a = 0 — no exceptional cases, hence no
 // data-dependent branch and no wavefront divergence (P+P, P+(-P), infinity operands and
 // zero digits all go through the same instruction stream).  GLV: k = k0 + k1*x^2 with
-// [x^2](x,y) = (beta*x, -y), so both 128-bit halves share ONE 16-entry window table that
-// lives in HBM in limb-major SoA order (coalesced when written, per-lane gathered when read).
+// [x^2](x,y) = (beta*x, -y), so both 128-bit halves share ONE table of 8 multiples of P (signed
+// 4-bit windows) that lives in HBM as one contiguous 1408-byte record per lane.
 #pragma once
 #include "fp.hpp"
 
@@ -20,28 +20,28 @@ C12381_HD void g1_set_inf(g1p& p) { fp_zero(p.x); fp_one(p.y); fp_zero(p.z); }
 C12381_HD bool g1_is_inf(const g1p& p) { return fp_is_zero(p.z); }
 C12381_HD void g1_norm1(g1p& r, const g1p& p) { fp_norm1(r.x, p.x); fp_norm1(r.y, p.y); fp_norm1(r.z, p.z); }
 
-// P = 2P.  6M + 2S + one small-constant multiply.  Operand limb bound: <= 2^29.
+// P = 2P.  6M + 2S with 7 reductions (Y3 is a lazily reduced sum of two products).
+// Operand limb bound: <= 2^29.
 C12381_HD void g1_dbl(g1p& p) {
-    fp t0, t1, t2, x3, y3, z3;
+    fp t0, t1, t2, z8, u, y3, x3, z3;
     fp_sqr(t0, p.y);
     fp_mul(t1, p.y, p.z);
     fp_sqr(t2, p.z);
-    fp_dbl(z3, t0); fp_dbl(z3, z3); fp_dbl(z3, z3);      // 8 Y^2 (limbs < 2^31)
+    fp_mul_small(z8, t0, 8);                             // 8 Y^2
     fp_mul_small(t2, t2, 12);                            // 3b Z^2
-    fp_mul(x3, t2, z3);
     fp_add(y3, t0, t2);
-    fp_mul(z3, t1, z3);
-    fp_dbl(t1, t2); fp_add(t2, t2, t1);                  // 9b Z^2
-    fp_sub(t0, t0, t2);
-    fp_mul(y3, t0, y3);
-    fp_add(y3, y3, x3);
+    fp_mul(z3, t1, z8);
+    fp_dbl(u, t2); fp_add(u, u, t2);                     // 9b Z^2
+    fp_sub(u, t0, u);
+    fp_norm1(u, u);
+    fp_mul2<false>(y3, u, y3, t2, z8);                   // (Y^2 - 9bZ^2)(Y^2 + 3bZ^2) + 3bZ^2 * 8Y^2
     fp_mul(t1, p.x, p.y);
-    fp_mul(x3, t0, t1);
+    fp_mul(x3, u, t1);
     fp_dbl(x3, x3);
     p.x = x3; p.y = y3; p.z = z3;
 }
 
-// P = P + Q (complete).  12M + three small-constant multiplies.
+// P = P + Q (complete).  12 products, 9 reductions.
 // Operand limb bounds: P <= 2^29, Q <= 2^28 (+ carry slack): table entries are stored normalised.
 C12381_HD void g1_add(g1p& p, const g1p& q) {
     fp t0, t1, t2, t3, t4, x3, y3, z3;
@@ -49,7 +49,7 @@ C12381_HD void g1_add(g1p& p, const g1p& q) {
     fp_mul(t1, p.y, q.y);
     fp_mul(t2, p.z, q.z);
     fp_add(t3, p.x, p.y); fp_add(t4, q.x, q.y); fp_mul(t3, t3, t4);
-    fp_add(t4, t0, t1); fp_sub(t3, t3, t4);
+    fp_add(t4, t0, t1); fp_sub(t3, t3, t4); fp_norm1(t3, t3);
     fp_add(t4, p.y, p.z); fp_add(x3, q.y, q.z); fp_mul(t4, t4, x3);
     fp_add(x3, t1, t2); fp_sub(t4, t4, x3);
     fp_add(x3, p.x, p.z); fp_add(y3, q.x, q.z); fp_mul(x3, x3, y3);
@@ -58,9 +58,9 @@ C12381_HD void g1_add(g1p& p, const g1p& q) {
     fp_mul_small(t2, t2, 12);
     fp_add(z3, t1, t2); fp_sub(t1, t1, t2);
     fp_mul_small(y3, y3, 12);
-    fp_mul(x3, y3, t4); fp_mul(t2, t3, t1); fp_sub(p.x, t2, x3);
-    fp_mul(y3, y3, t0); fp_mul(t1, t1, z3); fp_add(p.y, y3, t1);
-    fp_mul(t0, t0, t3); fp_mul(z3, z3, t4); fp_add(p.z, z3, t0);
+    fp_mul2<true>(p.x, t3, t1, y3, t4);                  // X3 = t3*t1 - y3*t4
+    fp_mul2<false>(p.y, y3, t0, t1, z3);                 // Y3 = y3*t0 + t1*z3
+    fp_mul2<false>(p.z, z3, t4, t0, t3);                 // Z3 = z3*t4 + t0*t3
 }
 
 // (X:Y:Z) -> (beta*X : -Y : Z) = [x^2](X:Y:Z)
@@ -142,24 +142,83 @@ C12381_HD void soa_load_g1(g1p& p, const int32_t* base, size_t stride, size_t id
     soa_load_fp(p.z, base + (size_t)2 * NL * stride, stride, idx);
 }
 
-constexpr int G1_WIN = 4;                       // window width
-constexpr int G1_TAB = 1 << G1_WIN;             // entries 0..15 (entry 0 = infinity)
-constexpr int G1_TAB_DWORDS = G1_TAB * 3 * NL;  // per lane
+// ------------------------------------------------------------------ per-lane window table
+// Signed 4-bit windows: entries 1..8 of multiples of P, each entry X|Y|Z = 42 dwords padded to 44 (176 B,
+// eleven 16-byte accesses).  A lane's whole table is one contiguous 1408-byte record, so a gather of one
+// entry touches 176 consecutive bytes of HBM instead of 42 scattered dwords (the limb-major layout of the
+// first version moved ~16x the algorithmic bytes: profiles/r01_pmc_summary_before_table_fix.txt).
+constexpr int G1_WIN = 4;
+constexpr int G1_TAB = 8;                              // entries 1..8
+constexpr int G1_ENT_DWORDS = 44;
+constexpr int G1_TAB_DWORDS = G1_TAB * G1_ENT_DWORDS;  // 352 dwords = 1408 B per lane
+struct alignas(16) q4 { int32_t v[4]; };
 
-// [k]P for an AFFINE input point (x, y) or infinity.  `tab` is this launch's table slab
-// (G1_TAB_DWORDS x stride dwords), `lane` this thread's column in it.
-C12381_HD void g1_scalar_mul(g1p& acc, const fp& px, const fp& py, bool p_is_inf, const uint32_t (&kin)[8],
-                             int32_t* tab, size_t stride, size_t lane) {
+C12381_HD void tab_store_g1(int32_t* ent, const g1p& p) {
+    int32_t w[G1_ENT_DWORDS];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) { w[i] = p.x.l[i]; w[NL + i] = p.y.l[i]; w[2 * NL + i] = p.z.l[i]; }
+    w[42] = 0; w[43] = 0;
+    q4* dst = reinterpret_cast<q4*>(ent);
+#pragma unroll
+    for (int i = 0; i < G1_ENT_DWORDS / 4; ++i) { q4 t; t.v[0] = w[4 * i]; t.v[1] = w[4 * i + 1]; t.v[2] = w[4 * i + 2]; t.v[3] = w[4 * i + 3]; dst[i] = t; }
+}
+C12381_HD void tab_load_g1(g1p& p, const int32_t* ent) {
+    int32_t w[G1_ENT_DWORDS];
+    const q4* src = reinterpret_cast<const q4*>(ent);
+#pragma unroll
+    for (int i = 0; i < G1_ENT_DWORDS / 4; ++i) { q4 t = src[i]; w[4 * i] = t.v[0]; w[4 * i + 1] = t.v[1]; w[4 * i + 2] = t.v[2]; w[4 * i + 3] = t.v[3]; }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) { p.x.l[i] = w[i]; p.y.l[i] = w[NL + i]; p.z.l[i] = w[2 * NL + i]; }
+    C12381_BOUNDS(p.x.lb = p.y.lb = p.z.lb = 268435456.0 + 8.0; p.x.vb = p.y.vb = p.z.vb = 4.0;
+                  check_actual(p.x, "tab_load_g1"); check_actual(p.y, "tab_load_g1"); check_actual(p.z, "tab_load_g1");)
+}
+// signed digit of window w of k' = k + 0x888...8 (32 nibbles): d = nibble - 8 in [-8, 7]; window 32 is the
+// carry nibble (0 or 1, no bias).  Sum_w d_w 16^w = k.
+C12381_HD int glv_digit(const uint32_t (&kb)[5], int w) {
+    const int nib = (int)((kb[w >> 3] >> ((w & 7) * 4)) & 15u);
+    return w == 32 ? nib : nib - 8;
+}
+C12381_HD void glv_bias(uint32_t (&kb)[5], const uint32_t (&k)[4]) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { c += (uint64_t)k[i] + 0x88888888u; kb[i] = (uint32_t)c; c >>= 32; }
+    kb[4] = (uint32_t)c;
+}
+// acc += sign(d) * T[|d|]  (d == 0 adds the point at infinity: same instruction stream)
+C12381_HD void g1_add_digit(g1p& acc, const int32_t* lane_tab, int d, bool endo) {
+    const int mag = d < 0 ? -d : d;
+    const int idx = mag == 0 ? 1 : mag;
+    g1p q;
+    tab_load_g1(q, lane_tab + (idx - 1) * G1_ENT_DWORDS);
+    fp ny, zero, one;
+    fp_neg(ny, q.y);
+    fp_select(q.y, d < 0, ny, q.y);
+    fp_zero(zero); fp_one(one);
+    const bool isz = mag == 0;
+    fp_select(q.x, isz, zero, q.x); fp_select(q.y, isz, one, q.y); fp_select(q.z, isz, zero, q.z);
+    C12381_BOUNDS(q.x.lb = q.y.lb = q.z.lb = 268435456.0 + 8.0;)
+    if (endo) {                                     // compile-time constant at both call sites
+        g1p e;
+        g1_endo_x2(e, q);
+        g1_add(acc, e);
+    } else {
+        g1_add(acc, q);
+    }
+}
+
+// [k]P for an AFFINE input point (x, y) or infinity.  `lane_tab` = this lane's 1408-byte table record.
+C12381_HD void g1_scalar_mul(g1p& acc, const fp& px, const fp& py, bool p_is_inf, const uint32_t (&kin)[8], int32_t* lane_tab) {
     uint32_t k[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) k[i] = kin[i];
     scalar_mod_r(k);
-    uint32_t k0[4], k1[4];
+    uint32_t k0[4], k1[4], kb0[5], kb1[5];
     scalar_glv_split(k0, k1, k);
+    glv_bias(kb0, k0);
+    glv_bias(kb1, k1);
 
-    // window table T[j] = j*P, j = 0..15, stored normalised (limb bound 2^28 + slack)
+    // table T[j] = j*P, j = 1..8, stored normalised (limb bound 2^28 + slack)
     g1p base, t;
-    g1_set_inf(t);
     base.x = px; base.y = py; fp_one(base.z);
     {   // infinity input: use (0:1:0) as the base so every multiple is infinity
         g1p inf;
@@ -168,39 +227,30 @@ C12381_HD void g1_scalar_mul(g1p& acc, const fp& px, const fp& py, bool p_is_inf
         fp_select(base.y, p_is_inf, inf.y, base.y);
         fp_select(base.z, p_is_inf, inf.z, base.z);
     }
-    const size_t ent = (size_t)3 * NL * stride;
-    soa_store_g1(tab, stride, lane, t);                 // T[0]
-    soa_store_g1(tab + ent, stride, lane, base);        // T[1]
+    tab_store_g1(lane_tab, base);                               // T[1]
     t = base;
     g1_dbl(t);
     {
         g1p n;
         g1_norm1(n, t);
-        soa_store_g1(tab + 2 * ent, stride, lane, n);   // T[2]
+        tab_store_g1(lane_tab + G1_ENT_DWORDS, n);              // T[2]
         t = n;
     }
 #pragma unroll 1
-    for (int j = 3; j < G1_TAB; ++j) {
+    for (int j = 3; j <= G1_TAB; ++j) {
         g1_add(t, base);
         g1p n;
         g1_norm1(n, t);
-        soa_store_g1(tab + (size_t)j * ent, stride, lane, n);
+        tab_store_g1(lane_tab + (j - 1) * G1_ENT_DWORDS, n);
         t = n;
     }
 
     g1_set_inf(acc);
 #pragma unroll 1
-    for (int w = 128 / G1_WIN - 1; w >= 0; --w) {
-        g1_dbl(acc); g1_dbl(acc); g1_dbl(acc); g1_dbl(acc);
-        const uint32_t d0 = (k0[w >> 3] >> ((w & 7) * 4)) & 15u;
-        const uint32_t d1 = (k1[w >> 3] >> ((w & 7) * 4)) & 15u;
-        g1p q;
-        soa_load_g1(q, tab + (size_t)d0 * ent, stride, lane);
-        g1_add(acc, q);
-        soa_load_g1(q, tab + (size_t)d1 * ent, stride, lane);
-        g1p e;
-        g1_endo_x2(e, q);
-        g1_add(acc, e);
+    for (int w = 32; w >= 0; --w) {
+        if (w != 32) { g1_dbl(acc); g1_dbl(acc); g1_dbl(acc); g1_dbl(acc); }    // wave-uniform
+        g1_add_digit(acc, lane_tab, glv_digit(kb0, w), false);
+        g1_add_digit(acc, lane_tab, glv_digit(kb1, w), true);
     }
 }
 

@@ -44,7 +44,8 @@ int sim_fp_op_batch(int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_
 
 // the per-lane scalar multiplication of g1.hpp, one "lane" at a time, table slab of stride 1
 int sim_g1_mul_batch(size_t n, const uint8_t* pts96, const uint8_t* scalars32, uint8_t* out, int fmt) {
-    std::vector<int32_t> tab(G1_TAB_DWORDS);
+    std::vector<int32_t> tabv(G1_TAB_DWORDS + 4);
+    int32_t* tab = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(tabv.data()) + 15) & ~(uintptr_t)15);
     for (size_t i = 0; i < n; ++i) {
         uint32_t rp[24], rs[8], k[8];
         load_raw(rp, pts96 + 96 * i, 24); load_raw(rs, scalars32 + 32 * i, 8);
@@ -53,7 +54,7 @@ int sim_g1_mul_batch(size_t n, const uint8_t* pts96, const uint8_t* scalars32, u
         fp_from_raw48(px, rp); fp_from_raw48(py, rp + 12);
         scalar_from_raw32(k, rs);
         g1p acc;
-        g1_scalar_mul(acc, px, py, inf, k, tab.data(), 1, 0);
+        g1_scalar_mul(acc, px, py, inf, k, tab);
         uint8_t* o = out + (size_t)fmt * i;
         if (g1_is_inf(acc)) { std::memset(o, 0, fmt); continue; }
         fp zn, zi, ax, ay;

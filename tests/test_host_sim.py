@@ -79,3 +79,28 @@ def test_sim_g1_mul_random_vs_oracle(sim, oracle_port):
     out = ctypes.create_string_buffer(49 * n)
     assert sim.sim_g1_mul_batch(sz(n), pts, sc, out, 49) == 0
     assert out.raw == oracle_port.g1_mul(pts, sc, 49, 4)
+
+
+def test_sim_g2_mul_golden(sim):
+    g = golden("g2")
+    pts, sc = cat(g["points"]), cat(g["scalars"])
+    n = len(pts) // 192
+    for fmt, key in ((97, "mul97"), (192, "mul192")):
+        out = ctypes.create_string_buffer(fmt * n)
+        assert sim.sim_g2_mul_batch(sz(n), pts, sc, out, fmt) == 0
+        assert out.raw == cat(g[key])
+
+
+def test_sim_pairing_golden(sim):
+    """Miller loop + final exponentiation of the device headers, incl. infinity arguments."""
+    g = golden("pairing")
+    g1, g2 = cat(g["g1"]), cat(g["g2"])
+    n = len(g1) // 96
+    out = ctypes.create_string_buffer(576 * n)
+    assert sim.sim_pair_batch(sz(n), g1, g2, out) == 0
+    assert out.raw == cat(g["gt"])
+    a1, a2, b1, b2 = cat(g["eq_a1"]), cat(g["eq_a2"]), cat(g["eq_b1"]), cat(g["eq_b2"])
+    m = len(a1) // 96
+    ok = ctypes.create_string_buffer(m)
+    assert sim.sim_pair_eq_batch(sz(m), a1, a2, b1, b2, ok) == 0
+    assert list(ok.raw[:m]) == g["eq"]

@@ -9,6 +9,6 @@ for v in $VARIANTS; do
   python - <<PY
 import json
 d=json.load(open("gpurun_out/ab_$v.json"))
-print("$v", "g1 %.3e /s (kernel %.2f ms)" % (d["value"], d["roofline"]["avg_launch_ms"]), "pair %.3e /s (kernel %.2f ms)" % (d["pairing"]["value"], d["pairing"]["roofline"]["avg_launch_ms"]))
+p=d.get("pairing"); print("$v", "g1 %.3e /s (kernel %.2f ms)" % (d["value"], d["roofline"]["avg_launch_ms"]), ("pair %.3e /s (kernel %.2f ms)" % (p["value"], p["roofline"]["avg_launch_ms"])) if p else "")
 PY
 done
