@@ -54,6 +54,12 @@ def load_library() -> ctypes.CDLL:
             getattr(lib, name).argtypes = [vp, sz, vp, vp, vp]
         for name in ("c12381_pair_eq_batch", "c12381_pair_eq_batch_dev"):
             getattr(lib, name).argtypes = [vp, sz, vp, vp, vp, vp, vp]
+        for name in ("c12381_g1_decompress_batch", "c12381_g2_decompress_batch"):
+            getattr(lib, name).argtypes = [vp, sz, vp, vp, vp]
+        lib.c12381_miller_batch.argtypes = [vp, sz, vp, vp, vp]
+        lib.c12381_fexp_batch.argtypes = [vp, sz, vp, vp]
+        lib.c12381_gt_op_batch.argtypes = [vp, ci, sz, vp, vp, vp]
+        lib.c12381_gt_is_unity_batch.argtypes = [vp, sz, vp, vp]
         _lib = lib
     return _lib
 
@@ -159,6 +165,44 @@ class Context:
         n = len(a1) // 96
         out = ctypes.create_string_buffer(max(n, 1))
         self._ck(self.lib.c12381_pair_eq_batch(self.h, n, _p(a1), _p(a2), _p(b1), _p(b2), _p(out)), allow_point=not strict)
+        return out.raw[:n]
+
+    def g1_decompress(self, c: bytes):
+        n = len(c) // 49
+        out, st = ctypes.create_string_buffer(max(96 * n, 1)), ctypes.create_string_buffer(max(n, 1))
+        self._ck(self.lib.c12381_g1_decompress_batch(self.h, n, _p(c), _p(out), _p(st)))
+        return out.raw[:96 * n], st.raw[:n]
+
+    def g2_decompress(self, c: bytes):
+        n = len(c) // 97
+        out, st = ctypes.create_string_buffer(max(192 * n, 1)), ctypes.create_string_buffer(max(n, 1))
+        self._ck(self.lib.c12381_g2_decompress_batch(self.h, n, _p(c), _p(out), _p(st)))
+        return out.raw[:192 * n], st.raw[:n]
+
+    def miller(self, g1: bytes, g2: bytes) -> bytes:
+        n = len(g1) // 96
+        out = ctypes.create_string_buffer(max(576 * n, 1))
+        self._ck(self.lib.c12381_miller_batch(self.h, n, _p(g1), _p(g2), _p(out)))
+        return out.raw[:576 * n]
+
+    def fexp(self, f: bytes) -> bytes:
+        n = len(f) // 576
+        out = ctypes.create_string_buffer(max(576 * n, 1))
+        self._ck(self.lib.c12381_fexp_batch(self.h, n, _p(f), _p(out)))
+        return out.raw[:576 * n]
+
+    GT_OPS = {"mul": 0, "conj": 1, "pow": 2, "fexp": 3}
+
+    def gt_op(self, op: str, a: bytes, b: bytes | None = None) -> bytes:
+        n = len(a) // 576
+        out = ctypes.create_string_buffer(max(576 * n, 1))
+        self._ck(self.lib.c12381_gt_op_batch(self.h, self.GT_OPS[op], n, _p(a), _p(b), _p(out)))
+        return out.raw[:576 * n]
+
+    def gt_is_unity(self, a: bytes) -> bytes:
+        n = len(a) // 576
+        out = ctypes.create_string_buffer(max(n, 1))
+        self._ck(self.lib.c12381_gt_is_unity_batch(self.h, n, _p(a), _p(out)))
         return out.raw[:n]
 
     # ---- device-pointer entry points (ints = device addresses, e.g. torch tensor.data_ptr())

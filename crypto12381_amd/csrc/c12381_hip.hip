@@ -368,6 +368,88 @@ __global__ void __launch_bounds__(BLOCK, 2) pair_eq_kernel(size_t n, const uint8
     out[i] = valid ? (fp12_is_one(g) ? 1 : 0) : 0xff;
 }
 
+// ------------------------------------------------------------------ decode / split pairing / GT kernels
+// ECP_fromOctet ecp_BLS12381.cpp:495-545 for 49-byte input (tags 02/03; a leading 00 is infinity as in
+// g1_point.hpp:89-93); status 1 ok / 0 reject; rejected and infinity lanes give 96 zero bytes.
+__global__ void __launch_bounds__(BLOCK) g1_decompress_kernel(size_t n, const uint8_t* in, uint8_t* out, uint8_t* status) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* sp = in + 49 * i;
+    const uint8_t tag = sp[0];
+    uint32_t raw[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) raw[j] = (uint32_t)sp[1 + 4 * j] | ((uint32_t)sp[2 + 4 * j] << 8) | ((uint32_t)sp[3 + 4 * j] << 16) | ((uint32_t)sp[4 + 4 * j] << 24);
+    fp x, y;
+    fp_from_raw48(x, raw);
+    const bool ok_tag = tag == 2 || tag == 3;
+    const bool ok = g1_set_x(y, x, tag & 1) && ok_tag;
+    uint32_t rx[12], ry[12];
+    fp_to_raw48(rx, x); fp_to_raw48(ry, y);
+    if (!ok) {
+#pragma unroll
+        for (int j = 0; j < 12; ++j) { rx[j] = 0; ry[j] = 0; }
+    }
+    store_raw48(out + 96 * i, rx); store_raw48(out + 96 * i + 48, ry);
+    status[i] = tag == 0 ? 1 : (ok ? 1 : 0);
+}
+// ECP2_fromOctet ecp2_BLS12381.cpp:225-266 for 97-byte input: any tag other than 04 is "compressed, sign = tag & 1"
+__global__ void __launch_bounds__(BLOCK) g2_decompress_kernel(size_t n, const uint8_t* in, uint8_t* out, uint8_t* status) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* sp = in + 97 * i;
+    const uint8_t tag = sp[0];
+    uint32_t raw[24];
+#pragma unroll
+    for (int j = 0; j < 24; ++j) raw[j] = (uint32_t)sp[1 + 4 * j] | ((uint32_t)sp[2 + 4 * j] << 8) | ((uint32_t)sp[3 + 4 * j] << 16) | ((uint32_t)sp[4 + 4 * j] << 24);
+    fp2 x, y;
+    fp_from_raw48(x.b, raw); fp_from_raw48(x.a, raw + 12);
+    const bool ok = g2_set_x(y, x, tag & 1) && tag != 0 && tag != 4;
+    uint8_t* o = out + 192 * i;
+    if (ok) { fp2_store_raw96(o, x); fp2_store_raw96(o + 96, y); }
+    else { uint4* q = reinterpret_cast<uint4*>(o); for (int j = 0; j < 12; ++j) q[j] = make_uint4(0, 0, 0, 0); }
+    status[i] = tag == 0 ? 1 : (ok ? 1 : 0);
+}
+
+__device__ __noinline__ void gt_load576(fp12& f, const uint8_t* p) {
+#pragma unroll 1
+    for (int j = 0; j < 12; ++j) {
+        uint32_t raw[12];
+        load_raw48(raw, p + 48 * j);
+        fp_from_raw48(fp12_coord_mut(f, j), raw);
+    }
+}
+// pair_ate alone: the Miller value as FP12_toOctet bytes (the same field element as the reference's)
+__global__ void __launch_bounds__(BLOCK, 2) miller_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* out, int* bad_flag) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    fp px, py; fp2 qx, qy; bool pinf, qinf, ok;
+    pair_inputs(px, py, pinf, qx, qy, qinf, ok, g1 + 96 * i, g2 + 192 * i);
+    if (!ok) { *bad_flag = 1; pinf = true; qinf = true; }
+    fp12 f;
+    miller_loop(f, px, py, pinf, qx, qy, qinf);
+    gt_store576(out + 576 * i, f, !ok);
+}
+// op 0: a*b (FP12_mul), 1: conj(a), 2: a^e (FP12_pow, e = 32-byte exponent used as given), 3: final exponentiation
+__global__ void __launch_bounds__(BLOCK, 2) gt_op_kernel(int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    fp12 x, r;
+    gt_load576(x, a + 576 * i);
+    if (op == 0) { fp12 y; gt_load576(y, b + 576 * i); fp12_mul(r, x, y); }
+    else if (op == 1) { fp12_conj(r, x); }
+    else if (op == 2) { uint32_t raw[8], e[8]; load_raw32(raw, b + 32 * i); scalar_from_raw32(e, raw); fp12_pow_generic(r, x, e); }
+    else { r = x; final_exp(r); }
+    gt_store576(out + 576 * i, r, false);
+}
+// FP12_isunity per element
+__global__ void __launch_bounds__(BLOCK, 2) gt_is_unity_kernel(size_t n, const uint8_t* a, uint8_t* out) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    fp12 x;
+    gt_load576(x, a + 576 * i);
+    out[i] = fp12_is_one(x) ? 1 : 0;
+}
+
 }  // namespace
 
 // ====================================================================== host side
@@ -733,6 +815,71 @@ int c12381_pair_eq_batch(c12381_ctx* c, size_t n, const uint8_t* a1, const uint8
     if ((rc = c12381_pair_eq_batch_dev(c, n, d_a1, d_a2, d_b1, d_b2, d_ok))) return rc;
     HIPCK(c, hipMemcpyAsync(ok, d_ok, n, hipMemcpyDeviceToHost, c->stream));
     return read_flag(c);
+}
+
+// ---------------------------------------------------------------- decode / split pairing / GT
+int c12381_g1_decompress_batch(c12381_ctx* c, size_t n, const uint8_t* in49, uint8_t* out96, uint8_t* status) {
+    int rc = bind(c); if (rc) return rc;
+    if (!in49 || !out96 || !status) return C12381_E_ARG;
+    if (n == 0) return 0;
+    staged s;
+    if ((rc = stage_in(c, s, in49, 49 * n, nullptr, n, 96 * n))) return rc;
+    hipLaunchKernelGGL(g1_decompress_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, s.in0, s.out, s.in1);
+    HIPCK(c, hipGetLastError());
+    if ((rc = stage_out(c, s, out96, 96 * n))) return rc;
+    HIPCK(c, hipMemcpyAsync(status, s.in1, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int c12381_g2_decompress_batch(c12381_ctx* c, size_t n, const uint8_t* in97, uint8_t* out192, uint8_t* status) {
+    int rc = bind(c); if (rc) return rc;
+    if (!in97 || !out192 || !status) return C12381_E_ARG;
+    if (n == 0) return 0;
+    staged s;
+    if ((rc = stage_in(c, s, in97, 97 * n, nullptr, n, 192 * n))) return rc;
+    hipLaunchKernelGGL(g2_decompress_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, s.in0, s.out, s.in1);
+    HIPCK(c, hipGetLastError());
+    if ((rc = stage_out(c, s, out192, 192 * n))) return rc;
+    HIPCK(c, hipMemcpyAsync(status, s.in1, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int c12381_miller_batch(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* out576) {
+    int rc = bind(c); if (rc) return rc;
+    if (!g1 || !g2 || !out576) return C12381_E_ARG;
+    if (n == 0) return 0;
+    staged s;
+    if ((rc = stage_in(c, s, g1, 96 * n, g2, 192 * n, 576 * n))) return rc;
+    hipLaunchKernelGGL(miller_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, s.in0, s.in1, s.out, c->d_flag);
+    HIPCK(c, hipGetLastError());
+    if ((rc = stage_out(c, s, out576, 576 * n))) return rc;
+    return read_flag(c);
+}
+int c12381_gt_op_batch(c12381_ctx* c, int op, size_t n, const uint8_t* a576, const uint8_t* b, uint8_t* out576) {
+    int rc = bind(c); if (rc) return rc;
+    if (op < 0 || op > 3 || !a576 || !out576 || ((op == 0 || op == 2) && !b)) return C12381_E_ARG;
+    if (n == 0) return 0;
+    staged s;
+    const size_t bb = op == 0 ? 576 * n : (op == 2 ? 32 * n : 0);
+    if ((rc = stage_in(c, s, a576, 576 * n, bb ? b : nullptr, bb, 576 * n))) return rc;
+    hipLaunchKernelGGL(gt_op_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, op, n, s.in0, s.in1, s.out);
+    HIPCK(c, hipGetLastError());
+    if ((rc = stage_out(c, s, out576, 576 * n))) return rc;
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int c12381_fexp_batch(c12381_ctx* c, size_t n, const uint8_t* in576, uint8_t* out576) { return c12381_gt_op_batch(c, 3, n, in576, nullptr, out576); }
+int c12381_gt_is_unity_batch(c12381_ctx* c, size_t n, const uint8_t* a576, uint8_t* out) {
+    int rc = bind(c); if (rc) return rc;
+    if (!a576 || !out) return C12381_E_ARG;
+    if (n == 0) return 0;
+    staged s;
+    if ((rc = stage_in(c, s, a576, 576 * n, nullptr, 0, n))) return rc;
+    hipLaunchKernelGGL(gt_is_unity_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, s.in0, s.out);
+    HIPCK(c, hipGetLastError());
+    if ((rc = stage_out(c, s, out, n))) return rc;
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return 0;
 }
 
 }  // extern "C"

@@ -420,5 +420,22 @@ C12381_HDN void fp_pow_fixed(fp& r, const fp& a, const uint32_t (&e)[12]) {
 C12381_HD void fp_inv(fp& r, const fp& a) { fp_pow_fixed(r, a, EXP_P_MINUS_2); }
 // candidate square root a^((p+1)/4) (p = 3 mod 4); caller verifies r^2 == a
 C12381_HD void fp_sqrt_candidate(fp& r, const fp& a) { fp_pow_fixed(r, a, EXP_P_PLUS_1_DIV_4); }
+// One exponentiation h = a^((p-3)/4) (MIRACL's "progen", FP_progen fp_BLS12381.cpp:782-797) yields all of
+//   c = h*a = a^((p+1)/4)  (a square root of a or of -a),   chi = c*h = a^((p-1)/2) = +-1 (0 for a = 0),
+//   1/c = chi*h.   Returns is_qr = (chi == 1), i.e. FP_qr :800-813 (0 is reported as a non-residue).
+C12381_HD bool fp_sqrt_progen(fp& c, fp& cinv, const fp& a) {
+    fp h, an, chi, one, d;
+    fp_norm1(an, a);
+    fp_pow_fixed(h, an, EXP_P_MINUS_3_DIV_4);
+    fp_mul(c, h, an);
+    fp_mul(chi, c, h);
+    fp_one(one);
+    fp_sub(d, chi, one);
+    const bool qr = fp_is_zero(d);
+    fp nh;
+    fp_neg(nh, h);
+    fp_select(cinv, qr, h, nh);
+    return qr;
+}
 
 }  // namespace c12381

@@ -210,4 +210,40 @@ C12381_HDN void fp12_pow_x_unitary(fp12& r, const fp12& a) {
     r = w;
 }
 
+// FP12_pow :736-774 for a per-lane exponent e < 2^256 used AS GIVEN (no reduction): signed-digit ladder over
+// (3e, e) with Granger-Scott squarings, so — like the reference — it is a power only for unitary inputs.
+// Lanes hold different exponents: the schedule is made uniform by always forming both candidates and
+// selecting (no divergence); "started" tracks each lane's own top bit.
+C12381_HDN void fp12_pow_generic(fp12& r, const fp12& a, const uint32_t (&e)[8]) {
+    uint32_t e3[9];
+    {
+        uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { c += (uint64_t)e[i] * 3u; e3[i] = (uint32_t)c; c >>= 32; }
+        e3[8] = (uint32_t)c;
+    }
+    int nb = 0;                                     // number of bits of 3e
+#pragma unroll 1
+    for (int i = 0; i < 9 * 32; ++i) if ((e3[i >> 5] >> (i & 31)) & 1u) nb = i + 1;
+    fp12 w = a, ac, one;
+    fp12_conj(ac, a);
+    fp12_one(one);
+#pragma unroll 1
+    for (int i = 257; i >= 1; --i) {
+        const bool active = i <= nb - 2;            // the reference starts from w = a at bit nb-1
+        fp12 t, m, t2;
+        fp12_usqr(t, w);
+        fp12_weak_reduce(t, t);
+        const int b3 = (int)((e3[i >> 5] >> (i & 31)) & 1u);
+        const int b1 = i < 256 ? (int)((e[i >> 5] >> (i & 31)) & 1u) : 0;
+        const int bt = b3 - b1;
+        fp12_select(m, bt < 0, ac, a);
+        fp12_mul(t2, t, m);
+        fp12 nxt;
+        fp12_select(nxt, bt != 0, t2, t);
+        fp12_select(w, active, nxt, w);
+    }
+    fp12_select(r, nb == 0, one, w);
+}
+
 }  // namespace c12381

@@ -74,6 +74,28 @@ C12381_HD int fp2_sign(const fp2& x) {
     for (int i = 0; i < NL; ++i) o |= ca.l[i];
     return o == 0 ? (cb.l[0] & 1) : (ca.l[0] & 1);
 }
+// FP2_qr :446 + FP2_sqrt :460-521 (complex method) in one pass.  Returns false when the norm a^2+b^2 is a
+// non-residue (or 0); on success w is the root of sign 0, exactly as the reference returns it.
+C12381_HDN bool fp2_sqrt(fp2& w, const fp2& u) {
+    fp n, w1, w1inv, w2, hb, half, ra, rainv, rb;
+    fp_reduce_cols(n, [&](int k) { return fp_col_sqr(u.a, k) + fp_col_sqr(u.b, k); });
+    C12381_BOUNDS(set_lazy_bounds(n, u.a.lb * u.a.lb + u.b.lb * u.b.lb, u.a.vb * u.a.vb + u.b.vb * u.b.vb, "fp2_sqrt");)
+    const bool norm_qr = fp_sqrt_progen(w1, w1inv, n);          // w1 = sqrt(a^2 + b^2)
+    fp_set_const(half, FP_HALF);
+    fp_add(w2, u.a, w1);
+    fp_norm1(w2, w2);
+    fp_mul(w2, w2, half);                                       // (a + w1) / 2
+    fp_mul(hb, u.b, half);                                      // b / 2
+    const bool qr = fp_sqrt_progen(ra, rainv, w2);              // ra = sqrt(w2) or sqrt(-w2); rainv = 1/ra
+    fp_mul(rb, hb, rainv);                                      // (b/2) / ra
+    fp2 r;
+    fp_select(r.a, qr, ra, rb);
+    fp_select(r.b, qr, rb, ra);
+    fp2 nr;
+    fp2_neg(nr, r);
+    fp2_select(w, fp2_sign(r) != 0, nr, r);
+    return norm_qr;
+}
 C12381_HD void fp2_set_const(fp2& r, const int32_t (&ca)[NL], const int32_t (&cb)[NL]) { fp_set_const(r.a, ca); fp_set_const(r.b, cb); }
 
 }  // namespace c12381

@@ -261,4 +261,18 @@ C12381_HD void g1_to_affine(fp& ax, fp& ay, const g1p& p, const fp& zinv) {
     fp_mul(ay, p.y, zinv);
 }
 
+// ------------------------------------------------------------------ compressed-point decoding
+// ECP_setx ecp_BLS12381.cpp:302-323: y = sqrt(x^3 + 4) with parity s; fails when the right-hand side is
+// not a residue (0 counts as a non-residue: FP_qr).  x is taken mod p (FP_nres), no subgroup check.
+C12381_HD bool g1_set_x(fp& y, const fp& x, int s) {
+    fp x2, x3, four, rhs, c, cinv, ny;
+    fp_sqr(x2, x); fp_mul(x3, x2, x);
+    fp_set_const(four, FP_FOUR);
+    fp_add(rhs, x3, four);
+    const bool qr = fp_sqrt_progen(c, cinv, rhs);
+    fp_neg(ny, c);
+    fp_select(y, fp_sign(c) != s, ny, c);
+    return qr;
+}
+
 }  // namespace c12381

@@ -132,4 +132,16 @@ C12381_HDN void g2_scalar_mul(g2p& acc, const fp2& qx, const fp2& qy, bool q_is_
     }
 }
 
+// ECP2_setx ecp2_BLS12381.cpp:322-344: y = sqrt(x^3 + 4(1+i)) with FP2_sign(y) == s.
+C12381_HD bool g2_set_x(fp2& y, const fp2& x, int s) {
+    fp2 x2, x3, b, rhs, r, nr;
+    fp2_sqr(x2, x); fp2_mul(x3, x2, x);
+    fp_set_const(b.a, FP_FOUR); fp_set_const(b.b, FP_FOUR);
+    fp2_add(rhs, x3, b);
+    const bool ok = fp2_sqrt(r, rhs);
+    fp2_neg(nr, r);
+    fp2_select(y, fp2_sign(r) != s, nr, r);
+    return ok;
+}
+
 }  // namespace c12381

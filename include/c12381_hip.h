@@ -109,6 +109,28 @@ int c12381_pair_eq_batch(c12381_ctx* ctx, size_t n, const uint8_t* a1_96, const 
 int c12381_pair_eq_batch_dev(c12381_ctx* ctx, size_t n, const uint8_t* a1_96, const uint8_t* a2_192, const uint8_t* b1_96,
                              const uint8_t* b2_192, uint8_t* ok);
 
+/* wire formats either side of the path -------------------------------------- */
+/* Batched from_bytes(point1&, bytes_view&) for 49-byte compressed input (miracl_core_interface.hpp:92,
+ * src/miracl_core_interface.cpp:109-112 -> ECP_fromOctet -> ECP_setx: one square root per point, on-curve by
+ * construction, NO subgroup check, x taken mod p).  A leading 0x00 byte means infinity (g1_point.hpp:89-93).
+ * status[i] = 1 ok / 0 reject; out96[i] = x||y, zeros for infinity or reject. */
+int c12381_g1_decompress_batch(c12381_ctx* ctx, size_t n, const uint8_t* in49, uint8_t* out96, uint8_t* status);
+/* Batched from_bytes(point2&, bytes_view&) for 97-byte input (:146, :187-190 -> ECP2_fromOctet -> ECP2_setx);
+ * any tag other than 0x04 and 0x00 is treated as compressed with sign = tag & 1, as the reference does. */
+int c12381_g2_decompress_batch(c12381_ctx* ctx, size_t n, const uint8_t* in97, uint8_t* out192, uint8_t* status);
+
+/* split pairing and GT arithmetic (what the reference's GTMiller / GTPoint types call) ----------- */
+/* pair_ate(fp12&, point2&, point1&) alone (:199 -> 276-279 -> PAIR_ate): the Miller value as FP12_toOctet bytes. */
+int c12381_miller_batch(c12381_ctx* ctx, size_t n, const uint8_t* g1_96, const uint8_t* g2_192, uint8_t* out576);
+/* pair_final_exponentiation(fp12&) alone (:201 -> 281-284 -> PAIR_fexp). */
+int c12381_fexp_batch(c12381_ctx* ctx, size_t n, const uint8_t* in576, uint8_t* out576);
+/* op 0: multiply(fp12& r, fp12& v) r*=v (:193 -> 256-259 -> FP12_mul); 1: conjugate (:191 -> 251-254);
+ * 2: pow(fp12&, fp12& base, const big&) (:195 -> 261-264 -> FP12_pow; b = 32-byte exponents, used as given,
+ *    unitary squarings exactly like the reference); 3: final exponentiation. */
+int c12381_gt_op_batch(c12381_ctx* ctx, int op, size_t n, const uint8_t* a576, const uint8_t* b, uint8_t* out576);
+/* is_unity(fp12&) (:197 -> 271-274 -> FP12_isunity): out[i] = 1 / 0. */
+int c12381_gt_is_unity_batch(c12381_ctx* ctx, size_t n, const uint8_t* a576, uint8_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -134,6 +134,18 @@ class Oracle:
         self._ck(self._f("pair_batch")(_sz(n), g1, g2, o, nthreads), "pair_batch")
         return o.raw[:576 * n]
 
+    def miller(self, g1: bytes, g2: bytes) -> bytes:
+        n = len(g1) // 96
+        o = self._buf(576 * n)
+        self._ck(self._f("miller_batch")(_sz(n), g1, g2, o), "miller_batch")
+        return o.raw[:576 * n]
+
+    def fexp(self, f: bytes) -> bytes:
+        n = len(f) // 576
+        o = self._buf(576 * n)
+        self._ck(self._f("fexp_batch")(_sz(n), f, o), "fexp_batch")
+        return o.raw[:576 * n]
+
     def pair_eq(self, a1: bytes, a2: bytes, b1: bytes, b2: bytes, nthreads: int = 1) -> bytes:
         n = len(a1) // 96
         o = self._buf(n)

@@ -769,6 +769,22 @@ int orc_pair_batch(size_t n, const uint8_t* g1_96, const uint8_t* g2_192, uint8_
     par_for(n, nthreads, pair_range, &m);
     return m.bad ? -2 : 0;
 }
+/* PAIR_ate alone and PAIR_fexp alone on FP12_toOctet bytes */
+int orc_miller_batch(size_t n, const uint8_t* g1_96, const uint8_t* g2_192, uint8_t* out576) {
+    INIT();
+    for (size_t i = 0; i < n; i++) {
+        g1p P; g2p Q; fp12 f;
+        if (!g1_load96(&P, g1_96 + 96 * i) || !g2_load192(&Q, g2_192 + 192 * i)) return -2;
+        pair_ate(&f, &Q, &P);
+        fp12_to_bytes(out576 + 576 * i, &f);
+    }
+    return 0;
+}
+int orc_fexp_batch(size_t n, const uint8_t* in576, uint8_t* out576) {
+    INIT();
+    for (size_t i = 0; i < n; i++) { fp12 f; fp12_from_bytes(&f, in576 + 576 * i); pair_fexp(&f); fp12_to_bytes(out576 + 576 * i, &f); }
+    return 0;
+}
 /* pair(a1,a2) == pair(b1,b2) as include/crypto12381/liner_pair.hpp:339-350 of the reference */
 static void pair_eq_range(size_t lo, size_t hi, void* c) {
     pair_ctx* m = (pair_ctx*)c;

@@ -24,6 +24,8 @@ int orc_g2_add_batch(size_t n, const uint8_t* a192, const uint8_t* b192, uint8_t
 int orc_g2_decompress_batch(size_t n, const uint8_t* in97, uint8_t* out192, uint8_t* status);
 int orc_g2_compress_batch(size_t n, const uint8_t* in192, uint8_t* out97);
 int orc_pair_batch(size_t n, const uint8_t* g1_96, const uint8_t* g2_192, uint8_t* gt576, int nthreads);
+int orc_miller_batch(size_t n, const uint8_t* g1_96, const uint8_t* g2_192, uint8_t* out576);
+int orc_fexp_batch(size_t n, const uint8_t* in576, uint8_t* out576);
 int orc_pair_eq_batch(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, uint8_t* ok, int nthreads);
 int orc_pair2_batch(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, uint8_t* gt576);
 int orc_gt_op_batch(int op, size_t n, const uint8_t* a576, const uint8_t* b, uint8_t* out576);

@@ -299,6 +299,31 @@ int ref_pair_batch(size_t n, const uint8_t* g1_96, const uint8_t* g2_192, uint8_
     return bad ? -2 : 0;
 }
 
+// pair_ate alone (Miller value; not canonical in general, but a well-defined field element whose
+// FP12_toOctet bytes can be compared) and pair_final_exponentiation alone, on 576-byte values
+int ref_miller_batch(size_t n, const uint8_t* g1_96, const uint8_t* g2_192, uint8_t* out576) {
+    for (size_t i = 0; i < n; ++i) {
+        mc::point1 P; mc::point2 Q; mc::fp12 f;
+        if (!g1_load(P, g1_96 + 96 * i) || !g2_load(Q, g2_192 + 192 * i)) return -2;
+        mc::pair_ate(f, Q, P);
+        mc::bytes_view v{0, 576, (char*)out576 + 576 * i};
+        mc::to_bytes(v, f);
+    }
+    return 0;
+}
+int ref_fexp_batch(size_t n, const uint8_t* in576, uint8_t* out576) {
+    for (size_t i = 0; i < n; ++i) {
+        mc::fp12 f; char buf[576];
+        std::memcpy(buf, in576 + 576 * i, 576);
+        mc::bytes_view vi{576, 576, buf};
+        mc::from_bytes(f, vi);
+        mc::pair_final_exponentiation(f);
+        mc::bytes_view vo{0, 576, (char*)out576 + 576 * i};
+        mc::to_bytes(vo, f);
+    }
+    return 0;
+}
+
 // e(a1,a2) == e(b1,b2) exactly as include/crypto12381/liner_pair.hpp:339-350:
 // two Miller loops, conjugate, multiply, ONE final exponentiation, is_unity.
 int ref_pair_eq_batch(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, uint8_t* ok, int nthreads) {

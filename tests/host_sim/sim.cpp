@@ -169,3 +169,79 @@ int sim_pair_eq_batch(size_t n, const uint8_t* a1, const uint8_t* a2, const uint
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------- decompression, Miller/fexp split, GT ops
+extern "C" {
+
+int sim_g1_decompress_batch(size_t n, const uint8_t* in49, uint8_t* out96, uint8_t* status) {
+    for (size_t i = 0; i < n; ++i) {
+        const uint8_t* sp = in49 + 49 * i;
+        uint8_t* o = out96 + 96 * i;
+        std::memset(o, 0, 96);
+        if (sp[0] == 0) { status[i] = 1; continue; }
+        if (sp[0] != 2 && sp[0] != 3) { status[i] = 0; continue; }
+        uint32_t raw[12];
+        std::memcpy(raw, sp + 1, 48);
+        fp x, y;
+        fp_from_raw48(x, raw);
+        const bool ok = g1_set_x(y, x, sp[0] & 1);
+        status[i] = ok ? 1 : 0;
+        if (!ok) continue;
+        uint32_t rx[12], ry[12];
+        fp_to_raw48(rx, x); fp_to_raw48(ry, y);
+        std::memcpy(o, rx, 48); std::memcpy(o + 48, ry, 48);
+    }
+    return 0;
+}
+int sim_g2_decompress_batch(size_t n, const uint8_t* in97, uint8_t* out192, uint8_t* status) {
+    for (size_t i = 0; i < n; ++i) {
+        const uint8_t* sp = in97 + 97 * i;
+        uint8_t* o = out192 + 192 * i;
+        std::memset(o, 0, 192);
+        if (sp[0] == 0) { status[i] = 1; continue; }
+        if (sp[0] == 4) { status[i] = 0; continue; }
+        uint8_t tmp[96];
+        std::memcpy(tmp, sp + 1, 96);
+        fp2 x, y;
+        fp2_from_bytes96(x, tmp);
+        const bool ok = g2_set_x(y, x, sp[0] & 1);
+        status[i] = ok ? 1 : 0;
+        if (!ok) continue;
+        fp2_to_bytes96(o, x); fp2_to_bytes96(o + 96, y);
+    }
+    return 0;
+}
+static void gt_load(fp12& f, const uint8_t* p) {
+    for (int j = 0; j < 12; ++j) {
+        uint32_t raw[12];
+        std::memcpy(raw, p + 48 * j, 48);
+        fp_from_raw48(fp12_coord_mut(f, j), raw);
+    }
+}
+// op 0 mul, 1 conj, 2 pow (b = 32-byte exponents), 3 final exponentiation, 4 is-unity (out[0] per element)
+int sim_gt_op_batch(int op, size_t n, const uint8_t* a576, const uint8_t* b, uint8_t* out) {
+    for (size_t i = 0; i < n; ++i) {
+        fp12 x, y, r;
+        gt_load(x, a576 + 576 * i);
+        if (op == 0) { gt_load(y, b + 576 * i); fp12_mul(r, x, y); }
+        else if (op == 1) fp12_conj(r, x);
+        else if (op == 2) { uint32_t rs[8], e[8]; load_raw(rs, b + 32 * i, 8); scalar_from_raw32(e, rs); fp12_pow_generic(r, x, e); }
+        else if (op == 3) { r = x; final_exp(r); }
+        else if (op == 4) { out[i] = fp12_is_one(x) ? 1 : 0; continue; }
+        else return -1;
+        gt_store(out + 576 * i, r);
+    }
+    return 0;
+}
+int sim_miller_batch(size_t n, const uint8_t* g1_96, const uint8_t* g2_192, uint8_t* out576) {
+    for (size_t i = 0; i < n; ++i) {
+        fp px, py; fp2 qx, qy; bool pinf, qinf;
+        pair_load(px, py, pinf, qx, qy, qinf, g1_96 + 96 * i, g2_192 + 192 * i);
+        fp12 f;
+        miller_loop(f, px, py, pinf, qx, qy, qinf);
+        gt_store(out576 + 576 * i, f);
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -88,3 +88,53 @@ def test_pairing_full_size_2_16(ctx, oracle_port):
     sq = b"".join(Q[192 * i:192 * i + 192] for i in idx)
     exp = oracle_port.pair(sp, sq, 16)
     assert b"".join(gt[576 * i:576 * i + 576] for i in idx) == exp
+
+
+def test_decompress_golden(ctx):
+    g = golden("g1")
+    out, st = ctx.g1_decompress(cat(g["compressed"]))
+    assert list(st) == g["decompress_status"] and out == cat(g["decompressed"])
+    g = golden("g2")
+    out, st = ctx.g2_decompress(cat(g["compressed"]))
+    assert list(st) == g["decompress_status"] and out == cat(g["decompressed"])
+
+
+def test_decompress_roundtrip_vs_oracle(ctx, oracle_port):
+    n = 2000
+    g1 = bytes.fromhex(golden("g1")["generator"])
+    pts = ctx.g1_mul(g1 * n, scalars(431, n), 96)
+    comp = ctx.g1_mul(g1 * n, scalars(431, n), 49)
+    assert comp == oracle_port.g1_compress(pts)
+    out, st = ctx.g1_decompress(comp)
+    assert st == b"\x01" * n and out == pts
+    # random x: about half are not on the curve; statuses and points must match the oracle lane by lane
+    rnd = b"".join(bytes([2 + (i & 1)]) + (prng(432, i, 48) % (1 << 381)).to_bytes(48, "big") for i in range(n))
+    out, st = ctx.g1_decompress(rnd)
+    eo, es = oracle_port.g1_decompress(rnd)
+    assert st == es and out == eo and 0 < sum(st) < n
+    g2 = bytes.fromhex(golden("g2")["generator"])
+    m = 500
+    q = ctx.g2_mul(g2 * m, scalars(433, m), 192)
+    qc = ctx.g2_mul(g2 * m, scalars(433, m), 97)
+    out, st = ctx.g2_decompress(qc)
+    assert st == b"\x01" * m and out == q
+    rnd2 = b"".join(bytes([2 + (i & 1)]) + (prng(434, i, 48) % (1 << 381)).to_bytes(48, "big") + (prng(435, i, 48) % (1 << 381)).to_bytes(48, "big")
+                    for i in range(m))
+    out, st = ctx.g2_decompress(rnd2)
+    eo, es = oracle_port.g2_decompress(rnd2)
+    assert st == es and out == eo and 0 < sum(st) < m
+
+
+def test_gt_ops_and_split_pairing(ctx, oracle_port):
+    g = golden("pairing")
+    gt = cat(g["gt"])
+    gta, gtb = gt[:576 * 4], gt[576 * 4:]
+    assert ctx.gt_op("mul", gta, gtb) == cat(g["gt_mul"])
+    assert ctx.gt_op("conj", gta) == cat(g["gt_conj"])
+    assert ctx.gt_op("pow", gta, cat(g["gt_pow_exp"])) == cat(g["gt_pow"])
+    g1, g2 = cat(g["g1"]), cat(g["g2"])
+    m = ctx.miller(g1, g2)
+    assert m == oracle_port.miller(g1, g2)
+    assert ctx.fexp(m) == gt
+    one = ctx.gt_op("mul", gta, ctx.gt_op("conj", gta))     # unitary: a * conj(a) = 1
+    assert ctx.gt_is_unity(one) == b"\x01" * 4 and ctx.gt_is_unity(gta)[:3] == b"\x00" * 3

@@ -104,3 +104,38 @@ def test_sim_pairing_golden(sim):
     ok = ctypes.create_string_buffer(m)
     assert sim.sim_pair_eq_batch(sz(m), a1, a2, b1, b2, ok) == 0
     assert list(ok.raw[:m]) == g["eq"]
+
+
+def test_sim_decompress(sim):
+    g = golden("g1")
+    cin = cat(g["compressed"])
+    n = len(cin) // 49
+    out, st = ctypes.create_string_buffer(96 * n), ctypes.create_string_buffer(n)
+    assert sim.sim_g1_decompress_batch(sz(n), cin, out, st) == 0
+    assert list(st.raw[:n]) == g["decompress_status"]
+    assert out.raw == cat(g["decompressed"])
+    g = golden("g2")
+    cin = cat(g["compressed"])
+    n = len(cin) // 97
+    out, st = ctypes.create_string_buffer(192 * n), ctypes.create_string_buffer(n)
+    assert sim.sim_g2_decompress_batch(sz(n), cin, out, st) == 0
+    assert list(st.raw[:n]) == g["decompress_status"]
+    assert out.raw == cat(g["decompressed"])
+
+
+def test_sim_gt_ops_and_split_pairing(sim, oracle_port):
+    g = golden("pairing")
+    gt = cat(g["gt"])
+    gta, gtb = gt[:576 * 4], gt[576 * 4:]
+    out = ctypes.create_string_buffer(576 * 4)
+    assert sim.sim_gt_op_batch(0, sz(4), gta, gtb, out) == 0 and out.raw == cat(g["gt_mul"])
+    assert sim.sim_gt_op_batch(1, sz(4), gta, None, out) == 0 and out.raw == cat(g["gt_conj"])
+    assert sim.sim_gt_op_batch(2, sz(4), gta, cat(g["gt_pow_exp"]), out) == 0 and out.raw == cat(g["gt_pow"])
+    # Miller value and final exponentiation separately, against the oracle's PAIR_ate / PAIR_fexp
+    g1, g2 = cat(g["g1"])[:96 * 3], cat(g["g2"])[:192 * 3]
+    m = ctypes.create_string_buffer(576 * 3)
+    assert sim.sim_miller_batch(sz(3), g1, g2, m) == 0
+    assert m.raw == oracle_port.miller(g1, g2)
+    f = ctypes.create_string_buffer(576 * 3)
+    assert sim.sim_gt_op_batch(3, sz(3), m.raw, None, f) == 0
+    assert f.raw == gt[:576 * 3] == oracle_port.fexp(m.raw)
