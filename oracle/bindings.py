@@ -17,6 +17,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PORT = os.path.join(_HERE, "liboracle.so")
 _REF = os.path.join(_HERE, "_ref", "libc12381_ref.so")
+_SHIM = os.path.join(_HERE, "_ref", "libc12381_shimtest.so")     # same wrapper, boundary overridden by our HIP shim
 
 _sz = ctypes.c_size_t
 
@@ -31,11 +32,15 @@ def have_reference() -> bool:
     return os.path.exists(_REF)
 
 
+def have_shim() -> bool:
+    return os.path.exists(_SHIM)
+
+
 class Oracle:
     def __init__(self, kind: str = "port"):
-        if kind not in ("port", "reference"):
+        if kind not in ("port", "reference", "shim"):
             raise ValueError(kind)
-        path = _PORT if kind == "port" else _REF
+        path = {"port": _PORT, "reference": _REF, "shim": _SHIM}[kind]
         if not os.path.exists(path):
             build()
         if not os.path.exists(path):

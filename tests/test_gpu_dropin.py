@@ -1,0 +1,81 @@
+"""GPU test of the DROP-IN boundary: oracle/_ref/libc12381_shimtest.so is the reference's own boundary file +
+MIRACL for hash/big/random, with crypto12381_amd/csrc/miracl_core_interface_hip.cpp linked in front so that
+every G1 / G2 / GT boundary function runs on the GPU through the C ABI (size-1 batches).  The same wrapper
+(oracle/ref_wrap.cpp) drives both libraries, so equality of outputs is equality at the reference's seam."""
+import pytest
+
+from util import R, cat, golden, scalars
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def shim():
+    from oracle.bindings import Oracle, have_shim
+    if not have_shim():
+        pytest.skip("oracle/_ref/libc12381_shimtest.so not built (needs /root/reference at build time)")
+    return Oracle("shim")
+
+
+def test_dropin_g1(shim, oracle_ref):
+    g = golden("g1")
+    pts, sc = cat(g["points"]), cat(g["scalars"])
+    assert shim.g1_generator() == oracle_ref.g1_generator()
+    assert shim.g1_mul(pts, sc, 49) == cat(g["mul49"])                      # multiply + to_bytes(compressed)
+    assert shim.g1_mul(pts, sc, 96) == cat(g["mul96"])
+    assert shim.g1_add(cat(g["add_a"]), cat(g["add_b"]), 96) == cat(g["add96"])
+    dec, st = shim.g1_decompress(cat(g["compressed"]))                       # from_bytes (sqrt on the device)
+    assert list(st) == g["decompress_status"] and dec == cat(g["decompressed"])
+    assert shim.g1_msm(pts, sc, 49, 1).hex() == g["msm49"]                  # multiply + add chain
+
+
+def test_dropin_g1_sum_of_products_and_double_multiply(shim, oracle_ref):
+    import ctypes
+    g = golden("g1")
+    pts, sc = cat(g["points"])[:96 * 9], cat(g["scalars"])[:32 * 9]
+    for lib in (shim, oracle_ref):
+        o = ctypes.create_string_buffer(49)
+        assert lib.lib.ref_g1_sum_of_products(9, pts, sc, o, 49) == 0
+        lib._sop = o.raw[:49]
+        o2 = ctypes.create_string_buffer(96 * 4)
+        assert lib.lib.ref_g1_mul2_batch(ctypes.c_size_t(4), pts[:96 * 4], pts[96 * 4:96 * 8], sc[:32 * 4], sc[32 * 4:32 * 8], o2, 96) == 0
+        lib._mul2 = o2.raw[:96 * 4]
+    assert shim._sop == oracle_ref._sop == oracle_ref.g1_msm(pts, sc, 49, 1)
+    assert shim._mul2 == oracle_ref._mul2
+
+
+def test_dropin_g2(shim, oracle_ref):
+    g = golden("g2")
+    pts, sc = cat(g["points"]), cat(g["scalars"])
+    assert shim.g2_generator() == oracle_ref.g2_generator()
+    assert shim.g2_mul(pts, sc, 97) == cat(g["mul97"])
+    assert shim.g2_mul(pts, sc, 192) == cat(g["mul192"])
+    assert shim.g2_add(cat(g["add_a"]), cat(g["add_b"]), 192) == cat(g["add192"])
+    dec, st = shim.g2_decompress(cat(g["compressed"]))
+    assert list(st) == g["decompress_status"] and dec == cat(g["decompressed"])
+
+
+def test_dropin_pairing_and_gt(shim, oracle_ref):
+    g = golden("pairing")
+    g1, g2 = cat(g["g1"]), cat(g["g2"])
+    gt = shim.pair(g1, g2)                                                   # pair_ate + pair_final_exponentiation + to_bytes
+    assert gt == cat(g["gt"])
+    a1, a2, b1, b2 = g1[:96 * 4], g2[:192 * 4], g1[96 * 4:], g2[192 * 4:]
+    assert shim.pair2(a1, a2, b1, b2) == cat(g["pair2"])                    # pair_double_ate
+    assert list(shim.pair_eq(cat(g["eq_a1"]), cat(g["eq_a2"]), cat(g["eq_b1"]), cat(g["eq_b2"]))) == g["eq"]
+    gta, gtb = gt[:576 * 4], gt[576 * 4:]
+    assert shim.gt_op("mul", gta, gtb) == cat(g["gt_mul"])
+    assert shim.gt_op("conj", gta) == cat(g["gt_conj"])
+    assert shim.gt_op("pow", gta, cat(g["gt_pow_exp"])) == cat(g["gt_pow"])
+    assert shim.miller(g1, g2) == oracle_ref.miller(g1, g2)
+
+
+def test_dropin_config1_bilinearity(shim):
+    """BASELINE configs[0] at the boundary, on the GPU: pair(g1^x, g2^y) == pair(g1, g2)^(xy)."""
+    g = golden("config1_bilinearity")
+    sc = cat(g["scalars"])
+    x, y = sc[64:96], sc[96:128]
+    Pp, Qq = bytes.fromhex(g["P"]), bytes.fromhex(g["Q"])
+    lhs = shim.pair(shim.g1_mul(Pp, x, 96), shim.g2_mul(Qq, y, 192))
+    assert lhs.hex() == g["pair_Px_Qy"]
+    assert shim.gt_op("pow", shim.pair(Pp, Qq), bytes.fromhex(g["xy"])) == lhs
