@@ -94,56 +94,106 @@ C12381_HD void fp2_weak_reduce(fp2& r, const fp2& x) { fp_weak_reduce(r.a, x.a);
 C12381_HD void fp4_weak_reduce(fp4& r, const fp4& x) { fp2_weak_reduce(r.a, x.a); fp2_weak_reduce(r.b, x.b); }
 C12381_HDN void fp12_weak_reduce(fp12& r, const fp12& x) { fp4_weak_reduce(r.a, x.a); fp4_weak_reduce(r.b, x.b); fp4_weak_reduce(r.c, x.c); }
 
+// ---- fused helpers: the Fp12 routines below keep their Fp4 temporaries in private memory, so every pass over
+// them is HBM traffic (profiles/r01_pmc_summary_before_table_fix.txt: the first pairing kernel moved ~2.5 MB per
+// pairing and was bandwidth-bound).  Sums feeding a product are formed inside the product routine and each
+// result is assembled in ONE pass over the products.
+// (x1 + x2) * (y1 + y2)
+C12381_HDN void fp4_mul_ss(fp4& w, const fp4& x1, const fp4& x2, const fp4& y1, const fp4& y2) {
+    fp4 sx, sy;
+    fp4_addn(sx, x1, x2);
+    fp4_addn(sy, y1, y2);
+    fp2 t1, t2, t3, t4;
+    fp2_mul(t1, sx.a, sy.a);
+    fp2_mul(t2, sx.b, sy.b);
+    fp2_add(t3, sy.b, sy.a);
+    fp2_add(t4, sx.b, sx.a);
+    fp2_mul(t4, t4, t3);
+    fp2_sub(t4, t4, t1);
+    fp2_sub(t4, t4, t2);
+    fp2_mul_ip(t3, t2);
+    fp2_add(t3, t3, t1);
+    fp2_norm1(w.b, t4);
+    fp2_norm1(w.a, t3);
+}
+// (x1 + x2 + x3)^2
+C12381_HDN void fp4_sqr_s3(fp4& w, const fp4& x1, const fp4& x2, const fp4& x3) {
+    fp4 t, x;
+    fp4_add(t, x1, x2); fp4_add(t, t, x3); fp4_norm1(x, t);
+    fp2 t1, t2, t3, wa;
+    fp2_mul(t3, x.a, x.b);
+    fp2_add(t1, x.a, x.b);
+    fp2_mul_ip(t2, x.b);
+    fp2_add(t2, x.a, t2);
+    fp2_norm1(t2, t2);
+    fp2_mul(wa, t1, t2);
+    fp2_mul_ip(t2, t3);
+    fp2_add(t2, t2, t3);
+    fp2_sub(wa, wa, t2);
+    fp2_dbl(t3, t3);
+    fp2_norm1(w.a, wa);
+    fp2_norm1(w.b, t3);
+}
+// w = z0 + s(z3 - z2 - z4),  z1 - z0 - z2 + s z4,  z5 - z0 - z4 + z2     (one pass over the six products)
+C12381_HDN void fp12_mul_combine(fp12& w, const fp4& z0, const fp4& z1, const fp4& z2, const fp4& z3, const fp4& z4, const fp4& z5) {
+    fp4 t, u;
+    fp4_sub(t, z3, z2); fp4_sub(t, t, z4); fp4_times_i(u, t); fp4_add(u, u, z0);
+    fp4_norm1(w.a, u);
+    fp4_sub(t, z1, z0); fp4_sub(t, t, z2); fp4_times_i(u, z4); fp4_add(t, t, u);
+    fp4_norm1(w.b, t);
+    fp4_sub(t, z5, z0); fp4_sub(t, t, z4); fp4_add(t, t, z2);
+    fp4_norm1(w.c, t);
+}
 // FP12_mul :246-299 (Karatsuba over Fp4: 6 Fp4 products = 18 Fp2 products)
 C12381_HDN void fp12_mul(fp12& w, const fp12& x, const fp12& y) {
-    fp4 z0, z1, z2, z3, t0, t1, wb;
+    fp4 z0, z1, z2, z3, z4, z5;
     fp4_mul(z0, x.a, y.a);
     fp4_mul(z2, x.b, y.b);
-    fp4_addn(t0, x.a, x.b); fp4_addn(t1, y.a, y.b); fp4_mul(z1, t0, t1);
-    fp4_addn(t0, x.b, x.c); fp4_addn(t1, y.b, y.c); fp4_mul(z3, t0, t1);
-    fp4_sub(z1, z1, z0); fp4_sub(wb, z1, z2);
-    fp4_sub(z3, z3, z2);
-    fp4_sub(z2, z2, z0);
-    fp4_addn(t0, x.a, x.c); fp4_addn(t1, y.a, y.c); fp4_mul(t0, t1, t0);
-    fp4_add(z2, z2, t0);
-    fp4_mul(t0, x.c, y.c);
-    fp4_sub(z2, z2, t0);
-    fp4_sub(z3, z3, t0);
-    fp4_times_i(t1, t0); fp4_add(wb, wb, t1);
-    fp4_norm1(z3, z3); fp4_times_i(t1, z3); fp4_add(z0, z0, t1);
-    fp4_norm1(w.a, z0); fp4_norm1(w.b, wb); fp4_norm1(w.c, z2);
+    fp4_mul(z4, x.c, y.c);
+    fp4_mul_ss(z1, x.a, x.b, y.a, y.b);
+    fp4_mul_ss(z3, x.b, x.c, y.b, y.c);
+    fp4_mul_ss(z5, x.a, x.c, y.a, y.c);
+    fp12_mul_combine(w, z0, z1, z2, z3, z4, z5);
 }
-// FP12_sqr :190-238 (Chung-Hasan SQR2: 3 Fp4 squarings + 2 Fp4 products)
+// wa = A + s 2B,  wb = s C + 2D,  wc = S - A - 2B - C - 2D
+C12381_HDN void fp12_sqr_combine(fp12& w, const fp4& A, const fp4& B, const fp4& C, const fp4& D, const fp4& S) {
+    fp4 b2, d2, t, u;
+    fp4_add(b2, B, B); fp4_add(d2, D, D);
+    fp4_times_i(u, b2); fp4_add(u, u, A);
+    fp4_norm1(w.a, u);
+    fp4_times_i(u, C); fp4_add(u, u, d2);
+    fp4_norm1(w.b, u);
+    fp4_sub(t, S, A); fp4_sub(t, t, b2); fp4_sub(t, t, C); fp4_sub(t, t, d2);
+    fp4_norm1(w.c, t);
+}
+// FP12_sqr :190-238 (Chung-Hasan SQR2: 3 Fp4 squarings + 2 Fp4 products).  w may alias x.
 C12381_HDN void fp12_sqr(fp12& w, const fp12& x) {
-    fp4 A, B, C, D, S, t;
+    fp4 A, B, C, D, S;
     fp4_sqr(A, x.a);
     fp4_mul(B, x.b, x.c);
     fp4_sqr(C, x.c);
     fp4_mul(D, x.a, x.b);
-    fp4_add(t, x.a, x.c); fp4_add(t, t, x.b); fp4_norm1(t, t);
-    fp4_sqr(S, t);
-    fp4_add(B, B, B); fp4_add(D, D, D);
-    // wc = S - (A + B + C + D)
-    fp4_add(t, A, B); fp4_add(t, t, C); fp4_add(t, t, D);
-    fp4_sub(S, S, t);
-    fp4 sB, sC;
-    fp4_times_i(sB, B); fp4_times_i(sC, C);
-    fp4_add(A, A, sB);
-    fp4_add(D, D, sC);
-    fp4_norm1(w.a, A); fp4_norm1(w.b, D); fp4_norm1(w.c, S);
+    fp4_sqr_s3(S, x.a, x.b, x.c);
+    fp12_sqr_combine(w, A, B, C, D, S);
 }
-// FP12_usqr :147-186 (Granger-Scott; equals sqr only for unitary elements)
-C12381_HDN void fp12_usqr(fp12& w, const fp12& x) {
-    fp4 A, B, C, t, wa, wb, wc;
-    fp4_sqr(wa, x.a);
-    fp4_add(t, wa, wa); fp4_add(wa, t, wa);                    // 3 xa^2
-    fp4_nconj(A, x.a); fp4_add(A, A, A); fp4_add(wa, wa, A);   // - 2 conj(xa)
-    fp4_sqr(B, x.c); fp4_times_i(t, B); fp4_norm1(t, t); fp4_add(B, t, t); fp4_add(B, B, t);      // 3 s xc^2
-    fp4_sqr(C, x.b); fp4_add(t, C, C); fp4_add(C, C, t);                         // 3 xb^2
-    fp4_conj(wb, x.b); fp4_add(wb, wb, wb);
-    fp4_nconj(wc, x.c); fp4_add(wc, wc, wc);
-    fp4_add(wb, B, wb); fp4_add(wc, C, wc);
+// wa = 3A - 2 conj(xa),  wb = 3 s B + 2 conj(xb),  wc = 3C - 2 conj(xc)     (w may alias x)
+C12381_HDN void fp12_usqr_combine(fp12& w, const fp12& x, const fp4& A, const fp4& B, const fp4& C) {
+    fp4 t, u, wa, wb, wc;
+    fp4_add(t, A, A); fp4_add(t, t, A);
+    fp4_nconj(u, x.a); fp4_add(u, u, u); fp4_add(wa, t, u);
+    fp4_times_i(t, B); fp4_norm1(t, t); fp4_add(u, t, t); fp4_add(t, u, t);
+    fp4_conj(u, x.b); fp4_add(u, u, u); fp4_add(wb, t, u);
+    fp4_add(t, C, C); fp4_add(t, t, C);
+    fp4_nconj(u, x.c); fp4_add(u, u, u); fp4_add(wc, t, u);
     fp4_norm1(w.a, wa); fp4_norm1(w.b, wb); fp4_norm1(w.c, wc);
+}
+// FP12_usqr :147-186 (Granger-Scott; equals sqr only for unitary elements).  w may alias x.
+C12381_HDN void fp12_usqr(fp12& w, const fp12& x) {
+    fp4 A, B, C;
+    fp4_sqr(A, x.a);
+    fp4_sqr(B, x.c);
+    fp4_sqr(C, x.b);
+    fp12_usqr_combine(w, x, A, B, C);
 }
 // FP12_inv :627-664
 C12381_HDN void fp12_inv(fp12& w, const fp12& x) {
@@ -171,24 +221,39 @@ C12381_HDN void fp12_frob(fp12& w, const fp12& x) {
     // conj leaves .a lazily negated only: still normalised
     w.a = a; w.b = b; w.c = c;
 }
+// X * la (dense Fp4 product) and (X.a * l2, X.b * l2) in one routine: X is read once
+C12381_HDN void fp4_mul_la_l2(fp4& p, fp2& q0, fp2& q1, const fp4& x, const fp4& la, const fp2& l2) {
+    fp2_mul(q0, x.a, l2);
+    fp2_mul(q1, x.b, l2);
+    fp2 t1, t2, t3, t4;
+    fp2_mul(t1, x.a, la.a);
+    fp2_mul(t2, x.b, la.b);
+    fp2_add(t3, la.b, la.a);
+    fp2_add(t4, x.b, x.a);
+    fp2_mul(t4, t4, t3);
+    fp2_sub(t4, t4, t1);
+    fp2_sub(t4, t4, t2);
+    fp2_mul_ip(t3, t2);
+    fp2_add(t3, t3, t1);
+    fp2_norm1(p.b, t4);
+    fp2_norm1(p.a, t3);
+}
 // f *= line, line = [l0, l1] + [0, l2] w^2  (the M-type sparse element of PAIR_line pair_BLS12381.cpp:129-143;
 // replaces FP12_ssmul's dense x sparser branch fp12_BLS12381.cpp:440-487).  15 Fp2 products.
+//   wa = fa*la + s*(fb*lc),  wb = fb*la + s*(fc*lc),  wc = fc*la + fa*lc,   lc = l2 s:
+//   X*lc = ((1+i) x1 l2, x0 l2),   s*(X*lc) = ((1+i) x0 l2, (1+i) x1 l2)
 C12381_HDN void fp12_mul_line(fp12& f, const fp2& l0, const fp2& l1, const fp2& l2) {
     fp4 la; la.a = l0; la.b = l1;
     fp4 pa, pb, pc;
-    fp4_mul(pa, f.a, la); fp4_mul(pb, f.b, la); fp4_mul(pc, f.c, la);
     fp2 a0, a1, b0, b1, c0, c1;
-    fp2_mul(a0, f.a.a, l2); fp2_mul(a1, f.a.b, l2);
-    fp2_mul(b0, f.b.a, l2); fp2_mul(b1, f.b.b, l2);
-    fp2_mul(c0, f.c.a, l2); fp2_mul(c1, f.c.b, l2);
+    fp4_mul_la_l2(pa, a0, a1, f.a, la, l2);
+    fp4_mul_la_l2(pb, b0, b1, f.b, la, l2);
+    fp4_mul_la_l2(pc, c0, c1, f.c, la, l2);
     fp2 t;
-    // wa = fa*la + s*(fb*lc),  s*(X*lc) = ((1+i) x0 l2, (1+i) x1 l2)
     fp2_mul_ip(t, b0); fp2_add(pa.a, pa.a, t);
     fp2_mul_ip(t, b1); fp2_add(pa.b, pa.b, t);
-    // wb = fb*la + s*(fc*lc)
     fp2_mul_ip(t, c0); fp2_add(pb.a, pb.a, t);
     fp2_mul_ip(t, c1); fp2_add(pb.b, pb.b, t);
-    // wc = fc*la + fa*lc,  X*lc = ((1+i) x1 l2, x0 l2)
     fp2_mul_ip(t, a1); fp2_add(pc.a, pc.a, t);
     fp2_add(pc.b, pc.b, a0);
     fp4_norm1(f.a, pa); fp4_norm1(f.b, pb); fp4_norm1(f.c, pc);
@@ -200,12 +265,11 @@ C12381_HDN void fp12_pow_x_unitary(fp12& r, const fp12& a) {
     fp12 w = a;
 #pragma unroll 1
     for (int i = 62; i >= 0; --i) {
-        fp12 t;
-        fp12_usqr(t, w);
+        fp12_usqr(w, w);
         // the squaring carries the linear term -2 conj(w): the integer representative doubles each
         // step, so re-bound it every 2nd step (data-independent schedule)
-        if ((i & 1) == 0) fp12_weak_reduce(w, t); else w = t;
-        if ((BLS_X >> i) & 1ull) { fp12_mul(t, w, a); w = t; }
+        if ((i & 1) == 0) fp12_weak_reduce(w, w);
+        if ((BLS_X >> i) & 1ull) fp12_mul(w, w, a);
     }
     r = w;
 }

@@ -69,9 +69,7 @@ C12381_HDN void miller_loop(fp12& f, const fp& px, const fp& py, bool p_inf, con
     constexpr unsigned __int128 N3 = N1 * 3;
 #pragma unroll 1
     for (int i = 64; i >= 1; --i) {
-        fp12 t;
-        fp12_sqr(t, f);
-        f = t;
+        fp12_sqr(f, f);
         fp2 l0, l1, l2;
         miller_dbl_step(T, l0, l1, l2, px, py);
         fp12_mul_line(f, l0, l1, l2);
