@@ -187,13 +187,17 @@ def main():
         avg_launch_s = (mul_ms / max(mul_launches, 1)) * 1e-3
         hbm_achieved = BYTES_PER_G1_MUL * units_per_launch / avg_launch_s / 1e9
         valu_achieved = MAC32_PER_G1_MUL * units_per_launch / avg_launch_s
-        traffic = None
+        # HBM bytes per launch from the committed PMC passes (profiles/traffic.json), scaled to this launch size
+        traffic = pair_traffic = None
         tr_path = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tr_path):
             try:
-                traffic = json.load(open(tr_path)).get("g1_mul_kernel_hbm_bytes_per_launch")
+                tj = json.load(open(tr_path))
+                traffic = tj["g1_mul_kernel_hbm_bytes_per_launch"] * units_per_launch / tj["units_per_launch"]
+                if pair is not None:
+                    pair_traffic = tj["pair_kernel"]["hbm_bytes_per_launch"] * pair["npair"] / tj["pair_kernel"]["units_per_launch"]
             except Exception:
-                traffic = None
+                traffic = pair_traffic = None
         result = {
             "metric": "G1 scalar-muls/s per MI355X (batch 2^%d per GPU), bit-exact vs CPU" % args.log2_batch,
             "value": value, "unit": "scalar-muls/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -244,7 +248,7 @@ def main():
                 "ms_per_step": pair["elapsed"] / pair["steps"] * 1e3,
                 "parity": {"checked_lanes": len(pidx), "oracle": kind, "bit_exact": True},
                 "roofline": {"bound": "hbm", "achieved": BYTES_PER_PAIRING * npair / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": BYTES_PER_PAIRING * npair / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "pair_kernel",
+                             "frac": BYTES_PER_PAIRING * npair / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": pair_traffic, "kernel": "pair_kernel",
                              "avg_launch_ms": avg_s * 1e3},
                 "valu_roofline": {"bound": "int-valu", "achieved": MAC32_PER_PAIRING * npair / avg_s / 1e9, "peak": VALU_PEAK_MAC32 / 1e9,
                                   "unit": "GMAC32/s", "frac": MAC32_PER_PAIRING * npair / avg_s / VALU_PEAK_MAC32,
