@@ -60,6 +60,8 @@ def load_library() -> ctypes.CDLL:
         lib.c12381_fexp_batch.argtypes = [vp, sz, vp, vp]
         lib.c12381_gt_op_batch.argtypes = [vp, ci, sz, vp, vp, vp]
         lib.c12381_gt_is_unity_batch.argtypes = [vp, sz, vp, vp]
+        for name in ("c12381_bbs_plus_verify_batch", "c12381_bbs_plus_verify_batch_dev"):
+            getattr(lib, name).argtypes = [vp, sz, sz] + [vp] * 10
         _lib = lib
     return _lib
 
@@ -204,6 +206,20 @@ class Context:
         out = ctypes.create_string_buffer(max(n, 1))
         self._ck(self.lib.c12381_gt_is_unity_batch(self.h, n, _p(a), _p(out)))
         return out.raw[:n]
+
+    def bbs_plus_verify(self, g1: bytes, g2: bytes, h0: bytes, h: bytes, w: bytes, A: bytes, x: bytes, r: bytes, m: bytes,
+                        strict: bool = True) -> bytes:
+        """m is message-major: block i of signature j at m[32*(i*n + j)]."""
+        n = len(A) // 96
+        nmsg = len(h) // 96
+        out = ctypes.create_string_buffer(max(n, 1))
+        self._ck(self.lib.c12381_bbs_plus_verify_batch(self.h, n, nmsg, _p(g1), _p(g2), _p(h0), _p(h) if nmsg else None, _p(w), _p(A),
+                                                       _p(x), _p(r), _p(m) if nmsg else None, _p(out)), allow_point=not strict)
+        return out.raw[:n]
+
+    def bbs_plus_verify_dev(self, n, nmsg, g1, g2, h0, h, w, A, x, r, m, ok):
+        self._ck(self.lib.c12381_bbs_plus_verify_batch_dev(self.h, n, nmsg, _p(g1), _p(g2), _p(h0), _p(h), _p(w), _p(A), _p(x), _p(r),
+                                                           _p(m), _p(ok)))
 
     # ---- device-pointer entry points (ints = device addresses, e.g. torch tensor.data_ptr())
     def g2_mul_dev(self, n, pts_ptr, sc_ptr, out_ptr, fmt=97):

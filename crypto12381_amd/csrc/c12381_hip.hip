@@ -109,13 +109,14 @@ __global__ void __launch_bounds__(BLOCK) fp_mulchain_kernel(size_t n, int iters,
 
 // ------------------------------------------------------------------ G1 kernels
 // proj layout: coordinate-major, limb-major SoA: proj[(c*NL + limb) * stride + element]
-__global__ void __launch_bounds__(BLOCK, 2) g1_mul_kernel(size_t n, const uint8_t* pts, const uint8_t* scalars, int32_t* tab,
+// pt_stride = 96 for per-lane points, 0 to broadcast one point to every lane (fixed-base columns of BBS+)
+__global__ void __launch_bounds__(BLOCK, 2) g1_mul_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab,
                                                        int32_t* proj, size_t proj_stride, size_t proj_off, int* bad_flag) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     fp px, py;
     bool inf, ok;
-    g1_parse96(px, py, inf, ok, pts + 96 * i);
+    g1_parse96(px, py, inf, ok, pts + pt_stride * i);
     uint32_t raw[8], k[8];
     load_raw32(raw, scalars + 32 * i);
     scalar_from_raw32(k, raw);
@@ -288,13 +289,13 @@ __device__ __noinline__ void g2_store_affine(uint8_t* o, const g2p& acc, int fmt
     }
 }
 
-__global__ void __launch_bounds__(BLOCK) g2_mul_kernel(size_t n, const uint8_t* pts, const uint8_t* scalars, int32_t* tab, size_t tab_stride,
-                                                       uint8_t* out, int fmt, int* bad_flag) {
+__global__ void __launch_bounds__(BLOCK) g2_mul_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab,
+                                                       size_t tab_stride, uint8_t* out, int fmt, int* bad_flag) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     fp2 qx, qy;
     bool inf, ok;
-    g2_parse192(qx, qy, inf, ok, pts + 192 * i);
+    g2_parse192(qx, qy, inf, ok, pts + pt_stride * i);
     uint32_t raw[8], k[8];
     load_raw32(raw, scalars + 32 * i);
     scalar_from_raw32(k, raw);
@@ -304,12 +305,13 @@ __global__ void __launch_bounds__(BLOCK) g2_mul_kernel(size_t n, const uint8_t* 
     g2_store_affine(out + (size_t)fmt * i, acc, fmt, !ok);
 }
 
-__global__ void __launch_bounds__(BLOCK) g2_add_kernel(size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out, int fmt, int* bad_flag) {
+__global__ void __launch_bounds__(BLOCK) g2_add_kernel(size_t n, const uint8_t* a, size_t a_stride, const uint8_t* b, uint8_t* out, int fmt,
+                                                       int* bad_flag) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     g2p p, q, inf_pt;
     bool ia, oa, ib, ob;
-    g2_parse192(p.x, p.y, ia, oa, a + 192 * i); fp2_one(p.z);
+    g2_parse192(p.x, p.y, ia, oa, a + a_stride * i); fp2_one(p.z);
     g2_parse192(q.x, q.y, ib, ob, b + 192 * i); fp2_one(q.z);
     g2_set_inf(inf_pt);
     fp2_select(p.x, ia, inf_pt.x, p.x); fp2_select(p.y, ia, inf_pt.y, p.y); fp2_select(p.z, ia, inf_pt.z, p.z);
@@ -349,7 +351,7 @@ __global__ void __launch_bounds__(BLOCK, 2) pair_kernel(size_t n, const uint8_t*
 }
 
 __global__ void __launch_bounds__(BLOCK, 2) pair_eq_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2,
-                                                        uint8_t* out, int* bad_flag) {
+                                                        size_t b2_stride, uint8_t* out, int* bad_flag) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     fp px, py; fp2 qx, qy; bool pinf, qinf, ok, okb;
@@ -357,7 +359,7 @@ __global__ void __launch_bounds__(BLOCK, 2) pair_eq_kernel(size_t n, const uint8
     pair_inputs(px, py, pinf, qx, qy, qinf, ok, a1 + 96 * i, a2 + 192 * i);
     if (!ok) { pinf = true; qinf = true; }
     miller_loop(f, px, py, pinf, qx, qy, qinf);
-    pair_inputs(px, py, pinf, qx, qy, qinf, okb, b1 + 96 * i, b2 + 192 * i);
+    pair_inputs(px, py, pinf, qx, qy, qinf, okb, b1 + 96 * i, b2 + b2_stride * i);
     if (!okb) { pinf = true; qinf = true; }
     miller_loop(g, px, py, pinf, qx, qy, qinf);
     fp12_conj(t, g);
@@ -366,6 +368,23 @@ __global__ void __launch_bounds__(BLOCK, 2) pair_eq_kernel(size_t n, const uint8
     const bool valid = ok && okb;
     if (!valid) *bad_flag = 1;
     out[i] = valid ? (fp12_is_one(g) ? 1 : 0) : 0xff;
+}
+
+// proj[i] += P for one affine point P broadcast to every lane (BBS+: the constant g1 term)
+__global__ void __launch_bounds__(BLOCK) g1_add_const_kernel(size_t n, int32_t* proj, size_t stride, const uint8_t* pt96, int* bad_flag) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    g1p q, inf_pt, acc;
+    bool inf, ok;
+    g1_parse96(q.x, q.y, inf, ok, pt96); fp_one(q.z);
+    g1_set_inf(inf_pt);
+    fp_select(q.x, inf, inf_pt.x, q.x); fp_select(q.y, inf, inf_pt.y, q.y); fp_select(q.z, inf, inf_pt.z, q.z);
+    if (!ok) *bad_flag = 1;
+    soa_load_g1(acc, proj, stride, i);
+    g1_add(acc, q);
+    g1p o;
+    g1_norm1(o, acc);
+    soa_store_g1(proj, stride, i, o);
 }
 
 // ------------------------------------------------------------------ decode / split pairing / GT kernels
@@ -458,7 +477,7 @@ struct c12381_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     char err[256] = {0};
-    enum { WS_TAB, WS_PROJ, WS_PREF, WS_IN0, WS_IN1, WS_OUT, WS_RED0, WS_RED1, WS_COUNT };
+    enum { WS_TAB, WS_PROJ, WS_PREF, WS_IN0, WS_IN1, WS_OUT, WS_RED0, WS_RED1, WS_BBS_Q, WS_BBS_B, WS_BBS_IN, WS_COUNT };
     void* ws[WS_COUNT] = {nullptr};
     size_t ws_bytes[WS_COUNT] = {0};
     int* d_flag = nullptr;
@@ -508,7 +527,9 @@ struct timed {
 };
 
 // scalar multiplication of n elements into the projective SoA workspace (stride = padded n)
-int g1_mul_to_proj(c12381_ctx* c, size_t n, const uint8_t* d_pts, const uint8_t* d_sc, size_t stride) {
+// (results land at proj[proj_off + i]; pt_stride 96 = per-lane points, 0 = one broadcast point)
+int g1_mul_to_proj(c12381_ctx* c, size_t n, const uint8_t* d_pts, const uint8_t* d_sc, size_t stride, size_t pt_stride = 96,
+                   size_t proj_off = 0) {
     const size_t chunk = n < G1_CHUNK ? round_up(n, 64) : G1_CHUNK;
     int rc;
     if ((rc = ensure(c, c12381_ctx::WS_TAB, (size_t)G1_TAB_DWORDS * chunk * 4))) return rc;
@@ -516,8 +537,8 @@ int g1_mul_to_proj(c12381_ctx* c, size_t n, const uint8_t* d_pts, const uint8_t*
     for (size_t off = 0; off < n; off += chunk) {
         const size_t m = n - off < chunk ? n - off : chunk;
         timed tm(c, 0);
-        hipLaunchKernelGGL(g1_mul_kernel, dim3(grid_for(m)), dim3(BLOCK), 0, c->stream, m, d_pts + 96 * off, d_sc + 32 * off,
-                           (int32_t*)c->ws[c12381_ctx::WS_TAB], (int32_t*)c->ws[c12381_ctx::WS_PROJ], stride, off, c->d_flag);
+        hipLaunchKernelGGL(g1_mul_kernel, dim3(grid_for(m)), dim3(BLOCK), 0, c->stream, m, d_pts + pt_stride * off, pt_stride, d_sc + 32 * off,
+                           (int32_t*)c->ws[c12381_ctx::WS_TAB], (int32_t*)c->ws[c12381_ctx::WS_PROJ], stride, proj_off + off, c->d_flag);
         HIPCK(c, hipGetLastError());
     }
     return 0;
@@ -729,7 +750,11 @@ int c12381_g1_msm(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc
 }
 
 // ---------------------------------------------------------------- G2
+static int g2_mul_dev_strided(c12381_ctx* c, size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* sc, uint8_t* out, int fmt);
 int c12381_g2_mul_batch_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
+    return g2_mul_dev_strided(c, n, pts, 192, sc, out, fmt);
+}
+static int g2_mul_dev_strided(c12381_ctx* c, size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* sc, uint8_t* out, int fmt) {
     int rc = bind(c); if (rc) return rc;
     if (!pts || !sc || !out || (fmt != 97 && fmt != 192)) return C12381_E_ARG;
     if (n == 0) return 0;
@@ -738,7 +763,7 @@ int c12381_g2_mul_batch_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const u
     for (size_t off = 0; off < n; off += chunk) {
         const size_t m = n - off < chunk ? n - off : chunk;
         timed tm(c, 2);
-        hipLaunchKernelGGL(g2_mul_kernel, dim3(grid_for(m)), dim3(BLOCK), 0, c->stream, m, pts + 192 * off, sc + 32 * off,
+        hipLaunchKernelGGL(g2_mul_kernel, dim3(grid_for(m)), dim3(BLOCK), 0, c->stream, m, pts + pt_stride * off, pt_stride, sc + 32 * off,
                            (int32_t*)c->ws[c12381_ctx::WS_TAB], chunk, out + (size_t)fmt * off, fmt, c->d_flag);
         HIPCK(c, hipGetLastError());
     }
@@ -760,7 +785,7 @@ int c12381_g2_add_batch(c12381_ctx* c, size_t n, const uint8_t* a, const uint8_t
     if (n == 0) return 0;
     staged s;
     if ((rc = stage_in(c, s, a, 192 * n, b, 192 * n, (size_t)fmt * n))) return rc;
-    hipLaunchKernelGGL(g2_add_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, s.in0, s.in1, s.out, fmt, c->d_flag);
+    hipLaunchKernelGGL(g2_add_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, s.in0, (size_t)192, s.in1, s.out, fmt, c->d_flag);
     HIPCK(c, hipGetLastError());
     if ((rc = stage_out(c, s, out, (size_t)fmt * n))) return rc;
     return read_flag(c);
@@ -791,7 +816,7 @@ int c12381_pair_eq_batch_dev(c12381_ctx* c, size_t n, const uint8_t* a1, const u
     if (!a1 || !a2 || !b1 || !b2 || !ok) return C12381_E_ARG;
     if (n == 0) return 0;
     timed tm(c, 4);
-    hipLaunchKernelGGL(pair_eq_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, a1, a2, b1, b2, ok, c->d_flag);
+    hipLaunchKernelGGL(pair_eq_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, a1, a2, b1, b2, (size_t)192, ok, c->d_flag);
     HIPCK(c, hipGetLastError());
     return 0;
 }
@@ -880,6 +905,68 @@ int c12381_gt_is_unity_batch(c12381_ctx* c, size_t n, const uint8_t* a576, uint8
     if ((rc = stage_out(c, s, out, n))) return rc;
     HIPCK(c, hipStreamSynchronize(c->stream));
     return 0;
+}
+
+// ---------------------------------------------------------------- BBS+ batch verification
+// ok[j] = [ e(A_j, w + x_j g2) == e(g1 + r_j h0 + sum_i m_{i,j} h_i, g2) ]   — the verification equation of the
+// reference's examples/bbs-plus/src/bbs+.cpp:57-73, evaluated as liner_pair.hpp:339-350 does (two Miller loops,
+// one final exponentiation).  Message scalars are message-major: m[i*n + j] belongs to signature j.  All
+// pointers are DEVICE pointers; the public parameters are single points.
+int c12381_bbs_plus_verify_batch_dev(c12381_ctx* c, size_t n, size_t nmsg, const uint8_t* g1_96, const uint8_t* g2_192, const uint8_t* h0_96,
+                                     const uint8_t* h_96, const uint8_t* w_192, const uint8_t* A_96, const uint8_t* x_32, const uint8_t* r_32,
+                                     const uint8_t* m_32, uint8_t* ok) {
+    int rc = bind(c); if (rc) return rc;
+    if (!g1_96 || !g2_192 || !h0_96 || !w_192 || !A_96 || !x_32 || !r_32 || !ok || (nmsg && (!h_96 || !m_32))) return C12381_E_ARG;
+    if (n == 0) return 0;
+    // Q_j = w + x_j g2
+    if ((rc = ensure(c, c12381_ctx::WS_BBS_Q, 192 * n))) return rc;
+    if ((rc = ensure(c, c12381_ctx::WS_BBS_B, 192 * n))) return rc;
+    uint8_t* d_q = (uint8_t*)c->ws[c12381_ctx::WS_BBS_Q];
+    uint8_t* d_b = (uint8_t*)c->ws[c12381_ctx::WS_BBS_B];
+    if ((rc = g2_mul_dev_strided(c, n, g2_192, 0, x_32, d_b, 192))) return rc;
+    hipLaunchKernelGGL(g2_add_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, w_192, (size_t)0, d_b, d_q, 192, c->d_flag);
+    HIPCK(c, hipGetLastError());
+    // B_j = g1 + r_j h0 + sum_i m_ij h_i : (nmsg + 1) fixed-base columns of n scalar multiplications, summed per lane
+    const size_t cols = nmsg + 1, total = cols * n, stride = round_up(total, 64);
+    if ((rc = g1_mul_to_proj(c, n, h0_96, r_32, stride, 0, 0))) return rc;
+    for (size_t i = 0; i < nmsg; ++i)
+        if ((rc = g1_mul_to_proj(c, n, h_96 + 96 * i, m_32 + 32 * n * i, stride, 0, (i + 1) * n))) return rc;
+    const size_t rstride = round_up(n, 64);
+    if ((rc = ensure(c, c12381_ctx::WS_RED0, (size_t)3 * NL * rstride * 4))) return rc;
+    int32_t* red = (int32_t*)c->ws[c12381_ctx::WS_RED0];
+    hipLaunchKernelGGL(g1_reduce_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, total, (const int32_t*)c->ws[c12381_ctx::WS_PROJ], stride, n, red, rstride);
+    HIPCK(c, hipGetLastError());
+    hipLaunchKernelGGL(g1_add_const_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, red, rstride, g1_96, c->d_flag);
+    HIPCK(c, hipGetLastError());
+    if ((rc = g1_finish(c, n, red, rstride, d_b, 96))) return rc;
+    timed tm(c, 4);
+    hipLaunchKernelGGL(pair_eq_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, A_96, d_q, d_b, g2_192, (size_t)0, ok, c->d_flag);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+int c12381_bbs_plus_verify_batch(c12381_ctx* c, size_t n, size_t nmsg, const uint8_t* g1_96, const uint8_t* g2_192, const uint8_t* h0_96,
+                                 const uint8_t* h_96, const uint8_t* w_192, const uint8_t* A_96, const uint8_t* x_32, const uint8_t* r_32,
+                                 const uint8_t* m_32, uint8_t* ok) {
+    int rc = bind(c); if (rc) return rc;
+    if (!g1_96 || !g2_192 || !h0_96 || !w_192 || !A_96 || !x_32 || !r_32 || !ok || (nmsg && (!h_96 || !m_32))) return C12381_E_ARG;
+    if (n == 0) return 0;
+    // one staging slab: public parameters, then the per-signature arrays
+    const size_t o_g1 = 0, o_g2 = 96, o_h0 = 288, o_w = 384, o_h = 576, o_A = round_up(o_h + 96 * nmsg, 256), o_x = o_A + 96 * n,
+                 o_r = o_x + 32 * n, o_m = o_r + 32 * n, o_ok = round_up(o_m + 32 * n * nmsg, 256), bytes = o_ok + round_up(n, 256);
+    if ((rc = ensure(c, c12381_ctx::WS_BBS_IN, bytes))) return rc;
+    uint8_t* d = (uint8_t*)c->ws[c12381_ctx::WS_BBS_IN];
+    HIPCK(c, hipMemcpyAsync(d + o_g1, g1_96, 96, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d + o_g2, g2_192, 192, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d + o_h0, h0_96, 96, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d + o_w, w_192, 192, hipMemcpyHostToDevice, c->stream));
+    if (nmsg) HIPCK(c, hipMemcpyAsync(d + o_h, h_96, 96 * nmsg, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d + o_A, A_96, 96 * n, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d + o_x, x_32, 32 * n, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d + o_r, r_32, 32 * n, hipMemcpyHostToDevice, c->stream));
+    if (nmsg) HIPCK(c, hipMemcpyAsync(d + o_m, m_32, 32 * n * nmsg, hipMemcpyHostToDevice, c->stream));
+    if ((rc = c12381_bbs_plus_verify_batch_dev(c, n, nmsg, d + o_g1, d + o_g2, d + o_h0, d + o_h, d + o_w, d + o_A, d + o_x, d + o_r, d + o_m, d + o_ok))) return rc;
+    HIPCK(c, hipMemcpyAsync(ok, d + o_ok, n, hipMemcpyDeviceToHost, c->stream));
+    return read_flag(c);
 }
 
 }  // extern "C"

@@ -131,6 +131,20 @@ int c12381_gt_op_batch(c12381_ctx* ctx, int op, size_t n, const uint8_t* a576, c
 /* is_unity(fp12&) (:197 -> 271-274 -> FP12_isunity): out[i] = 1 / 0. */
 int c12381_gt_is_unity_batch(c12381_ctx* ctx, size_t n, const uint8_t* a576, uint8_t* out);
 
+/* caller pattern of BASELINE config 5 ------------------------------------------ */
+/* ok[j] = [ e(A_j, w + x_j*g2) == e(g1 + r_j*h0 + sum_i m[i*n + j]*h_i, g2) ]: the BBS+ verification equation of the
+ * reference's examples/bbs-plus/src/bbs+.cpp:57-73 for n signatures of nmsg message blocks each, evaluated like
+ * liner_pair.hpp:339-350 (two Miller loops, ONE final exponentiation, is_unity).  Public parameters are single
+ * points (g1 96 B, g2 192 B, h0 96 B, h nmsg x 96 B, w 192 B); per-signature inputs are arrays (A n x 96 B, x and r
+ * n x 32 B, m nmsg x n x 32 B message-major).  ok[j] = 1 / 0, 0xff if an input point of lane j is invalid.
+ * Message encoding (encode_to<Zp>, zp_number.hpp:1011-1037) and parsing stay on the caller's side. */
+int c12381_bbs_plus_verify_batch(c12381_ctx* ctx, size_t n, size_t nmsg, const uint8_t* g1_96, const uint8_t* g2_192,
+                                 const uint8_t* h0_96, const uint8_t* h_96, const uint8_t* w_192, const uint8_t* A_96,
+                                 const uint8_t* x_32, const uint8_t* r_32, const uint8_t* m_32, uint8_t* ok);
+int c12381_bbs_plus_verify_batch_dev(c12381_ctx* ctx, size_t n, size_t nmsg, const uint8_t* g1_96, const uint8_t* g2_192,
+                                     const uint8_t* h0_96, const uint8_t* h_96, const uint8_t* w_192, const uint8_t* A_96,
+                                     const uint8_t* x_32, const uint8_t* r_32, const uint8_t* m_32, uint8_t* ok);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,73 @@
+"""GPU parity test of the BBS+ batch-verification entry point (SURVEY.md §8 f2 / BASELINE configs[4]): signatures
+are produced with the CPU oracle exactly as the reference's sign() does (examples/bbs-plus/src/bbs+.cpp:38-55:
+A = (g1 * h0^r * prod h_i^m_i)^(1/(gamma+x))), some are corrupted, and the GPU booleans must equal the oracle's
+evaluation of the verification equation (bbs+.cpp:57-73) lane by lane."""
+import pytest
+
+from util import R, golden, prng, scalars
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(orc, nmsg):
+    g1 = bytes.fromhex(golden("g1")["generator"])
+    g2 = bytes.fromhex(golden("g2")["generator"])
+    # public parameters: random group elements (setup, bbs+.cpp:7-24) and a key pair (key_gen :26-36)
+    gs = orc.g1_mul(g1 * (nmsg + 2), scalars(701, nmsg + 2), 96)
+    G1p, h0, h = gs[:96], gs[96:192], gs[192:]
+    G2p = orc.g2_mul(g2, scalars(702, 1), 192)
+    gamma = prng(703, 0) % R
+    w = orc.g2_mul(G2p, gamma.to_bytes(32, "big"), 192)
+    return G1p, G2p, h0, h, gamma, w
+
+
+def _sign(orc, G1p, h0, h, gamma, msgs, x, r):
+    nmsg = len(msgs)
+    pts = G1p + h0 + h[:96 * nmsg]
+    sc = (1).to_bytes(32, "big") + r.to_bytes(32, "big") + b"".join(m.to_bytes(32, "big") for m in msgs)
+    B = orc.g1_msm(pts, sc, 96, 1)
+    e = pow((gamma + x) % R, -1, R)
+    return orc.g1_mul(B, e.to_bytes(32, "big"), 96)
+
+
+def test_bbs_plus_verify_batch(oracle_port):
+    from crypto12381_amd import Context
+    orc = oracle_port
+    nmsg, n = 3, 96
+    G1p, G2p, h0, h, gamma, w = _setup(orc, nmsg)
+    A, X, Rr, M = [], [], [], [[] for _ in range(nmsg)]
+    expect_valid = []
+    for j in range(n):
+        msgs = [prng(710 + i, j) % R for i in range(nmsg)]
+        x, r = prng(720, j) % R, prng(721, j) % R
+        a = _sign(orc, G1p, h0, h, gamma, msgs, x, r)
+        kind = j % 4
+        if kind == 1:
+            msgs[0] = (msgs[0] + 1) % R                    # wrong message
+        elif kind == 2:
+            a = orc.g1_mul(a, (2).to_bytes(32, "big"), 96)  # tampered A
+        elif kind == 3 and j % 8 == 3:
+            x = (x + 5) % R                                 # wrong x
+        A.append(a); X.append(x.to_bytes(32, "big")); Rr.append(r.to_bytes(32, "big"))
+        for i in range(nmsg):
+            M[i].append(msgs[i].to_bytes(32, "big"))
+        expect_valid.append(kind == 0 or (kind == 3 and j % 8 != 3))
+    A, X, Rr = b"".join(A), b"".join(X), b"".join(Rr)
+    Mm = b"".join(b"".join(col) for col in M)              # message-major
+    ctx = Context(0)
+    got = ctx.bbs_plus_verify(G1p, G2p, h0, h, w, A, X, Rr, Mm)
+    # oracle evaluation of the same equation
+    Q = orc.g2_add(w * n, orc.g2_mul(G2p * n, X, 192, 8), 192)
+    Bv = b""
+    for j in range(n):
+        pts = G1p + h0 + h
+        sc = (1).to_bytes(32, "big") + Rr[32 * j:32 * j + 32] + b"".join(M[i][j] for i in range(nmsg))
+        Bv += orc.g1_msm(pts, sc, 96, 1)
+    exp = orc.pair_eq(A, Q, Bv, G2p * n, 8)
+    assert got == exp
+    assert [b == 1 for b in got] == expect_valid
+    # zero message blocks: e(A, w + x g2) == e(g1 + r h0, g2)
+    a0 = _sign(orc, G1p, h0, h, gamma, [], 11, 22)
+    ok = ctx.bbs_plus_verify(G1p, G2p, h0, b"", w, a0 * 2, (11).to_bytes(32, "big") + (12).to_bytes(32, "big"), (22).to_bytes(32, "big") * 2, b"")
+    assert ok == b"\x01\x00"
+    ctx.close()
