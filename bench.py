@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--log2-batch", type=int, default=20)
     ap.add_argument("--log2-pairings", type=int, default=16)
     ap.add_argument("--no-pairing", action="store_true", help="skip the secondary (pairings/s) measurement")
+    ap.add_argument("--all-configs", action="store_true",
+                    help="also time BASELINE configs[3] (MSM n=2^22 per GPU) and configs[4] (2^18 BBS+ verifications per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -168,6 +170,55 @@ def main():
         pair = {"npair": npair, "steps": psteps, "elapsed": pel, "kernel_ms": pk_ms, "launches": pk_launches,
                 "p1": p1, "q2": q2, "gt": gt}
 
+    # ---- optional: configs[3] (MSM) and configs[4] (BBS+ batch verification), reported as extra objects
+    extras = {}
+    if args.all_configs:
+        def timed_steps(fn, steps):
+            fn()
+            torch.cuda.synchronize(dev)
+            if dist:
+                dist.barrier()
+            t_a = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize(dev)
+            if dist:
+                dist.barrier()
+            el = time.perf_counter() - t_a
+            if dist:
+                tt = torch.tensor([el], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                el = float(tt.item())
+            return el
+        # MSM: 2^22 terms per GPU = 4 x the 2^20 point batch (the combine across GPUs is 96 B per rank)
+        nm = 1 << 22
+        reps = nm // n
+        mp_ = pts.repeat(reps).contiguous() if reps > 1 else pts
+        ms_ = torch.from_numpy(make_scalars(4000 + rank, nm)).to(dev)
+        mo_ = torch.empty(96, dtype=torch.uint8, device=dev)
+        el = timed_steps(lambda: ctx.g1_msm_dev(nm, mp_.data_ptr(), ms_.data_ptr(), mo_.data_ptr(), 96), 2)
+        extras["msm"] = {"metric": "G1 MSM terms/s (n = 2^22 per GPU, local part; cross-GPU combine = all-gather of 96 B)",
+                         "value": world * nm * 2 / el, "unit": "terms/s", "ms_per_msm": el / 2 * 1e3}
+        del mp_, ms_
+        # BBS+: 2^18 signatures, 1 message block (as the reference's example message), random (mostly invalid) signatures:
+        # the verification cost does not depend on validity; parity of this entry point is covered by tests/test_gpu_bbs.py
+        nb = 1 << 18
+        xs = torch.from_numpy(make_scalars(5000 + rank, nb)).to(dev)
+        rs = torch.from_numpy(make_scalars(5001 + rank, nb)).to(dev)
+        mm = torch.from_numpy(make_scalars(5002 + rank, nb)).to(dev)
+        okb = torch.empty(nb, dtype=torch.uint8, device=dev)
+        pub_g1, pub_h0, pub_h = pts[96:192], pts[192:288], pts[288:384]
+        g2d = torch.from_numpy(np.frombuffer(G2_GEN, dtype=np.uint8).copy()).to(dev)
+        wd = torch.empty(192, dtype=torch.uint8, device=dev)
+        ctx.g2_mul_dev(1, g2d.data_ptr(), base_sc[64:96].data_ptr(), wd.data_ptr(), 192)
+        a_pts = pts[: nb * 96]
+        el = timed_steps(lambda: ctx.bbs_plus_verify_dev(nb, 1, pub_g1.data_ptr(), g2d.data_ptr(), pub_h0.data_ptr(), pub_h.data_ptr(),
+                                                         wd.data_ptr(), a_pts.data_ptr(), xs.data_ptr(), rs.data_ptr(), mm.data_ptr(),
+                                                         okb.data_ptr()), 2)
+        extras["bbs_plus"] = {"metric": "BBS+ signature verifications/s (2^18 per GPU, 1 message block)", "value": world * nb * 2 / el,
+                              "unit": "verifications/s", "ms_per_batch": el / 2 * 1e3}
+        ctx.sync()
+
     # ---- parity (outside the timed region): sampled lanes vs the CPU oracle, all edge lanes included
     from oracle.bindings import Oracle, have_reference
     kind = "reference" if have_reference() else "port"
@@ -263,6 +314,8 @@ def main():
                     raise SystemExit("bench: CPU pairing baseline differs from the GPU output")
                 result["pairing"]["cpu_baseline"] = {"value": ps / cpu_ps, "unit": "pairings/s", "cores": cores, "kind": kind,
                                                      "sample": "first %d lanes of the same batch, %d threads; bit-exact vs GPU" % (ps, cores)}
+        if extras:
+            result["extra_configs"] = extras
         print(json.dumps(result), flush=True)
     ctx.close()
     if dist:

@@ -176,25 +176,49 @@ C12381_HDN void fp12_sqr(fp12& w, const fp12& x) {
     fp4_sqr_s3(S, x.a, x.b, x.c);
     fp12_sqr_combine(w, A, B, C, D, S);
 }
-// wa = 3A - 2 conj(xa),  wb = 3 s B + 2 conj(xb),  wc = 3C - 2 conj(xc)     (w may alias x)
-C12381_HDN void fp12_usqr_combine(fp12& w, const fp12& x, const fp4& A, const fp4& B, const fp4& C) {
-    fp4 t, u, wa, wb, wc;
+// FP12_usqr :147-186 (Granger-Scott; equals sqr only for unitary elements), split by output coefficient so
+// that every Fp4 operand is read once and every result written once (the squaring ladder of the final
+// exponentiation was the largest source of private-memory traffic):
+//   wa = 3 xa^2 - 2 conj(xa)                       needs xa only
+//   wb = 3 s xc^2 + 2 conj(xb),  wc = 3 xb^2 - 2 conj(xc)   need xb and xc
+// `reduce` re-bounds the results (fp_weak_reduce) in the same pass.  Outputs may alias inputs.
+C12381_HD void fp4_sqr_core(fp4& w, const fp4& x) {            // fp4_sqr body, inlined into the callers below
+    fp2 t1, t2, t3, wa;
+    fp2_mul(t3, x.a, x.b);
+    fp2_add(t1, x.a, x.b);
+    fp2_mul_ip(t2, x.b);
+    fp2_add(t2, x.a, t2);
+    fp2_norm1(t2, t2);
+    fp2_mul(wa, t1, t2);
+    fp2_mul_ip(t2, t3);
+    fp2_add(t2, t2, t3);
+    fp2_sub(wa, wa, t2);
+    fp2_dbl(t3, t3);
+    fp2_norm1(w.a, wa);
+    fp2_norm1(w.b, t3);
+}
+C12381_HDN void fp12_usqr_a(fp4& wa, const fp4& xa, bool reduce) {
+    fp4 A, t, u;
+    fp4_sqr_core(A, xa);
     fp4_add(t, A, A); fp4_add(t, t, A);
-    fp4_nconj(u, x.a); fp4_add(u, u, u); fp4_add(wa, t, u);
+    fp4_nconj(u, xa); fp4_add(u, u, u); fp4_add(t, t, u);
+    if (reduce) fp4_weak_reduce(wa, t); else fp4_norm1(wa, t);
+}
+C12381_HDN void fp12_usqr_bc(fp4& wb, fp4& wc, const fp4& xb, const fp4& xc, bool reduce) {
+    fp4 B, C, t, u, rb, rc;
+    fp4_sqr_core(B, xc);
+    fp4_sqr_core(C, xb);
     fp4_times_i(t, B); fp4_norm1(t, t); fp4_add(u, t, t); fp4_add(t, u, t);
-    fp4_conj(u, x.b); fp4_add(u, u, u); fp4_add(wb, t, u);
+    fp4_conj(u, xb); fp4_add(u, u, u); fp4_add(rb, t, u);
     fp4_add(t, C, C); fp4_add(t, t, C);
-    fp4_nconj(u, x.c); fp4_add(u, u, u); fp4_add(wc, t, u);
-    fp4_norm1(w.a, wa); fp4_norm1(w.b, wb); fp4_norm1(w.c, wc);
+    fp4_nconj(u, xc); fp4_add(u, u, u); fp4_add(rc, t, u);
+    if (reduce) { fp4_weak_reduce(wb, rb); fp4_weak_reduce(wc, rc); } else { fp4_norm1(wb, rb); fp4_norm1(wc, rc); }
 }
-// FP12_usqr :147-186 (Granger-Scott; equals sqr only for unitary elements).  w may alias x.
-C12381_HDN void fp12_usqr(fp12& w, const fp12& x) {
-    fp4 A, B, C;
-    fp4_sqr(A, x.a);
-    fp4_sqr(B, x.c);
-    fp4_sqr(C, x.b);
-    fp12_usqr_combine(w, x, A, B, C);
+C12381_HD void fp12_usqr_r(fp12& w, const fp12& x, bool reduce) {
+    fp12_usqr_a(w.a, x.a, reduce);
+    fp12_usqr_bc(w.b, w.c, x.b, x.c, reduce);
 }
+C12381_HD void fp12_usqr(fp12& w, const fp12& x) { fp12_usqr_r(w, x, false); }
 // FP12_inv :627-664
 C12381_HDN void fp12_inv(fp12& w, const fp12& x) {
     fp4 f0, f1, f2, f3, t;
@@ -265,10 +289,9 @@ C12381_HDN void fp12_pow_x_unitary(fp12& r, const fp12& a) {
     fp12 w = a;
 #pragma unroll 1
     for (int i = 62; i >= 0; --i) {
-        fp12_usqr(w, w);
         // the squaring carries the linear term -2 conj(w): the integer representative doubles each
-        // step, so re-bound it every 2nd step (data-independent schedule)
-        if ((i & 1) == 0) fp12_weak_reduce(w, w);
+        // step, so re-bound it every 2nd step (data-independent schedule), in the same pass
+        fp12_usqr_r(w, w, (i & 1) == 0);
         if ((BLS_X >> i) & 1ull) fp12_mul(w, w, a);
     }
     r = w;
@@ -296,8 +319,7 @@ C12381_HDN void fp12_pow_generic(fp12& r, const fp12& a, const uint32_t (&e)[8])
     for (int i = 257; i >= 1; --i) {
         const bool active = i <= nb - 2;            // the reference starts from w = a at bit nb-1
         fp12 t, m, t2;
-        fp12_usqr(t, w);
-        fp12_weak_reduce(t, t);
+        fp12_usqr_r(t, w, true);
         const int b3 = (int)((e3[i >> 5] >> (i & 31)) & 1u);
         const int b1 = i < 256 ? (int)((e[i >> 5] >> (i & 31)) & 1u) : 0;
         const int bt = b3 - b1;
