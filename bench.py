@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log2-batch", type=int, default=20)
     ap.add_argument("--log2-pairings", type=int, default=16)
+    ap.add_argument("--pairings", type=int, default=0, help="exact pairing batch size (overrides --log2-pairings; experiments only)")
     ap.add_argument("--no-pairing", action="store_true", help="skip the secondary (pairings/s) measurement")
     ap.add_argument("--all-configs", action="store_true",
                     help="also time BASELINE configs[3] (MSM n=2^22 per GPU) and configs[4] (2^18 BBS+ verifications per GPU)")
@@ -136,7 +137,7 @@ def main():
     # ---- second half of the metric: ate pairings/s on a batch of 2^16 (BASELINE configs[2]), same protocol
     pair = None
     if not args.no_pairing:
-        npair = 1 << args.log2_pairings
+        npair = args.pairings if args.pairings > 0 else (1 << args.log2_pairings)
         t_sc = torch.from_numpy(make_scalars(3000 + rank, npair)).to(dev)
         g2gen = torch.from_numpy(np.frombuffer(G2_GEN, dtype=np.uint8).copy()).to(dev).repeat(npair).contiguous()
         q2 = torch.empty(npair * 192, dtype=torch.uint8, device=dev)

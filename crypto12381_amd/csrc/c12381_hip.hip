@@ -26,6 +26,7 @@
 #include "g1.hpp"
 #include "g2.hpp"
 #include "pairing.hpp"
+#include "pairing3.hpp"
 
 using namespace c12381;
 
@@ -71,7 +72,7 @@ __device__ __forceinline__ void g1_parse96(fp& x, fp& y, bool& inf, bool& ok, co
 }
 
 // ------------------------------------------------------------------ Fp kernels
-__global__ void __launch_bounds__(BLOCK) fp_op_kernel(int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+__global__ void __launch_bounds__(BLOCK, 2) fp_op_kernel(int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     uint32_t raw[12];
@@ -90,7 +91,7 @@ __global__ void __launch_bounds__(BLOCK) fp_op_kernel(int op, size_t n, const ui
     store_raw48(out + 48 * i, raw);
 }
 
-__global__ void __launch_bounds__(BLOCK) fp_mulchain_kernel(size_t n, int iters, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+__global__ void __launch_bounds__(BLOCK, 2) fp_mulchain_kernel(size_t n, int iters, const uint8_t* a, const uint8_t* b, uint8_t* out) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     uint32_t raw[12];
@@ -132,7 +133,7 @@ __global__ void __launch_bounds__(BLOCK, 2) g1_mul_kernel(size_t n, const uint8_
     soa_store_g1(proj, proj_stride, proj_off + i, o);
 }
 
-__global__ void __launch_bounds__(BLOCK) g1_add_kernel(size_t n, const uint8_t* a, const uint8_t* b, int32_t* proj, size_t proj_stride,
+__global__ void __launch_bounds__(BLOCK, 2) g1_add_kernel(size_t n, const uint8_t* a, const uint8_t* b, int32_t* proj, size_t proj_stride,
                                                        int* bad_flag) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -152,7 +153,7 @@ __global__ void __launch_bounds__(BLOCK) g1_add_kernel(size_t n, const uint8_t* 
 
 // Simultaneous inversion (Montgomery's trick) + affine + encode.  Lane t owns elements
 // t, t+T, t+2T, ... so every global access is coalesced across the wavefront.
-__global__ void __launch_bounds__(BLOCK) g1_finish_kernel(size_t n, const int32_t* proj, size_t stride, int32_t* pref, uint8_t* out,
+__global__ void __launch_bounds__(BLOCK, 2) g1_finish_kernel(size_t n, const int32_t* proj, size_t stride, int32_t* pref, uint8_t* out,
                                                           int fmt, size_t T) {
     const size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (t >= T || t >= n) return;
@@ -217,7 +218,7 @@ __global__ void __launch_bounds__(BLOCK) g1_finish_kernel(size_t n, const int32_
 }
 
 // One reduction level: out[j] = sum over i = j, j+m, j+2m, ... < n of in[i]   (projective, complete adds)
-__global__ void __launch_bounds__(BLOCK) g1_reduce_kernel(size_t n, const int32_t* in, size_t in_stride, size_t m, int32_t* outp,
+__global__ void __launch_bounds__(BLOCK, 2) g1_reduce_kernel(size_t n, const int32_t* in, size_t in_stride, size_t m, int32_t* outp,
                                                           size_t out_stride) {
     const size_t j = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (j >= m) return;
@@ -289,7 +290,7 @@ __device__ __noinline__ void g2_store_affine(uint8_t* o, const g2p& acc, int fmt
     }
 }
 
-__global__ void __launch_bounds__(BLOCK) g2_mul_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab,
+__global__ void __launch_bounds__(BLOCK, 2) g2_mul_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab,
                                                        size_t tab_stride, uint8_t* out, int fmt, int* bad_flag) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -305,7 +306,7 @@ __global__ void __launch_bounds__(BLOCK) g2_mul_kernel(size_t n, const uint8_t* 
     g2_store_affine(out + (size_t)fmt * i, acc, fmt, !ok);
 }
 
-__global__ void __launch_bounds__(BLOCK) g2_add_kernel(size_t n, const uint8_t* a, size_t a_stride, const uint8_t* b, uint8_t* out, int fmt,
+__global__ void __launch_bounds__(BLOCK, 2) g2_add_kernel(size_t n, const uint8_t* a, size_t a_stride, const uint8_t* b, uint8_t* out, int fmt,
                                                        int* bad_flag) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -371,7 +372,7 @@ __global__ void __launch_bounds__(BLOCK, 2) pair_eq_kernel(size_t n, const uint8
 }
 
 // proj[i] += P for one affine point P broadcast to every lane (BBS+: the constant g1 term)
-__global__ void __launch_bounds__(BLOCK) g1_add_const_kernel(size_t n, int32_t* proj, size_t stride, const uint8_t* pt96, int* bad_flag) {
+__global__ void __launch_bounds__(BLOCK, 2) g1_add_const_kernel(size_t n, int32_t* proj, size_t stride, const uint8_t* pt96, int* bad_flag) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     g1p q, inf_pt, acc;
@@ -387,10 +388,69 @@ __global__ void __launch_bounds__(BLOCK) g1_add_const_kernel(size_t n, int32_t* 
     soa_store_g1(proj, stride, i, o);
 }
 
+// ------------------------------------------------------------------ three-lanes-per-pairing kernels (pairing3.hpp)
+constexpr int TRI_PER_WAVE = 21;
+__device__ __forceinline__ void tri_setup(tri& t, size_t& idx, bool& active, size_t n) {
+    const unsigned lane = threadIdx.x & 63u;
+    const size_t wave = ((size_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    const unsigned trip = lane / 3u;
+    t.role = lane == 63u ? 0 : (int)(lane - 3u * trip);
+    t.base = lane == 63u ? 63 : (int)(3u * trip);
+    const size_t i = wave * TRI_PER_WAVE + (lane == 63u ? TRI_PER_WAVE - 1 : trip);
+    active = lane < 63u && i < n;
+    idx = i < n ? i : n - 1;                    // inactive lanes shadow the last element: same instruction stream
+}
+__device__ __forceinline__ void gt_store_coeff(uint8_t* o576, const fp4& x, int role) {
+    uint8_t* o = o576 + (role == 0 ? 384 : (role == 1 ? 192 : 0));      // FP12_toOctet: c | b | a
+    uint32_t raw[12];
+    fp_to_raw48(raw, x.b.b); store_raw48(o, raw);
+    fp_to_raw48(raw, x.b.a); store_raw48(o + 48, raw);
+    fp_to_raw48(raw, x.a.b); store_raw48(o + 96, raw);
+    fp_to_raw48(raw, x.a.a); store_raw48(o + 144, raw);
+}
+__global__ void __launch_bounds__(BLOCK, 2) pair3_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag) {
+    if ((((size_t)blockIdx.x * BLOCK + threadIdx.x) >> 6) * TRI_PER_WAVE >= n) return;      // whole wavefront idle
+    tri t; size_t i; bool active;
+    tri_setup(t, i, active, n);
+    fp px, py; fp2 qx, qy; bool pinf, qinf, ok;
+    pair_inputs(px, py, pinf, qx, qy, qinf, ok, g1 + 96 * i, g2 + 192 * i);
+    if (!ok) { if (active) *bad_flag = 1; pinf = true; qinf = true; }
+    fp4 F;
+    miller3_loop(F, px, py, pinf, qx, qy, qinf, t);
+    f12t_final_exp(F, t);
+    if (active) {
+        if (!ok) { uint4* q = reinterpret_cast<uint4*>(gt + 576 * i + (t.role == 0 ? 384 : (t.role == 1 ? 192 : 0))); for (int j = 0; j < 12; ++j) q[j] = make_uint4(~0u, ~0u, ~0u, ~0u); }
+        else gt_store_coeff(gt + 576 * i, F, t.role);
+    }
+}
+__global__ void __launch_bounds__(BLOCK, 2) pair3_eq_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2,
+                                                         size_t b2_stride, uint8_t* out, int* bad_flag) {
+    if ((((size_t)blockIdx.x * BLOCK + threadIdx.x) >> 6) * TRI_PER_WAVE >= n) return;
+    tri t; size_t i; bool active;
+    tri_setup(t, i, active, n);
+    fp px, py; fp2 qx, qy; bool pinf, qinf, ok, okb;
+    fp4 F, G, Gc;
+    pair_inputs(px, py, pinf, qx, qy, qinf, ok, a1 + 96 * i, a2 + 192 * i);
+    if (!ok) { pinf = true; qinf = true; }
+    miller3_loop(F, px, py, pinf, qx, qy, qinf, t);
+    pair_inputs(px, py, pinf, qx, qy, qinf, okb, b1 + 96 * i, b2 + b2_stride * i);
+    if (!okb) { pinf = true; qinf = true; }
+    miller3_loop(G, px, py, pinf, qx, qy, qinf, t);
+    f12t_conj(Gc, G, t);
+    f12t_mul(F, F, Gc, t);
+    f12t_final_exp(F, t);
+    const bool one = f12t_is_one(F, t);
+    const bool valid = ok && okb;
+    if (active && t.role == 0) {
+        if (!valid) *bad_flag = 1;
+        out[i] = valid ? (one ? 1 : 0) : 0xff;
+    }
+}
+
 // ------------------------------------------------------------------ decode / split pairing / GT kernels
 // ECP_fromOctet ecp_BLS12381.cpp:495-545 for 49-byte input (tags 02/03; a leading 00 is infinity as in
 // g1_point.hpp:89-93); status 1 ok / 0 reject; rejected and infinity lanes give 96 zero bytes.
-__global__ void __launch_bounds__(BLOCK) g1_decompress_kernel(size_t n, const uint8_t* in, uint8_t* out, uint8_t* status) {
+__global__ void __launch_bounds__(BLOCK, 2) g1_decompress_kernel(size_t n, const uint8_t* in, uint8_t* out, uint8_t* status) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const uint8_t* sp = in + 49 * i;
@@ -412,7 +472,7 @@ __global__ void __launch_bounds__(BLOCK) g1_decompress_kernel(size_t n, const ui
     status[i] = tag == 0 ? 1 : (ok ? 1 : 0);
 }
 // ECP2_fromOctet ecp2_BLS12381.cpp:225-266 for 97-byte input: any tag other than 04 is "compressed, sign = tag & 1"
-__global__ void __launch_bounds__(BLOCK) g2_decompress_kernel(size_t n, const uint8_t* in, uint8_t* out, uint8_t* status) {
+__global__ void __launch_bounds__(BLOCK, 2) g2_decompress_kernel(size_t n, const uint8_t* in, uint8_t* out, uint8_t* status) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const uint8_t* sp = in + 97 * i;
@@ -792,12 +852,22 @@ int c12381_g2_add_batch(c12381_ctx* c, size_t n, const uint8_t* a, const uint8_t
 }
 
 // ---------------------------------------------------------------- pairing
+// C12381_PAIR_LANES=1 selects the one-lane-per-pairing kernels (kept for A/B measurements); default is 3.
+static int pair_lanes() {
+    static const int v = [] { const char* e = std::getenv("C12381_PAIR_LANES"); return (e && e[0] == '1') ? 1 : 3; }();
+    return v;
+}
+static unsigned grid_tri(size_t n) {
+    const size_t waves = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE;
+    return (unsigned)((waves * 64 + BLOCK - 1) / BLOCK);
+}
 int c12381_pair_batch_dev(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt) {
     int rc = bind(c); if (rc) return rc;
     if (!g1 || !g2 || !gt) return C12381_E_ARG;
     if (n == 0) return 0;
     timed tm(c, 3);
-    hipLaunchKernelGGL(pair_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag);
+    if (pair_lanes() == 1) hipLaunchKernelGGL(pair_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag);
+    else hipLaunchKernelGGL(pair3_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag);
     HIPCK(c, hipGetLastError());
     return 0;
 }
@@ -816,7 +886,8 @@ int c12381_pair_eq_batch_dev(c12381_ctx* c, size_t n, const uint8_t* a1, const u
     if (!a1 || !a2 || !b1 || !b2 || !ok) return C12381_E_ARG;
     if (n == 0) return 0;
     timed tm(c, 4);
-    hipLaunchKernelGGL(pair_eq_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, a1, a2, b1, b2, (size_t)192, ok, c->d_flag);
+    if (pair_lanes() == 1) hipLaunchKernelGGL(pair_eq_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, a1, a2, b1, b2, (size_t)192, ok, c->d_flag);
+    else hipLaunchKernelGGL(pair3_eq_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, a1, a2, b1, b2, (size_t)192, ok, c->d_flag);
     HIPCK(c, hipGetLastError());
     return 0;
 }
@@ -940,7 +1011,8 @@ int c12381_bbs_plus_verify_batch_dev(c12381_ctx* c, size_t n, size_t nmsg, const
     HIPCK(c, hipGetLastError());
     if ((rc = g1_finish(c, n, red, rstride, d_b, 96))) return rc;
     timed tm(c, 4);
-    hipLaunchKernelGGL(pair_eq_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, A_96, d_q, d_b, g2_192, (size_t)0, ok, c->d_flag);
+    if (pair_lanes() == 1) hipLaunchKernelGGL(pair_eq_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, A_96, d_q, d_b, g2_192, (size_t)0, ok, c->d_flag);
+    else hipLaunchKernelGGL(pair3_eq_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, A_96, d_q, d_b, g2_192, (size_t)0, ok, c->d_flag);
     HIPCK(c, hipGetLastError());
     return 0;
 }

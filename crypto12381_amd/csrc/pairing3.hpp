@@ -1,0 +1,319 @@
+// Optimal-ate pairing with THREE lanes per pairing.
+//
+// Why: with one pairing per lane the live state (an Fp12 accumulator, the G2 point, Karatsuba temporaries)
+// is ~7 KB per lane and lives in private memory; measured on MI355X that kernel moves ~2.5 MB of HBM traffic
+// per pairing and is bandwidth-bound (profiles/r01_pmc_summary_*).  Fp12 = Fp4[w]/(w^3 - s) has exactly three
+// Fp4 coefficients, so a TRIPLE of adjacent lanes holds one pairing: lane role 0/1/2 owns coefficient a/b/c
+// of every Fp12 value (56 dwords instead of 168) and coordinate X/Y/Z of the running G2 point.  Karatsuba
+// over Fp4 needs six Fp4 products — two per lane — and the operands/results that cross coefficients travel
+// through wavefront shuffles (ds_bpermute), not memory.  A 64-lane wavefront carries 21 pairings (lane 63
+// idles along).  All role-dependent choices are selects, so the three roles run one instruction stream.
+//
+// Same mathematics as pairing.hpp (the reference's PAIR_ate / PAIR_fexp, pair_BLS12381.cpp:425-505, 629-755):
+// the GT element — and its canonical bytes — are identical.
+#pragma once
+#include "fp12.hpp"
+#include "g2.hpp"
+#include "pairing.hpp"
+
+namespace c12381 {
+
+struct tri { int role; int base; };      // role 0,1,2 = coefficient a,b,c; base = lane of role 0 in the wavefront
+
+#if defined(__HIP_DEVICE_COMPILE__)
+C12381_HD void tri_fetch_fp(fp& out, const fp& v, int src_role, const tri& t) {
+    int src = t.base + src_role;
+    src = src > 63 ? 63 : src;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) out.l[i] = __shfl(v.l[i], src, 64);
+}
+C12381_HD int tri_fetch_int(int v, int src_role, const tri& t) {
+    int src = t.base + src_role;
+    src = src > 63 ? 63 : src;
+    return __shfl(v, src, 64);
+}
+#else
+// host simulation: three threads per pairing exchange through a barrier-protected mailbox (tests/host_sim/sim.cpp)
+void c12381_tri_exchange(void* out, const void* in, size_t bytes, int src_role, const tri& t);
+inline void tri_fetch_fp(fp& out, const fp& v, int src_role, const tri& t) { fp tmp; c12381_tri_exchange(&tmp, &v, sizeof(fp), src_role, t); out = tmp; }
+inline int tri_fetch_int(int v, int src_role, const tri& t) { int tmp; c12381_tri_exchange(&tmp, &v, sizeof(int), src_role, t); return tmp; }
+#endif
+C12381_HD void tri_fetch_fp2(fp2& out, const fp2& v, int s, const tri& t) { tri_fetch_fp(out.a, v.a, s, t); tri_fetch_fp(out.b, v.b, s, t); }
+C12381_HD void tri_fetch_fp4(fp4& out, const fp4& v, int s, const tri& t) { tri_fetch_fp2(out.a, v.a, s, t); tri_fetch_fp2(out.b, v.b, s, t); }
+C12381_HD int tri_next(const tri& t) { return t.role == 2 ? 0 : t.role + 1; }
+C12381_HD int tri_prev(const tri& t) { return t.role == 0 ? 2 : t.role - 1; }
+
+// ------------------------------------------------------------------ inlined Fp4 cores (operands stay in registers)
+C12381_HD void fp4_mul_core(fp4& w, const fp4& x, const fp4& y) {
+    fp2 t1, t2, t3, t4;
+    fp2_mul(t1, x.a, y.a);
+    fp2_mul(t2, x.b, y.b);
+    fp2_add(t3, y.b, y.a);
+    fp2_add(t4, x.b, x.a);
+    fp2_mul(t4, t4, t3);
+    fp2_sub(t4, t4, t1);
+    fp2_sub(t4, t4, t2);
+    fp2_mul_ip(t3, t2);
+    fp2_add(t3, t3, t1);
+    fp2_norm1(w.b, t4);
+    fp2_norm1(w.a, t3);
+}
+
+// ------------------------------------------------------------------ Fp12 arithmetic on a triple
+// combine step shared by product and square: given this lane's z = x_r y_r and e = x_r y_{r+1} + x_{r+1} y_r,
+//   w_a = z_a + s e_b,   w_b = e_a + s z_c,   w_c = e_c + z_b
+C12381_HD void f12t_combine(fp4& w, const fp4& z, const fp4& zn, const fp4& e, const tri& t) {
+    fp4 v1, v2, sa, sb, ra, rb, rc, r;
+    const int s1 = t.role == 0 ? tri_next(t) : (t.role == 1 ? tri_prev(t) : t.role);
+    tri_fetch_fp4(v1, e, s1, t);                         // a <- e_b, b <- e_a
+    const int s2 = t.role == 2 ? tri_prev(t) : t.role;
+    tri_fetch_fp4(v2, z, s2, t);                         // c <- z_b
+    fp4_times_i(sa, v1); fp4_add(ra, z, sa);
+    fp4_times_i(sb, zn); fp4_add(rb, v1, sb);
+    fp4_add(rc, e, v2);
+    fp4_select(r, t.role == 0, ra, rb);
+    fp4_select(r, t.role == 2, rc, r);
+    fp4_norm1(w, r);
+}
+// w = x * y  (FP12_mul fp12_BLS12381.cpp:246-299).  Two Fp4 products per lane.  w may alias x or y.
+C12381_HDN void f12t_mul(fp4& w, const fp4& x, const fp4& y, const tri& t) {
+    fp4 xn, yn, z, zc, zn, e, sx, sy;
+    tri_fetch_fp4(xn, x, tri_next(t), t);
+    tri_fetch_fp4(yn, y, tri_next(t), t);
+    fp4_mul_core(z, x, y);
+    fp4_addn(sx, x, xn); fp4_addn(sy, y, yn);
+    fp4_mul_core(zc, sx, sy);
+    tri_fetch_fp4(zn, z, tri_next(t), t);
+    fp4_sub(e, zc, z); fp4_sub(e, e, zn); fp4_norm1(e, e);
+    f12t_combine(w, z, zn, e, t);
+}
+// w = x^2 (FP12_sqr :190-238 as six squarings: z_r = x_r^2, (x_r + x_{r+1})^2).  w may alias x.
+C12381_HDN void f12t_sqr(fp4& w, const fp4& x, const tri& t) {
+    fp4 xn, z, zc, zn, e, sx;
+    tri_fetch_fp4(xn, x, tri_next(t), t);
+    fp4_sqr_core(z, x);
+    fp4_addn(sx, x, xn);
+    fp4_sqr_core(zc, sx);
+    tri_fetch_fp4(zn, z, tri_next(t), t);
+    fp4_sub(e, zc, z); fp4_sub(e, e, zn); fp4_norm1(e, e);
+    f12t_combine(w, z, zn, e, t);
+}
+// Granger-Scott unitary squaring (FP12_usqr :147-186): one Fp4 squaring per lane.
+//   w_a = 3 xa^2 - 2 conj(xa),  w_b = 3 s xc^2 + 2 conj(xb),  w_c = 3 xb^2 - 2 conj(xc)
+C12381_HDN void f12t_usqr(fp4& w, const fp4& x, bool reduce, const tri& t) {
+    fp4 q, qq, sq, three, lin, c1, c2, r;
+    fp4_sqr_core(q, x);
+    const int src = t.role == 0 ? t.role : (t.role == 1 ? tri_next(t) : tri_prev(t));
+    tri_fetch_fp4(qq, q, src, t);
+    fp4_times_i(sq, qq); fp4_norm1(sq, sq);
+    fp4_select(qq, t.role == 1, sq, qq);
+    fp4_add(three, qq, qq); fp4_add(three, three, qq);
+    fp4_conj(c1, x); fp4_nconj(c2, x);
+    fp4_select(lin, t.role == 1, c1, c2);
+    fp4_add(lin, lin, lin);
+    fp4_add(r, three, lin);
+    if (reduce) fp4_weak_reduce(w, r); else fp4_norm1(w, r);
+}
+// FP12_conj :117-123
+C12381_HD void f12t_conj(fp4& w, const fp4& x, const tri& t) {
+    fp4 c1, c2;
+    fp4_conj(c1, x); fp4_nconj(c2, x);
+    fp4_select(w, t.role == 1, c2, c1);
+}
+// FP12_frob :867-880
+C12381_HDN void f12t_frob(fp4& w, const fp4& x, const tri& t) {
+    fp2 f, f2, f3, m;
+    fp2_set_const(f, FROB_F_A, FROB_F_B);
+    fp2_set_const(f2, FROB_F2_A, FROB_F2_B);
+    fp2_set_const(f3, FROB_F3_A, FROB_F3_B);
+    fp4 y, ym;
+    fp4_frob(y, x, f3);
+    fp2_select(m, t.role == 1, f, f2);
+    fp4_pmul(ym, y, m);
+    fp4_select(w, t.role == 0, y, ym);
+}
+// FP12_inv :627-664
+C12381_HDN void f12t_inv(fp4& w, const fp4& x, const tri& t) {
+    fp4 xn, xp, xa, xb, xc;
+    tri_fetch_fp4(xn, x, tri_next(t), t);
+    tri_fetch_fp4(xp, x, tri_prev(t), t);
+    // role 0: (own,next,prev) = (a,b,c); role 1: (b,c,a); role 2: (c,a,b)
+    fp4_select(xa, t.role == 0, x, xp); fp4_select(xa, t.role == 2, xn, xa);
+    fp4_select(xb, t.role == 1, x, xn); fp4_select(xb, t.role == 2, xp, xb);
+    fp4_select(xc, t.role == 2, x, xp); fp4_select(xc, t.role == 1, xn, xc);
+    // f_0 = xa^2 - s xb xc,  f_1 = s xc^2 - xa xb,  f_2 = xb^2 - xa xc
+    fp4 P, u, v, sq, cr, tmp, f;
+    fp4_select(P, t.role == 0, xa, xb); fp4_select(P, t.role == 1, xc, P);
+    fp4_select(u, t.role == 0, xb, xa);
+    fp4_select(v, t.role == 1, xb, xc);
+    fp4_sqr_core(sq, P);
+    fp4_mul_core(cr, u, v);
+    fp4_times_i(tmp, sq); fp4_norm1(tmp, tmp); fp4_select(sq, t.role == 1, tmp, sq);
+    fp4_times_i(tmp, cr); fp4_norm1(tmp, tmp); fp4_select(cr, t.role == 0, tmp, cr);
+    fp4_sub(f, sq, cr); fp4_norm1(f, f);
+    // f3 = xa f0 + s (xc f1 + xb f2): this lane's term is P * f
+    fp4 term, tn, tp, ta, tbc, f3, f3i;
+    fp4_mul_core(term, P, f);
+    tri_fetch_fp4(tn, term, tri_next(t), t);
+    tri_fetch_fp4(tp, term, tri_prev(t), t);
+    fp4_select(ta, t.role == 0, term, tp); fp4_select(ta, t.role == 2, tn, ta);
+    fp4 o1, o2;
+    fp4_select(o1, t.role == 0, tn, term);                 // the two terms that are not term_a
+    fp4_select(o2, t.role == 1, tn, tp);
+    fp4_add(tbc, o1, o2);
+    fp4_times_i(tmp, tbc);
+    fp4_add(f3, ta, tmp);
+    fp4_norm1(f3, f3);
+    fp4_inv(f3i, f3);
+    fp4_mul_core(w, f, f3i);
+}
+// f *= line(l0, l1, l2)  (sparse M-type line, see fp12_mul_line).  One dense-by-sparse product per lane.
+C12381_HDN void f12t_mul_line(fp4& x, const fp2& l0, const fp2& l1, const fp2& l2, const tri& t) {
+    fp4 la; la.a = l0; la.b = l1;
+    fp4 p;
+    fp2 q0, q1, qn0, qn1, ia, ib;
+    fp2_mul(q0, x.a, l2);
+    fp2_mul(q1, x.b, l2);
+    fp4_mul_core(p, x, la);
+    tri_fetch_fp2(qn0, q0, tri_next(t), t);
+    tri_fetch_fp2(qn1, q1, tri_next(t), t);
+    // roles a, b: + ((1+i) qn0, (1+i) qn1);   role c: + ((1+i) qn1, qn0)
+    fp2 pick;
+    fp2_select(pick, t.role == 2, qn1, qn0);
+    fp2_mul_ip(ia, pick);
+    fp2_mul_ip(ib, qn1);
+    fp2_select(ib, t.role == 2, qn0, ib);
+    fp2_add(p.a, p.a, ia);
+    fp2_add(p.b, p.b, ib);
+    fp4_norm1(x, p);
+}
+C12381_HDN void f12t_pow_x(fp4& r, const fp4& a, const tri& t) {      // a^x for unitary a, x < 0; r must not alias a
+    fp4 w = a;
+#pragma unroll 1
+    for (int i = 62; i >= 0; --i) {
+        f12t_usqr(w, w, (i & 1) == 0, t);
+        if ((BLS_X >> i) & 1ull) f12t_mul(w, w, a, t);
+    }
+    f12t_conj(r, w, t);
+}
+// PAIR_fexp :629-755
+C12381_HDN void f12t_final_exp(fp4& r, const tri& t) {
+    fp4 t0, y0, y1;
+    f12t_inv(t0, r, t);
+    f12t_conj(r, r, t);
+    f12t_mul(r, r, t0, t);
+    f12t_frob(t0, r, t); f12t_frob(t0, t0, t);
+    f12t_mul(r, t0, r, t);
+    f12t_usqr(y1, r, false, t); f12t_mul(y1, y1, r, t);                       // r^3
+    f12t_pow_x(y0, r, t); f12t_conj(t0, r, t); f12t_mul(r, y0, t0, t);        // r^(x-1)
+    f12t_pow_x(y0, r, t); f12t_conj(t0, r, t); f12t_mul(r, y0, t0, t);        // r^(x-1)
+    f12t_pow_x(y0, r, t); f12t_frob(t0, r, t); f12t_mul(r, y0, t0, t);        // ^(x+p)
+    f12t_pow_x(t0, r, t); f12t_pow_x(y0, t0, t);                              // r^(x^2)
+    f12t_frob(t0, r, t); f12t_frob(t0, t0, t);                                // r^(p^2)
+    f12t_mul(y0, y0, t0, t);
+    f12t_conj(t0, r, t);
+    f12t_mul(r, y0, t0, t);                                                   // ^(x^2+p^2-1)
+    f12t_mul(r, r, y1, t);
+}
+// FP12_isunity: every lane tests its own coefficient, the verdict is combined over the triple
+C12381_HD bool f12t_is_one(const fp4& x, const tri& t) {
+    fp d, one;
+    fp_one(one);
+    fp_sub(d, x.a.a, one);
+    const bool first = t.role == 0 ? fp_is_zero(d) : fp_is_zero(x.a.a);
+    const int mine = (first & fp_is_zero(x.a.b) & fp_is_zero(x.b.a) & fp_is_zero(x.b.b)) ? 1 : 0;
+    const int a = tri_fetch_int(mine, 0, t), b = tri_fetch_int(mine, 1, t), c = tri_fetch_int(mine, 2, t);
+    return (a & b & c) != 0;
+}
+
+// ------------------------------------------------------------------ Miller loop on a triple
+// Doubling step: role 0/1/2 holds X/Y/Z of T in `tc`.  Three Fp2 products per lane (PAIR_double :40-78 +
+// ECP2_dbl ecp2_BLS12381.cpp:358-409); the three line coefficients are then shared with all lanes.
+C12381_HDN void miller3_dbl_step(fp2& tc, fp2& l0, fp2& l1, fp2& l2, const fp& px, const fp& py, const tri& t) {
+    fp2 yt, zt, s0, t0, t2b, z8, a, b, p2, u, y3p, p3, own, piece;
+    tri_fetch_fp2(yt, tc, 1, t);                           // Y to everyone
+    tri_fetch_fp2(zt, tc, 2, t);                           // Z to everyone
+    fp2_sqr(s0, tc);                                       // a: X^2, b: Y^2, c: Z^2
+    tri_fetch_fp2(t0, s0, 1, t);                           // t0 = Y^2 to everyone
+    {   // c: 3b' Z^2; shared afterwards
+        fp2 tb;
+        fp2_mul_b3(tb, s0);
+        tri_fetch_fp2(t2b, tb, 2, t);
+    }
+    fp2_mul_small(z8, t0, 8);
+    // round 2: a: X*Y, b: Y*Z, c: t2b * 8Y^2
+    fp2_select(a, t.role == 2, t2b, tc);
+    fp2_select(b, t.role == 0, yt, zt); fp2_select(b, t.role == 2, z8, b);
+    fp2_mul(p2, a, b);                                     // a: xy, b: t1 = YZ, c: x3 = t2b z8
+    // u = Y^2 - 9b' Z^2, y3' = Y^2 + 3b' Z^2
+    fp2_dbl(u, t2b); fp2_add(u, u, t2b); fp2_sub(u, t0, u); fp2_norm1(u, u);
+    fp2_add(y3p, t0, t2b);
+    // round 3: a: u * xy, b: t1 * z8, c: u * y3'
+    fp2_select(a, t.role == 1, p2, u);
+    fp2_select(b, t.role == 0, p2, z8); fp2_select(b, t.role == 2, y3p, b);
+    fp2_mul(p3, a, b);
+    // a: X3 = 2 u xy; b: Z3 = t1 z8; c: Y3 = u y3' + x3
+    fp2 xa, yc;
+    fp2_dbl(xa, p3);
+    fp2_add(yc, p3, p2);
+    fp2_select(own, t.role == 0, xa, p3); fp2_select(own, t.role == 2, yc, own);   // role b holds Z3, role c holds Y3
+    // line pieces: a: l2 = 3 X^2 px, b: l0 = -2 YZ (1+i) py, c: l1 = 3b'Z^2 - Y^2
+    fp2 cc, aa, pm, bb;
+    fp2_dbl(cc, s0); fp2_add(cc, cc, s0);                  // a: 3X^2
+    fp2_dbl(aa, p2); fp2_neg(aa, aa); fp2_mul_ip(aa, aa);  // b: -2YZ(1+i)
+    fp2_select(a, t.role == 0, cc, aa);
+    fp sel;
+    fp_select(sel, t.role == 0, px, py);
+    fp2_norm1(a, a);
+    fp2_mul_fp(pm, a, sel);
+    fp2_sub(bb, t2b, t0); fp2_norm1(bb, bb);
+    fp2_select(piece, t.role == 2, bb, pm);
+    tri_fetch_fp2(l2, piece, 0, t);
+    tri_fetch_fp2(l0, piece, 1, t);
+    tri_fetch_fp2(l1, piece, 2, t);
+    // put Y3 on role 1 and Z3 on role 2
+    fp2 sw;
+    const int src = t.role == 0 ? 0 : (t.role == 1 ? 2 : 1);
+    tri_fetch_fp2(sw, own, src, t);
+    tc = sw;
+}
+// f = conj(Miller_{|x|}(Q, P)) on a triple.  Returns this lane's coefficient.
+C12381_HDN void miller3_loop(fp4& F, const fp& px, const fp& py, bool p_inf, const fp2& qx, const fp2& qy, bool q_inf, const tri& t) {
+    g2p Q;
+    Q.x = qx; Q.y = qy; fp2_one(Q.z);
+    {
+        g2p inf;
+        g2_set_inf(inf);
+        fp2_select(Q.x, q_inf, inf.x, Q.x);
+        fp2_select(Q.y, q_inf, inf.y, Q.y);
+        fp2_select(Q.z, q_inf, inf.z, Q.z);
+    }
+    fp2 tc;
+    fp2_select(tc, t.role == 0, Q.x, Q.y); fp2_select(tc, t.role == 2, Q.z, tc);
+    fp4 one4, zero4;
+    fp4_zero(zero4); one4 = zero4; fp_one(one4.a.a);
+    fp4_select(F, t.role == 0, one4, zero4);
+    constexpr unsigned __int128 N1 = (unsigned __int128)BLS_X;
+    constexpr unsigned __int128 N3 = N1 * 3;
+#pragma unroll 1
+    for (int i = 64; i >= 1; --i) {
+        f12t_sqr(F, F, t);
+        fp2 l0, l1, l2;
+        miller3_dbl_step(tc, l0, l1, l2, px, py, t);
+        f12t_mul_line(F, l0, l1, l2, t);
+        const int bt = (int)((N3 >> i) & 1) - (int)((N1 >> i) & 1);
+        if (bt != 0) {                                     // wave-uniform; 5 of 64 iterations
+            g2p T, S = Q;
+            tri_fetch_fp2(T.x, tc, 0, t); tri_fetch_fp2(T.y, tc, 1, t); tri_fetch_fp2(T.z, tc, 2, t);
+            if (bt < 0) g2_neg(S, Q);
+            miller_add_step(T, S, l0, l1, l2, px, py);     // replicated on the three lanes
+            fp2_select(tc, t.role == 0, T.x, T.y); fp2_select(tc, t.role == 2, T.z, tc);
+            f12t_mul_line(F, l0, l1, l2, t);
+        }
+    }
+    fp4 c;
+    f12t_conj(c, F, t);
+    fp4_select(F, p_inf, (t.role == 0 ? one4 : zero4), c);
+}
+
+}  // namespace c12381

@@ -245,3 +245,67 @@ int sim_miller_batch(size_t n, const uint8_t* g1_96, const uint8_t* g2_192, uint
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------- three-lanes-per-pairing variant (pairing3.hpp)
+#include <pthread.h>
+#include "../../crypto12381_amd/csrc/pairing3.hpp"
+
+namespace {
+struct TriBox { pthread_barrier_t bar; unsigned char slot[3][sizeof(fp4)]; };
+thread_local TriBox* tl_box = nullptr;
+}
+namespace c12381 {
+void c12381_tri_exchange(void* out, const void* in, size_t bytes, int src_role, const tri& t) {
+    std::memcpy(tl_box->slot[t.role], in, bytes);
+    pthread_barrier_wait(&tl_box->bar);
+    std::memcpy(out, tl_box->slot[src_role], bytes);
+    pthread_barrier_wait(&tl_box->bar);
+}
+}
+namespace {
+struct Tri3Job { TriBox* box; int role; size_t n; const uint8_t *a1, *a2, *b1, *b2; uint8_t* out; int mode; };
+void gt_store_coeff(uint8_t* o576, const fp4& x, int role) {
+    // FP12_toOctet order c | b | a, each Fp4 as b.b, b.a, a.b, a.a
+    uint8_t* o = o576 + (role == 0 ? 384 : (role == 1 ? 192 : 0));
+    const fp* order[4] = {&x.b.b, &x.b.a, &x.a.b, &x.a.a};
+    for (int j = 0; j < 4; ++j) { uint32_t raw[12]; fp_to_raw48(raw, *order[j]); std::memcpy(o + 48 * j, raw, 48); }
+}
+void* tri3_worker(void* arg) {
+    Tri3Job* jb = (Tri3Job*)arg;
+    tl_box = jb->box;
+    tri t{jb->role, 0};
+    for (size_t i = 0; i < jb->n; ++i) {
+        fp px, py; fp2 qx, qy; bool pinf, qinf;
+        fp4 F;
+        pair_load(px, py, pinf, qx, qy, qinf, jb->a1 + 96 * i, jb->a2 + 192 * i);
+        miller3_loop(F, px, py, pinf, qx, qy, qinf, t);
+        if (jb->mode == 1) {          // equality: f * conj(g), one final exponentiation, is-unity
+            fp4 G, Gc;
+            pair_load(px, py, pinf, qx, qy, qinf, jb->b1 + 96 * i, jb->b2 + 192 * i);
+            miller3_loop(G, px, py, pinf, qx, qy, qinf, t);
+            f12t_conj(Gc, G, t);
+            f12t_mul(F, F, Gc, t);
+            f12t_final_exp(F, t);
+            const bool ok = f12t_is_one(F, t);
+            if (jb->role == 0) jb->out[i] = ok ? 1 : 0;
+        } else {
+            f12t_final_exp(F, t);
+            gt_store_coeff(jb->out + 576 * i, F, jb->role);
+        }
+    }
+    return nullptr;
+}
+int run_tri3(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, uint8_t* out, int mode) {
+    TriBox box;
+    pthread_barrier_init(&box.bar, nullptr, 3);
+    pthread_t th[3]; Tri3Job jb[3];
+    for (int r = 0; r < 3; ++r) { jb[r] = Tri3Job{&box, r, n, a1, a2, b1, b2, out, mode}; pthread_create(&th[r], nullptr, tri3_worker, &jb[r]); }
+    for (int r = 0; r < 3; ++r) pthread_join(th[r], nullptr);
+    pthread_barrier_destroy(&box.bar);
+    return 0;
+}
+}
+extern "C" {
+int sim_pair3_batch(size_t n, const uint8_t* g1_96, const uint8_t* g2_192, uint8_t* gt576) { return run_tri3(n, g1_96, g2_192, nullptr, nullptr, gt576, 0); }
+int sim_pair3_eq_batch(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, uint8_t* ok) { return run_tri3(n, a1, a2, b1, b2, ok, 1); }
+}

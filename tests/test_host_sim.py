@@ -21,7 +21,7 @@ def sim():
     so = os.path.join(SIM_DIR, "libsim.so")
     srcs = [os.path.join(SIM_DIR, "sim.cpp")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.run(["g++", "-O1", "-std=c++17", "-DC12381_CHECK_BOUNDS", "-fPIC", "-shared", "-o", so,
+        subprocess.run(["g++", "-O1", "-std=c++17", "-DC12381_CHECK_BOUNDS", "-fPIC", "-shared", "-pthread", "-o", so,
                         os.path.join(SIM_DIR, "sim.cpp")], check=True)
     return ctypes.CDLL(so)
 
@@ -139,3 +139,18 @@ def test_sim_gt_ops_and_split_pairing(sim, oracle_port):
     f = ctypes.create_string_buffer(576 * 3)
     assert sim.sim_gt_op_batch(3, sz(3), m.raw, None, f) == 0
     assert f.raw == gt[:576 * 3] == oracle_port.fexp(m.raw)
+
+
+def test_sim_pairing_three_lanes(sim):
+    """pairing3.hpp: three lanes per pairing, cross-lane shuffles emulated by three host threads and a barrier."""
+    g = golden("pairing")
+    g1, g2 = cat(g["g1"]), cat(g["g2"])
+    n = len(g1) // 96
+    out = ctypes.create_string_buffer(576 * n)
+    assert sim.sim_pair3_batch(sz(n), g1, g2, out) == 0
+    assert out.raw == cat(g["gt"])
+    a1, a2, b1, b2 = cat(g["eq_a1"]), cat(g["eq_a2"]), cat(g["eq_b1"]), cat(g["eq_b2"])
+    m = len(a1) // 96
+    ok = ctypes.create_string_buffer(m)
+    assert sim.sim_pair3_eq_batch(sz(m), a1, a2, b1, b2, ok) == 0
+    assert list(ok.raw[:m]) == g["eq"]
