@@ -34,7 +34,7 @@ namespace {
 
 constexpr int BLOCK = 256;
 constexpr size_t G1_CHUNK = (size_t)1 << 17;     // elements per scalar-mul launch = resident lanes at 2 waves/SIMD; table slab 176 MiB (fits the 256 MiB Infinity Cache)
-constexpr size_t G2_CHUNK = (size_t)1 << 17;     // G2 table slab = 704 MiB
+constexpr size_t G2_CHUNK = (size_t)1 << 17;     // G2 table slab = 352 MiB (2688-byte record per lane)
 constexpr int FINISH_M = 16;                     // elements per lane in the simultaneous inversion
 
 // ------------------------------------------------------------------ device helpers
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(BLOCK, 2) g2_mul_kernel(size_t n, const uint8_
     load_raw32(raw, scalars + 32 * i);
     scalar_from_raw32(k, raw);
     g2p acc;
-    g2_scalar_mul(acc, qx, qy, inf || !ok, k, tab, tab_stride, i);
+    g2_scalar_mul(acc, qx, qy, inf || !ok, k, tab + i * (size_t)G2_TAB_DWORDS);
     if (!ok) *bad_flag = 1;
     g2_store_affine(out + (size_t)fmt * i, acc, fmt, !ok);
 }

@@ -83,52 +83,153 @@ C12381_HD void soa_load_g2(g2p& p, const int32_t* base, size_t stride, size_t id
     soa_load_fp2(p.z, base + (size_t)4 * NL * stride, stride, idx);
 }
 
+// ------------------------------------------------------------------ per-lane window table (one 2688-byte record)
 constexpr int G2_WIN = 4;
-constexpr int G2_TAB = 1 << G2_WIN;
-constexpr int G2_TAB_DWORDS = G2_TAB * 6 * NL;
+constexpr int G2_TAB = 8;                               // entries 1..8 (signed digits)
+constexpr int G2_ENT_DWORDS = 6 * NL;                   // 84 dwords = 21 16-byte accesses
+constexpr int G2_TAB_DWORDS = G2_TAB * G2_ENT_DWORDS;   // 672 dwords per lane
 
-// [k]Q, Q affine or infinity; 4-bit fixed windows over k mod r (255 bits), table of 16 multiples in HBM.
-// (The reference uses a 4-dimensional GS decomposition, pair_BLS12381.cpp:814-873 + ECP2_mul4; only
-// the resulting group element is observable.)
-C12381_HDN void g2_scalar_mul(g2p& acc, const fp2& qx, const fp2& qy, bool q_is_inf, const uint32_t (&kin)[8],
-                             int32_t* tab, size_t stride, size_t lane) {
+C12381_HD void tab_store_g2(int32_t* ent, const g2p& p) {
+    const fp* c[6] = {&p.x.a, &p.x.b, &p.y.a, &p.y.b, &p.z.a, &p.z.b};
+    int32_t w[G2_ENT_DWORDS];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int i = 0; i < NL; ++i) w[j * NL + i] = c[j]->l[i];
+    q4* dst = reinterpret_cast<q4*>(ent);
+#pragma unroll
+    for (int i = 0; i < G2_ENT_DWORDS / 4; ++i) { q4 t; t.v[0] = w[4 * i]; t.v[1] = w[4 * i + 1]; t.v[2] = w[4 * i + 2]; t.v[3] = w[4 * i + 3]; dst[i] = t; }
+}
+C12381_HD void tab_load_g2(g2p& p, const int32_t* ent) {
+    int32_t w[G2_ENT_DWORDS];
+    const q4* src = reinterpret_cast<const q4*>(ent);
+#pragma unroll
+    for (int i = 0; i < G2_ENT_DWORDS / 4; ++i) { q4 t = src[i]; w[4 * i] = t.v[0]; w[4 * i + 1] = t.v[1]; w[4 * i + 2] = t.v[2]; w[4 * i + 3] = t.v[3]; }
+    fp* c[6] = {&p.x.a, &p.x.b, &p.y.a, &p.y.b, &p.z.a, &p.z.b};
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) c[j]->l[i] = w[j * NL + i];
+        C12381_BOUNDS(c[j]->lb = 268435456.0 + 8.0; c[j]->vb = 4.0; check_actual(*c[j], "tab_load_g2");)
+    }
+}
+
+// psi^I(X,Y,Z) = (conj^I(X) c_x, conj^I(Y) c_y, conj^I(Z))   (ECP2_frob ecp2_BLS12381.cpp:579-590 applied I times with
+// X = 1/f as PAIR_G2mul does for the M-type twist, pair_BLS12381.cpp:944-947).  psi is a group homomorphism of the
+// twist, so psi^I(d Q) = d psi^I(Q): one table of multiples of Q serves all four sub-scalars.
+template <int I>
+C12381_HD void g2_psi(g2p& r, const g2p& p) {
+    if (I == 0) { r = p; return; }
+    if (I == 2) {
+        fp cx, cy;
+        fp_set_const(cx, PSI2_X); fp_set_const(cy, PSI2_Y);
+        fp2_mul_fp(r.x, p.x, cx); fp2_mul_fp(r.y, p.y, cy); r.z = p.z;
+        return;
+    }
+    fp2 cx, cy, t;
+    if (I == 1) { fp2_set_const(cx, PSI1_X_A, PSI1_X_B); fp2_set_const(cy, PSI1_Y_A, PSI1_Y_B); }
+    else { fp2_set_const(cx, PSI3_X_A, PSI3_X_B); fp2_set_const(cy, PSI3_Y_A, PSI3_Y_B); }
+    fp2_conj(t, p.x); fp2_mul(r.x, t, cx);
+    fp2_conj(t, p.y); fp2_mul(r.y, t, cy);
+    fp2_conj(r.z, p.z);
+}
+
+// k (< r, 8 words) -> base-|x| digits u0..u3 (each < 2^64): k = u0 + u1|x| + u2|x|^2 + u3|x|^3   (gs() pair_BLS12381.cpp:814-873)
+C12381_HD void scalar_gs_split(uint32_t (&u)[4][2], const uint32_t (&k)[8]) {
+    uint32_t w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = k[i];
+#pragma unroll 1
+    for (int lvl = 0; lvl < 3; ++lvl) {
+        uint32_t rem[3] = {0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 1
+        for (int bit = 255; bit >= 0; --bit) {
+            const uint32_t in = (w[bit >> 5] >> (bit & 31)) & 1u;
+            rem[2] = (rem[2] << 1) | (rem[1] >> 31); rem[1] = (rem[1] << 1) | (rem[0] >> 31); rem[0] = (rem[0] << 1) | in;
+            uint32_t d[3]; uint64_t bw = 0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { uint64_t t = (uint64_t)rem[i] - (i < 2 ? BLS_X_W[i] : 0u) - bw; d[i] = (uint32_t)t; bw = (t >> 32) & 1; }
+            const bool ge = bw == 0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) rem[i] = ge ? d[i] : rem[i];
+            q[bit >> 5] |= (ge ? 1u : 0u) << (bit & 31);
+        }
+        u[lvl][0] = rem[0]; u[lvl][1] = rem[1];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = q[i];
+    }
+    u[3][0] = w[0]; u[3][1] = w[1];
+}
+// signed digit of window w (0..16) of u' = u + 0x8888888888888888; window 16 is the carry nibble
+C12381_HD int gs_digit(const uint32_t (&ub)[3], int w) {
+    const int nib = (int)((ub[w >> 3] >> ((w & 7) * 4)) & 15u);
+    return w == 16 ? nib : nib - 8;
+}
+C12381_HD void gs_bias(uint32_t (&ub)[3], const uint32_t (&u)[2]) {
+    uint64_t c = (uint64_t)u[0] + 0x88888888u; ub[0] = (uint32_t)c; c >>= 32;
+    c += (uint64_t)u[1] + 0x88888888u; ub[1] = (uint32_t)c; ub[2] = (uint32_t)(c >> 32);
+}
+// acc += (-1)^I sign(d) psi^I(T[|d|])
+template <int I>
+C12381_HD void g2_add_digit(g2p& acc, const int32_t* lane_tab, int d) {
+    const int mag = d < 0 ? -d : d;
+    const int idx = mag == 0 ? 1 : mag;
+    g2p q, e, inf;
+    tab_load_g2(q, lane_tab + (idx - 1) * G2_ENT_DWORDS);
+    g2_psi<I>(e, q);
+    const bool negate = (d < 0) != ((I & 1) != 0);
+    fp2 ny;
+    fp2_neg(ny, e.y);
+    fp2_select(e.y, negate, ny, e.y);
+    g2_set_inf(inf);
+    const bool isz = mag == 0;
+    fp2_select(e.x, isz, inf.x, e.x); fp2_select(e.y, isz, inf.y, e.y); fp2_select(e.z, isz, inf.z, e.z);
+    g2_add(acc, e);
+}
+
+// PAIR_G2mul pair_BLS12381.cpp:927-983: R = u0 Q - u1 psi(Q) + u2 psi^2(Q) - u3 psi^3(Q) for the base-|x| digits of
+// k mod r — exactly what the reference evaluates (ECP2_mul4 after gs() and the sign minimisation), on ANY point of
+// the twist; for Q in G2 it equals [k]Q.  64 doublings + 68 additions on one 8-entry table of multiples of Q.
+C12381_HDN void g2_scalar_mul(g2p& acc, const fp2& qx, const fp2& qy, bool q_is_inf, const uint32_t (&kin)[8], int32_t* lane_tab) {
     uint32_t k[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) k[i] = kin[i];
     scalar_mod_r(k);
+    uint32_t u[4][2], ub[4][3];
+    scalar_gs_split(u, k);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gs_bias(ub[i], u[i]);
     g2p base, t;
     g2_set_inf(t);
     base.x = qx; base.y = qy; fp2_one(base.z);
     fp2_select(base.x, q_is_inf, t.x, base.x);
     fp2_select(base.y, q_is_inf, t.y, base.y);
     fp2_select(base.z, q_is_inf, t.z, base.z);
-    const size_t ent = (size_t)6 * NL * stride;
-    soa_store_g2(tab, stride, lane, t);
-    soa_store_g2(tab + ent, stride, lane, base);
+    tab_store_g2(lane_tab, base);
     t = base;
     g2_dbl(t);
     {
         g2p n;
         g2_norm1(n, t);
-        soa_store_g2(tab + 2 * ent, stride, lane, n);
+        tab_store_g2(lane_tab + G2_ENT_DWORDS, n);
         t = n;
     }
 #pragma unroll 1
-    for (int j = 3; j < G2_TAB; ++j) {
+    for (int j = 3; j <= G2_TAB; ++j) {
         g2_add(t, base);
         g2p n;
         g2_norm1(n, t);
-        soa_store_g2(tab + (size_t)j * ent, stride, lane, n);
+        tab_store_g2(lane_tab + (j - 1) * G2_ENT_DWORDS, n);
         t = n;
     }
     g2_set_inf(acc);
 #pragma unroll 1
-    for (int w = 256 / G2_WIN - 1; w >= 0; --w) {
-        g2_dbl(acc); g2_dbl(acc); g2_dbl(acc); g2_dbl(acc);
-        const uint32_t d = (k[w >> 3] >> ((w & 7) * 4)) & 15u;
-        g2p q;
-        soa_load_g2(q, tab + (size_t)d * ent, stride, lane);
-        g2_add(acc, q);
+    for (int w = 16; w >= 0; --w) {
+        if (w != 16) { g2_dbl(acc); g2_dbl(acc); g2_dbl(acc); g2_dbl(acc); }
+        g2_add_digit<0>(acc, lane_tab, gs_digit(ub[0], w));
+        g2_add_digit<1>(acc, lane_tab, gs_digit(ub[1], w));
+        g2_add_digit<2>(acc, lane_tab, gs_digit(ub[2], w));
+        g2_add_digit<3>(acc, lane_tab, gs_digit(ub[3], w));
     }
 }
 

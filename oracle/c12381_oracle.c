@@ -400,14 +400,42 @@ static void scalar_load(uint64_t k[4], const uint8_t* s) {
         for (int i = 0; i < 4; i++) { u128 d = (u128)k[i] - RORD[i] - bw; k[i] = (uint64_t)d; bw = (d >> 64) & 1; }
     }
 }
-/* PAIR_G1mul pair_BLS12381.cpp:876-924.  The reference evaluates [k]P with a GLV split and
- * ECP_mul2's joint window (ecp_BLS12381.cpp:1150-1248); those are evaluation strategies for
- * the same group element, restated here as a plain left-to-right double-and-add on the
- * complete formulas. */
-static void g1_mul(g1p* P, const uint64_t k[4]) {
+/* plain left-to-right double-and-add on the complete formulas (the exact group operation) */
+static void g1_mul_plain(g1p* P, const uint64_t* k, int nw) {
     g1p acc; g1_inf(&acc);
-    for (int i = bn_nbits(k, 4) - 1; i >= 0; i--) { g1_dbl(&acc); if (bn_bit(k, 4, i)) g1_add(&acc, P); }
+    for (int i = bn_nbits(k, nw) - 1; i >= 0; i--) { g1_dbl(&acc); if (bn_bit(k, nw, i)) g1_add(&acc, P); }
     *P = acc;
+}
+/* q = a div d, rem = a mod d for a < 2^256 (4 words) and d < 2^128 (2 words): restoring division */
+static void bn_divmod_128(uint64_t q[4], uint64_t rem[2], const uint64_t a[4], const uint64_t d[2]) {
+    uint64_t r[3] = {0, 0, 0};
+    memset(q, 0, 32);
+    for (int i = 255; i >= 0; i--) {
+        r[2] = (r[2] << 1) | (r[1] >> 63); r[1] = (r[1] << 1) | (r[0] >> 63); r[0] = (r[0] << 1) | (uint64_t)bn_bit(a, 4, i);
+        int ge = r[2] || r[1] > d[1] || (r[1] == d[1] && r[0] >= d[0]);
+        if (ge) { u128 t = (u128)r[0] - d[0]; r[0] = (uint64_t)t; uint64_t bw = (uint64_t)(t >> 64) & 1; t = (u128)r[1] - d[1] - bw; r[1] = (uint64_t)t; bw = (uint64_t)(t >> 64) & 1; r[2] -= bw; q[i / 64] |= 1ULL << (i % 64); }
+    }
+    rem[0] = r[0]; rem[1] = r[1];
+}
+static fp BETA;      /* CRu (rom_field_BLS12381.cpp:54): (beta x, y) = [-x^2](x, y) on G1; fixed by a self-test at init */
+/* PAIR_G1mul pair_BLS12381.cpp:876-924 with glv() :793-805: u0 = k mod x^2, u1 = r - (k div x^2); the sign
+ * minimisation (:896-914) then replaces (u1, phi(P)) by (k div x^2, -phi(P)), so what ECP_mul2 evaluates — with
+ * complete formulas, i.e. as exact group operations on ANY curve point, in or out of the order-r subgroup — is
+ *     R = [k mod x^2] P + [k div x^2] (-phi(P)),   phi(x, y) = (beta x, y).
+ * (For P in G1 this is [k]P.)  The joint window schedule of ECP_clmul2 is an evaluation strategy. */
+static void g1_mul(g1p* P, const uint64_t k[4]) {
+    if (g1_is_inf(P)) return;
+    u128 x2 = (u128)BNX * BNX;
+    uint64_t d[2] = {(uint64_t)x2, (uint64_t)(x2 >> 64)}, q[4], u0[2];
+    bn_divmod_128(q, u0, k, d);
+    g1p A = *P, Q = *P;
+    g1_affine(&Q);
+    fp_mul(&Q.x, &Q.x, &BETA);
+    fp_neg(&Q.y, &Q.y);
+    g1_mul_plain(&A, u0, 2);
+    g1_mul_plain(&Q, q, 2);
+    g1_add(&A, &Q);
+    *P = A;
 }
 
 /* ------------------------------------------------------------------ G2 (ecp2_BLS12381.cpp) */
@@ -484,10 +512,41 @@ static void g2_store(uint8_t* out, g2p* P, int fmt) {                           
     if (fmt == 97) { out[0] = (uint8_t)(0x02 | fp2_sign(&P->y)); fp2_to_bytes(out + 1, &P->x); }
     else { fp2_to_bytes(out, &P->x); fp2_to_bytes(out + 96, &P->y); }
 }
-/* PAIR_G2mul pair_BLS12381.cpp:927-983 (4-dim GS + ECP2_mul4 are evaluation strategies; same element) */
-static void g2_mul(g2p* P, const uint64_t k[4]) {
+static void g2_mul_plain(g2p* P, const uint64_t* k, int nw) {
     g2p acc; g2_inf(&acc);
-    for (int i = bn_nbits(k, 4) - 1; i >= 0; i--) { g2_dbl(&acc); if (bn_bit(k, 4, i)) g2_add(&acc, P); }
+    for (int i = bn_nbits(k, nw) - 1; i >= 0; i--) { g2_dbl(&acc); if (bn_bit(k, nw, i)) g2_add(&acc, P); }
+    *P = acc;
+}
+static fp2 PSI_X, PSI_Y;   /* g^2, g^3 with g = 1/(Fra + i Frb): ECP2_frob ecp2_BLS12381.cpp:579-590 with X inverted (M-type, pair:944-947) */
+/* ECP2_frob :579-590 */
+static void g2_frob(g2p* P) {
+    fp2_conj(&P->x, &P->x); fp2_conj(&P->y, &P->y); fp2_conj(&P->z, &P->z);
+    fp2_mul(&P->x, &PSI_X, &P->x); fp2_mul(&P->y, &PSI_Y, &P->y);
+}
+/* PAIR_G2mul pair_BLS12381.cpp:927-983 with gs() :814-873 (BLS branch): k mod r is written in base |x|,
+ * k = u0 + u1|x| + u2|x|^2 + u3|x|^3; x < 0 makes the odd digits negative (:868-871) and the sign minimisation
+ * (:962-971) turns that into negated points, so ECP2_mul4 evaluates — exactly, on any point of the twist —
+ *     R = u0 Q - u1 psi(Q) + u2 psi^2(Q) - u3 psi^3(Q).
+ * (For Q in G2, psi(Q) = [x]Q and this is [k]Q.) */
+static void g2_mul(g2p* P, const uint64_t k[4]) {
+    if (g2_is_inf(P)) return;
+    uint64_t w[4], u[4];
+    memcpy(w, k, 32);
+    for (int i = 0; i < 3; i++) {
+        u128 rem = 0; uint64_t q[4];
+        for (int j = 3; j >= 0; j--) { u128 cur = (rem << 64) | w[j]; q[j] = (uint64_t)(cur / BNX); rem = cur % BNX; }
+        u[i] = (uint64_t)rem; memcpy(w, q, 32);
+    }
+    u[3] = w[0];
+    g2p acc, Q = *P; g2_inf(&acc);
+    for (int i = 0; i < 4; i++) {
+        g2p T = Q;
+        if (i & 1) g2_neg(&T);
+        uint64_t e[1] = {u[i]};
+        g2_mul_plain(&T, e, 1);
+        g2_add(&acc, &T);
+        g2_frob(&Q);
+    }
     *P = acc;
 }
 
@@ -593,6 +652,23 @@ static void init_consts(void) {
     fp2 base, acc; memset(&base, 0, sizeof base); base.a = ONE; base.b = ONE; fp2_one(&acc);
     for (int i = 0; i < 384; i++) { if (bn_bit(E_PM1D6, 6, i)) fp2_mul(&acc, &acc, &base); fp2_sqr(&base, &base); }
     FROB = acc;
+    /* psi constants: g = 1/f, g^2, g^3 */
+    fp2 g; fp2_inv(&g, &FROB);
+    fp2_sqr(&PSI_X, &g); fp2_mul(&PSI_Y, &PSI_X, &g);
+    /* beta: the primitive cube root of unity with (beta Gx, Gy) = [-x^2 mod r] G on the generator */
+    uint64_t pm1d3[6]; bn_div_small(pm1d3, pm1, 6, 3);
+    fp cand, gsmall, b1, b2;
+    for (int gi = 2;; gi++) { fp_set_int(&gsmall, gi); fp_pow(&cand, &gsmall, pm1d3, 6); if (!fp_eq(&cand, &ONE)) break; }
+    b1 = cand; fp_sqr(&b2, &cand);
+    uint8_t gb[96]; hex48(gb, G1X_HEX); hex48(gb + 48, G1Y_HEX);
+    g1p G, T; fp gx, gy; fp_from_bytes(&gx, gb); fp_from_bytes(&gy, gb + 48); g1_set(&G, &gx, &gy);
+    /* lam = r - x^2 */
+    u128 x2 = (u128)BNX * BNX; uint64_t lam[4]; u128 bw = 0;
+    uint64_t x2w[4] = {(uint64_t)x2, (uint64_t)(x2 >> 64), 0, 0};
+    for (int i = 0; i < 4; i++) { u128 d = (u128)RORD[i] - x2w[i] - (uint64_t)bw; lam[i] = (uint64_t)d; bw = (d >> 64) & 1; }
+    T = G; g1_mul_plain(&T, lam, 4); g1_affine(&T);
+    fp t1; fp_mul(&t1, &gx, &b1);
+    BETA = fp_eq(&t1, &T.x) ? b1 : b2;
 }
 #define INIT() pthread_once(&once, init_consts)
 

@@ -94,6 +94,19 @@ def main():
     # MSM
     g1j["msm_n"] = n
     g1j["msm49"] = ref.g1_msm(pts_e, sc, 49, 4).hex()
+    # points ON the curve but OUTSIDE the order-r subgroup (the reference performs no subgroup check, and its GLV
+    # evaluation [k mod x^2]P - [k div x^2]phi(P) is then NOT [k]P): decompress small x values
+    off, xv = [], 1
+    while len(off) < 6:
+        o, st = ref.g1_decompress(bytes([2 + (xv & 1)]) + xv.to_bytes(48, "big"))
+        if st[0] == 1:
+            off.append(o)
+        xv += 1
+    off = b"".join(off)
+    off_sc = scalars(24, 6, 1 << 256)
+    g1j["offsubgroup_points"], g1j["offsubgroup_scalars"] = hx(off, 96), hx(off_sc, 32)
+    g1j["offsubgroup_mul96"] = hx(ref.g1_mul(off, off_sc, 96), 96)
+    g1j["offsubgroup_msm49"] = ref.g1_msm(off, off_sc, 49, 2).hex()
     g1j["generator"] = g1.hex()
     json.dump(g1j, open(os.path.join(OUT, "g1.json"), "w"), indent=0)
 
@@ -123,6 +136,16 @@ def main():
     g2j["compressed"] = hx(cin2, 97)
     g2j["decompressed"] = hx(dec2, 192)
     g2j["decompress_status"] = list(st2)
+    off2, xv = [], 1
+    while len(off2) < 6:
+        o, st = ref.g2_decompress(bytes([2 + (xv & 1)]) + (7 * xv).to_bytes(48, "big") + xv.to_bytes(48, "big"))
+        if st[0] == 1:
+            off2.append(o)
+        xv += 1
+    off2 = b"".join(off2)
+    off2_sc = scalars(34, 6, 1 << 256)
+    g2j["offsubgroup_points"], g2j["offsubgroup_scalars"] = hx(off2, 192), hx(off2_sc, 32)
+    g2j["offsubgroup_mul192"] = hx(ref.g2_mul(off2, off2_sc, 192), 192)   # = u0 Q - u1 psi(Q) + u2 psi^2(Q) - u3 psi^3(Q)
     g2j["generator"] = g2.hex()
     json.dump(g2j, open(os.path.join(OUT, "g2.json"), "w"), indent=0)
 

@@ -103,7 +103,8 @@ static void fp2_to_bytes96(uint8_t* p, const fp2& x) {
 extern "C" {
 
 int sim_g2_mul_batch(size_t n, const uint8_t* pts192, const uint8_t* scalars32, uint8_t* out, int fmt) {
-    std::vector<int32_t> tab(G2_TAB_DWORDS);
+    std::vector<int32_t> tabv(G2_TAB_DWORDS + 4);
+    int32_t* tab = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(tabv.data()) + 15) & ~(uintptr_t)15);
     for (size_t i = 0; i < n; ++i) {
         uint32_t rp[48], rs[8], k[8];
         load_raw(rp, pts192 + 192 * i, 48); load_raw(rs, scalars32 + 32 * i, 8);
@@ -112,7 +113,7 @@ int sim_g2_mul_batch(size_t n, const uint8_t* pts192, const uint8_t* scalars32, 
         fp2_from_bytes96(qx, pts192 + 192 * i); fp2_from_bytes96(qy, pts192 + 192 * i + 96);
         scalar_from_raw32(k, rs);
         g2p acc;
-        g2_scalar_mul(acc, qx, qy, inf, k, tab.data(), 1, 0);
+        g2_scalar_mul(acc, qx, qy, inf, k, tab);
         uint8_t* o = out + (size_t)fmt * i;
         if (fp2_is_zero(acc.z)) { std::memset(o, 0, fmt); continue; }
         fp2 zn, zi, ax, ay;

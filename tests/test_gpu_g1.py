@@ -98,3 +98,14 @@ def test_g1_full_size_properties(ctx, oracle_port):
     for i in range(n):
         tot += s_base[i % m] * int.from_bytes(sc[32 * i:32 * i + 32], "big")
     assert lhs == oracle_port.g1_mul(g1, (tot % R).to_bytes(32, "big"), 49)
+
+
+def test_points_outside_the_subgroup(ctx):
+    """No subgroup check in the reference: GLV/GS results on such points are pinned by golden vectors."""
+    g = golden("g1")
+    pts, sc = cat(g["offsubgroup_points"]), cat(g["offsubgroup_scalars"])
+    assert ctx.g1_mul(pts, sc, 96) == cat(g["offsubgroup_mul96"])
+    assert ctx.g1_msm(pts, sc, 49).hex() == g["offsubgroup_msm49"]
+    g = golden("g2")
+    pts, sc = cat(g["offsubgroup_points"]), cat(g["offsubgroup_scalars"])
+    assert ctx.g2_mul(pts, sc, 192) == cat(g["offsubgroup_mul192"])

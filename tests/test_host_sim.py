@@ -91,6 +91,18 @@ def test_sim_g2_mul_golden(sim):
         assert out.raw == cat(g[key])
 
 
+def test_sim_points_outside_the_subgroup(sim):
+    """GLV (G1) and GS (G2) on the device reproduce the reference's results for curve points outside G1/G2."""
+    g = golden("g1")
+    pts, sc = cat(g["offsubgroup_points"]), cat(g["offsubgroup_scalars"])
+    out = ctypes.create_string_buffer(96 * 6)
+    assert sim.sim_g1_mul_batch(sz(6), pts, sc, out, 96) == 0 and out.raw == cat(g["offsubgroup_mul96"])
+    g = golden("g2")
+    pts, sc = cat(g["offsubgroup_points"]), cat(g["offsubgroup_scalars"])
+    out = ctypes.create_string_buffer(192 * 6)
+    assert sim.sim_g2_mul_batch(sz(6), pts, sc, out, 192) == 0 and out.raw == cat(g["offsubgroup_mul192"])
+
+
 def test_sim_pairing_golden(sim):
     """Miller loop + final exponentiation of the device headers, incl. infinity arguments."""
     g = golden("pairing")

@@ -63,6 +63,18 @@ def test_g1_golden(orc):
     assert orc.g1_generator().hex() == g["generator"]
 
 
+def test_points_outside_the_subgroup(orc):
+    """The reference never checks subgroup membership; its endomorphism-based multiplications are then a different
+    (well-defined) function of the input, which the oracle — and the GPU path — must reproduce."""
+    g = golden("g1")
+    pts, sc = cat(g["offsubgroup_points"]), cat(g["offsubgroup_scalars"])
+    assert orc.g1_mul(pts, sc, 96) == cat(g["offsubgroup_mul96"])
+    assert orc.g1_msm(pts, sc, 49, 2).hex() == g["offsubgroup_msm49"]
+    g = golden("g2")
+    pts, sc = cat(g["offsubgroup_points"]), cat(g["offsubgroup_scalars"])
+    assert orc.g2_mul(pts, sc, 192) == cat(g["offsubgroup_mul192"])
+
+
 def test_g1_edge_semantics(orc):
     """Edge cases the reference's unit tests pin as laws (unit-tests/g1_point.cpp:51-78)."""
     g = golden("g1")
