@@ -13,6 +13,7 @@
 //   pair_kernel        Miller loop + final exponentiation -> 576-byte GT
 //   pair_eq_kernel     e(a1,a2) == e(b1,b2): two Miller loops, ONE final exponentiation, is-unity
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <cstdio>
 #include <cstdlib>
@@ -27,6 +28,7 @@
 #include "g2.hpp"
 #include "pairing.hpp"
 #include "pairing3.hpp"
+#include "msm.hpp"
 
 using namespace c12381;
 
@@ -447,6 +449,47 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_kernel(size_t n, const uint
     }
 }
 
+// ------------------------------------------------------------------ bucket-method MSM kernels (msm.hpp)
+__global__ void __launch_bounds__(BLOCK, 2) msm_prep_kernel(size_t n, const uint8_t* pts, const uint8_t* scalars, int c, int W, int32_t* pts2,
+                                                         uint32_t* keys, uint32_t* vals, int* bad_flag) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint32_t rp[24], rs[8];
+    load_raw48(rp, pts + 96 * i); load_raw48(rp + 12, pts + 96 * i + 48);
+    load_raw32(rs, scalars + 32 * i);
+    if (!msm_prep_one(i, n, rp, rs, c, W, pts2, keys, vals)) *bad_flag = 1;
+}
+__global__ void __launch_bounds__(BLOCK, 2) msm_ranges_kernel(size_t E, const uint32_t* keys, uint32_t* lo, uint32_t* hi) {
+    const size_t j = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= E) return;
+    const uint32_t k = keys[j];
+    if (j == 0 || keys[j - 1] != k) lo[k] = (uint32_t)j;
+    if (j + 1 == E || keys[j + 1] != k) hi[k] = (uint32_t)(j + 1);
+}
+__global__ void __launch_bounds__(BLOCK, 2) msm_bucket_kernel(size_t nbk, const uint32_t* lo, const uint32_t* hi, const uint32_t* vals,
+                                                           const int32_t* pts2, int32_t* bk) {
+    const size_t b = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (b >= nbk) return;
+    g1p acc, nn;
+    msm_bucket_one(acc, lo[b], hi[b], vals, pts2);
+    g1_norm1(nn, acc);
+    tab_store_g1(bk + b * G1_ENT_DWORDS, nn);
+}
+__global__ void __launch_bounds__(BLOCK, 2) msm_wreduce_kernel(int W, uint32_t nb, uint32_t chunks, const int32_t* bk, int32_t* out, size_t out_stride) {
+    const size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= (size_t)W * chunks) return;
+    const uint32_t w = (uint32_t)(t / chunks), ch = (uint32_t)(t % chunks);
+    g1p part;
+    msm_wreduce_one(part, bk + (size_t)w * nb * G1_ENT_DWORDS, ch * MSM_CHUNK, nb);
+    soa_store_g1(out, out_stride, (size_t)ch * W + w, part);
+}
+__global__ void __launch_bounds__(64, 1) msm_horner_kernel(const int32_t* rw, size_t stride, int W, int c, int32_t* out, size_t out_stride) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    g1p acc;
+    msm_horner(acc, rw, stride, W, c);
+    soa_store_g1(out, out_stride, 0, acc);
+}
+
 // ------------------------------------------------------------------ decode / split pairing / GT kernels
 // ECP_fromOctet ecp_BLS12381.cpp:495-545 for 49-byte input (tags 02/03; a leading 00 is infinity as in
 // g1_point.hpp:89-93); status 1 ok / 0 reject; rejected and infinity lanes give 96 zero bytes.
@@ -537,7 +580,8 @@ struct c12381_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     char err[256] = {0};
-    enum { WS_TAB, WS_PROJ, WS_PREF, WS_IN0, WS_IN1, WS_OUT, WS_RED0, WS_RED1, WS_BBS_Q, WS_BBS_B, WS_BBS_IN, WS_COUNT };
+    enum { WS_TAB, WS_PROJ, WS_PREF, WS_IN0, WS_IN1, WS_OUT, WS_RED0, WS_RED1, WS_BBS_Q, WS_BBS_B, WS_BBS_IN,
+           WS_MSM_PTS, WS_MSM_K0, WS_MSM_K1, WS_MSM_V0, WS_MSM_V1, WS_MSM_TMP, WS_MSM_RNG, WS_MSM_BK, WS_COUNT };
     void* ws[WS_COUNT] = {nullptr};
     size_t ws_bytes[WS_COUNT] = {0};
     int* d_flag = nullptr;
@@ -639,6 +683,71 @@ int stage_out(c12381_ctx* c, const staged& s, void* hout, size_t bout) {
     return 0;
 }
 
+// Bucket-method MSM (msm.hpp): prep -> radix sort -> bucket sums -> window reduction -> Horner -> affine.
+int g1_msm_pippenger(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
+    const int cb = msm_window_bits(n), W = msm_windows(cb);
+    const size_t E = (size_t)2 * n * W, nb = (size_t)1 << cb, nbk = nb * W;
+    int rc;
+    if ((rc = ensure(c, c12381_ctx::WS_MSM_PTS, (size_t)2 * n * MSM_PT_DWORDS * 4))) return rc;
+    if ((rc = ensure(c, c12381_ctx::WS_MSM_K0, E * 4))) return rc;
+    if ((rc = ensure(c, c12381_ctx::WS_MSM_K1, E * 4))) return rc;
+    if ((rc = ensure(c, c12381_ctx::WS_MSM_V0, E * 4))) return rc;
+    if ((rc = ensure(c, c12381_ctx::WS_MSM_V1, E * 4))) return rc;
+    if ((rc = ensure(c, c12381_ctx::WS_MSM_RNG, (nbk + 1) * 8))) return rc;
+    if ((rc = ensure(c, c12381_ctx::WS_MSM_BK, nbk * G1_ENT_DWORDS * 4))) return rc;
+    int32_t* pts2 = (int32_t*)c->ws[c12381_ctx::WS_MSM_PTS];
+    uint32_t *k0 = (uint32_t*)c->ws[c12381_ctx::WS_MSM_K0], *k1 = (uint32_t*)c->ws[c12381_ctx::WS_MSM_K1];
+    uint32_t *v0 = (uint32_t*)c->ws[c12381_ctx::WS_MSM_V0], *v1 = (uint32_t*)c->ws[c12381_ctx::WS_MSM_V1];
+    uint32_t* lo = (uint32_t*)c->ws[c12381_ctx::WS_MSM_RNG];
+    uint32_t* hi = lo + nbk + 1;
+    int32_t* bk = (int32_t*)c->ws[c12381_ctx::WS_MSM_BK];
+    hipLaunchKernelGGL(msm_prep_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, pts, sc, cb, W, pts2, k0, v0, c->d_flag);
+    HIPCK(c, hipGetLastError());
+    int end_bit = cb;
+    while ((1 << (end_bit - cb)) <= W) ++end_bit;              // keys < (W + 1) << cb
+    size_t tmp_bytes = 0;
+    HIPCK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k0, k1, v0, v1, (int)E, 0, end_bit, c->stream));
+    if ((rc = ensure(c, c12381_ctx::WS_MSM_TMP, tmp_bytes + 256))) return rc;
+    HIPCK(c, hipcub::DeviceRadixSort::SortPairs(c->ws[c12381_ctx::WS_MSM_TMP], tmp_bytes, k0, k1, v0, v1, (int)E, 0, end_bit, c->stream));
+    HIPCK(c, hipMemsetAsync(lo, 0, (nbk + 1) * 8, c->stream));
+    hipLaunchKernelGGL(msm_ranges_kernel, dim3(grid_for(E)), dim3(BLOCK), 0, c->stream, E, k1, lo, hi);
+    HIPCK(c, hipGetLastError());
+    {
+        timed tm(c, 5);
+        hipLaunchKernelGGL(msm_bucket_kernel, dim3(grid_for(nbk)), dim3(BLOCK), 0, c->stream, nbk, lo, hi, v1, pts2, bk);
+        HIPCK(c, hipGetLastError());
+    }
+    const uint32_t chunks = (uint32_t)((nb + MSM_CHUNK - 1) / MSM_CHUNK);
+    size_t cur_n = (size_t)W * chunks, cur_stride = round_up(cur_n, 64);
+    if ((rc = ensure(c, c12381_ctx::WS_RED0, (size_t)3 * NL * cur_stride * 4))) return rc;
+    hipLaunchKernelGGL(msm_wreduce_kernel, dim3(grid_for(cur_n)), dim3(BLOCK), 0, c->stream, W, (uint32_t)nb, chunks, bk,
+                       (int32_t*)c->ws[c12381_ctx::WS_RED0], cur_stride);
+    HIPCK(c, hipGetLastError());
+    // per-window sums: element index = chunk * W + w, so reducing modulo (W * r) keeps windows apart
+    const int32_t* cur = (const int32_t*)c->ws[c12381_ctx::WS_RED0];
+    int slot = c12381_ctx::WS_RED1;
+    while (cur_n > (size_t)W) {
+        size_t groups = cur_n / W;                           // points per window still to be summed
+        size_t r = groups > 32 ? (groups + 31) / 32 : 1;     // keep r partial sums per window
+        const size_t m = (size_t)W * r, m_stride = round_up(m, 64);
+        if ((rc = ensure(c, slot, (size_t)3 * NL * m_stride * 4))) return rc;
+        hipLaunchKernelGGL(g1_reduce_kernel, dim3(grid_for(m)), dim3(BLOCK), 0, c->stream, cur_n, cur, cur_stride, m, (int32_t*)c->ws[slot], m_stride);
+        HIPCK(c, hipGetLastError());
+        cur = (const int32_t*)c->ws[slot]; cur_n = m; cur_stride = m_stride;
+        slot = slot == c12381_ctx::WS_RED0 ? c12381_ctx::WS_RED1 : c12381_ctx::WS_RED0;
+    }
+    if ((rc = ensure(c, c12381_ctx::WS_PROJ, (size_t)3 * NL * 64 * 4))) return rc;
+    hipLaunchKernelGGL(msm_horner_kernel, dim3(1), dim3(64), 0, c->stream, cur, cur_stride, W, cb, (int32_t*)c->ws[c12381_ctx::WS_PROJ], (size_t)64);
+    HIPCK(c, hipGetLastError());
+    return g1_finish(c, 1, (const int32_t*)c->ws[c12381_ctx::WS_PROJ], 64, out, fmt);
+}
+// C12381_MSM=naive forces the n-scalar-muls + tree-sum path (A/B measurements); default: buckets from 2^12 terms
+static bool msm_use_buckets(size_t n) {
+    static const int mode = [] { const char* e = std::getenv("C12381_MSM"); return e ? (e[0] == 'n' ? 1 : (e[0] == 'b' ? 2 : 0)) : 0; }();
+    if (mode == 1) return false;
+    if (mode == 2) return n >= 2;
+    return n >= 4096;
+}
 }  // namespace
 
 extern "C" {
@@ -783,6 +892,7 @@ int c12381_g1_msm_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t
     int rc = bind(c); if (rc) return rc;
     if (!out || (n && (!pts || !sc)) || (fmt != 49 && fmt != 96)) return C12381_E_ARG;
     if (n == 0) { HIPCK(c, hipMemsetAsync(out, 0, fmt, c->stream)); return 0; }
+    if (msm_use_buckets(n)) return g1_msm_pippenger(c, n, pts, sc, out, fmt);
     const size_t stride = round_up(n, 64);
     if ((rc = g1_mul_to_proj(c, n, pts, sc, stride))) return rc;
     const int32_t* cur = (const int32_t*)c->ws[c12381_ctx::WS_PROJ];

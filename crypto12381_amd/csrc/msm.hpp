@@ -1,0 +1,170 @@
+// Bucket-method (Pippenger) multi-scalar multiplication in G1 — the fast path behind c12381_g1_msm.
+// (The reference's Π[n](g[i]^x[i]) is n full scalar multiplications, g1_point.hpp:389-401; its bucket routine
+//  ECP_muln ecp_BLS12381.cpp:1112-1148 is exported but unused.  Only the final point is observable.)
+//
+// Every term is evaluated exactly as PAIR_G1mul does — [k mod x^2] P + [k div x^2] (-phi(P)) — so the sum equals
+// the reference's sum of multiply() results even for points outside the order-r subgroup.  Structure:
+//   prep     per point: parse, on-curve check, Montgomery form of P and of P' = (beta x, -y); per (half, window)
+//            one (key = window << c | digit, value = 2 i + half) entry, zero digits get the sentinel key
+//   sort     device radix sort of the entries by key (hipCUB)
+//   bucket   one lane per (window, digit): sum of its run of points with the complete MIXED addition
+//   wreduce  per window sum_d d B_d by running sums over chunks of buckets, chunk offset by double-and-add
+//   horner   sum_w 2^(c w) R_w
+#pragma once
+#include "g1.hpp"
+#include "codec.hpp"
+
+namespace c12381 {
+
+constexpr int MSM_PT_DWORDS = 2 * NL;          // affine (x, y) in Montgomery form, normalised limbs: 112 B, seven 16-byte words
+constexpr int MSM_CHUNK = 64;                  // buckets per lane in the window reduction
+
+C12381_HD int msm_window_bits(size_t n) {      // c ~ log2(2n) - 7, clamped
+    int lg = 0;
+    while (((size_t)2 << lg) <= 2 * n && lg < 40) ++lg;      // lg = floor(log2(2n))
+    int c = lg - 7;
+    return c < 4 ? 4 : (c > 16 ? 16 : c);
+}
+C12381_HD int msm_windows(int c) { return (128 + c - 1) / c; }
+
+// P + Q for an AFFINE Q = (qx, qy) that is not the point at infinity (Renes-Costello-Batina algorithm 8, a = 0):
+// 11 products, 8 reductions.  P limb bound <= 2^29, Q normalised.
+C12381_HD void g1_add_affine(g1p& p, const fp& qx, const fp& qy) {
+    fp t0, t1, t2, t3, t4, y3, z3;
+    fp_mul(t0, p.x, qx);
+    fp_mul(t1, p.y, qy);
+    fp_add(t3, qx, qy); fp_add(t4, p.x, p.y); fp_mul(t3, t3, t4);
+    fp_add(t4, t0, t1); fp_sub(t3, t3, t4); fp_norm1(t3, t3);                 // X1 Y2 + X2 Y1
+    fp_mul(t4, qy, p.z); fp_add(t4, t4, p.y); fp_norm1(t4, t4);               // Y2 Z1 + Y1
+    fp_mul(y3, qx, p.z); fp_add(y3, y3, p.x);                                 // X2 Z1 + X1
+    fp_mul_small(t0, t0, 3);
+    fp_mul_small(t2, p.z, 12);                                                // b3 Z1
+    fp_add(z3, t1, t2); fp_sub(t1, t1, t2);
+    fp_mul_small(y3, y3, 12);
+    fp_mul2<true>(p.x, t3, t1, y3, t4);                                       // X3 = t3 t1 - y3 t4
+    fp_mul2<false>(p.y, y3, t0, t1, z3);                                      // Y3 = y3 t0 + t1 z3
+    fp_mul2<false>(p.z, z3, t4, t0, t3);                                      // Z3 = z3 t4 + t0 t3
+}
+
+C12381_HD void msm_store_pt(int32_t* dst, const fp& x, const fp& y) {
+    int32_t w[MSM_PT_DWORDS];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) { w[i] = x.l[i]; w[NL + i] = y.l[i]; }
+    q4* d = reinterpret_cast<q4*>(dst);
+#pragma unroll
+    for (int i = 0; i < MSM_PT_DWORDS / 4; ++i) { q4 t; t.v[0] = w[4 * i]; t.v[1] = w[4 * i + 1]; t.v[2] = w[4 * i + 2]; t.v[3] = w[4 * i + 3]; d[i] = t; }
+}
+C12381_HD void msm_load_pt(fp& x, fp& y, const int32_t* src) {
+    int32_t w[MSM_PT_DWORDS];
+    const q4* s = reinterpret_cast<const q4*>(src);
+#pragma unroll
+    for (int i = 0; i < MSM_PT_DWORDS / 4; ++i) { q4 t = s[i]; w[4 * i] = t.v[0]; w[4 * i + 1] = t.v[1]; w[4 * i + 2] = t.v[2]; w[4 * i + 3] = t.v[3]; }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) { x.l[i] = w[i]; y.l[i] = w[NL + i]; }
+    C12381_BOUNDS(x.lb = y.lb = 268435456.0 + 8.0; x.vb = y.vb = 2.0; check_actual(x, "msm_load_pt"); check_actual(y, "msm_load_pt");)
+}
+// c-bit digit of window w of a 128-bit value (4 little-endian words)
+C12381_HD uint32_t msm_digit(const uint32_t (&k)[4], int w, int c) {
+    const int bit = w * c;
+    const int wi = bit >> 5, sh = bit & 31;
+    uint64_t v = k[wi];
+    if (wi + 1 < 4) v |= (uint64_t)k[wi + 1] << 32;
+    uint32_t d = (uint32_t)(v >> sh);
+    if (c < 32) d &= (1u << c) - 1u;
+    if (bit + c > 128) d &= (1u << (128 - bit)) - 1u;
+    return d;
+}
+// prep: returns false if the point is not on the curve.  pts2 holds P at 2i and P' = (beta x, -y) at 2i+1.
+C12381_HD bool msm_prep_one(size_t i, size_t n, const uint32_t* raw_pt /*24 words*/, const uint32_t* raw_sc /*8 words*/, int c, int W,
+                            int32_t* pts2, uint32_t* keys, uint32_t* vals) {
+    fp px, py;
+    const bool inf = raw_all_zero(raw_pt, 24);
+    fp_from_raw48(px, raw_pt); fp_from_raw48(py, raw_pt + 12);
+    bool ok = true;
+    if (!inf) {
+        fp x2, x3, y2, four, rhs;
+        fp_sqr(x2, px); fp_mul(x3, x2, px);
+        fp_set_const(four, FP_FOUR);
+        fp_add(rhs, x3, four);
+        fp_sqr(y2, py);
+        ok = fp_equal(y2, rhs);
+    }
+    const bool usable = ok && !inf;
+    fp beta, bx, ny, nyn;
+    fp_set_const(beta, FP_BETA_A);
+    fp_mul(bx, px, beta);
+    fp_neg(ny, py);
+    fp_norm1(nyn, ny);
+    msm_store_pt(pts2 + (2 * i) * MSM_PT_DWORDS, px, py);
+    msm_store_pt(pts2 + (2 * i + 1) * MSM_PT_DWORDS, bx, nyn);
+    uint32_t k[8];
+    scalar_from_raw32(k, raw_sc);
+    scalar_mod_r(k);
+    uint32_t k0[4], k1[4];
+    scalar_glv_split(k0, k1, k);
+    const uint32_t none = (uint32_t)W << c;
+    for (int w = 0; w < W; ++w) {
+        const uint32_t d0 = msm_digit(k0, w, c), d1 = msm_digit(k1, w, c);
+        const size_t e0 = ((size_t)w) * n + i, e1 = ((size_t)(W + w)) * n + i;
+        keys[e0] = (usable && d0) ? (((uint32_t)w << c) | d0) : none; vals[e0] = (uint32_t)(2 * i);
+        keys[e1] = (usable && d1) ? (((uint32_t)w << c) | d1) : none; vals[e1] = (uint32_t)(2 * i + 1);
+    }
+    return ok;
+}
+// bucket: sum of the points whose (sorted) entries lie in [lo, hi)
+C12381_HD void msm_bucket_one(g1p& acc, size_t lo, size_t hi, const uint32_t* vals_sorted, const int32_t* pts2) {
+    g1_set_inf(acc);
+    for (size_t j = lo; j < hi; ++j) {
+        fp x, y;
+        msm_load_pt(x, y, pts2 + (size_t)vals_sorted[j] * MSM_PT_DWORDS);
+        g1_add_affine(acc, x, y);
+    }
+}
+// window reduction for the chunk of MSM_CHUNK consecutive digits starting at d0 (d0 multiple of MSM_CHUNK):
+//   sum_{j} (d0 + j) B_{d0+j} = [d0] S + sum_j j B_{d0+j},  S = sum_j B_{d0+j}
+// `bk` = this window's buckets as 44-dword records (digit-indexed), nb = 2^c
+C12381_HD void msm_wreduce_one(g1p& out, const int32_t* bk, uint32_t d0, uint32_t nb) {
+    g1p run, acc, b;
+    g1_set_inf(run); g1_set_inf(acc);
+    for (int j = MSM_CHUNK - 1; j >= 1; --j) {
+        const uint32_t d = d0 + (uint32_t)j;
+        if (d < nb) {                              // uniform across the wavefront except in the last chunk
+            tab_load_g1(b, bk + (size_t)d * G1_ENT_DWORDS);
+            g1_add(run, b);
+            g1p nn; g1_norm1(nn, run); run = nn;
+            g1_add(acc, run);
+            g1_norm1(nn, acc); acc = nn;
+        }
+    }
+    if (d0 < nb) { tab_load_g1(b, bk + (size_t)d0 * G1_ENT_DWORDS); g1_add(run, b); g1p nn; g1_norm1(nn, run); run = nn; }
+    // [d0] S by double-and-add (d0 < 2^16), selects instead of branches
+    g1p t, inf;
+    g1_set_inf(t); g1_set_inf(inf);
+    for (int bit = 15; bit >= 0; --bit) {
+        g1_dbl(t);
+        g1p s;
+        const bool on = (d0 >> bit) & 1u;
+        fp_select(s.x, on, run.x, inf.x); fp_select(s.y, on, run.y, inf.y); fp_select(s.z, on, run.z, inf.z);
+        g1p tn; g1_norm1(tn, t);
+        g1_add(tn, s);
+        t = tn;
+    }
+    g1p tn; g1_norm1(tn, t);
+    g1_add(tn, acc);
+    g1_norm1(out, tn);
+}
+// R = sum_w 2^(c w) R_w   (R_w given as limb-major SoA, element w)
+C12381_HD void msm_horner(g1p& acc, const int32_t* rw, size_t stride, int W, int c) {
+    soa_load_g1(acc, rw, stride, (size_t)(W - 1));
+    for (int w = W - 2; w >= 0; --w) {
+        for (int b = 0; b < c; ++b) g1_dbl(acc);
+        g1p q, nn;
+        soa_load_g1(q, rw, stride, (size_t)w);
+        g1_norm1(nn, acc);
+        g1_add(nn, q);
+        acc = nn;
+    }
+    g1p nn; g1_norm1(nn, acc); acc = nn;
+}
+
+}  // namespace c12381

@@ -310,3 +310,60 @@ extern "C" {
 int sim_pair3_batch(size_t n, const uint8_t* g1_96, const uint8_t* g2_192, uint8_t* gt576) { return run_tri3(n, g1_96, g2_192, nullptr, nullptr, gt576, 0); }
 int sim_pair3_eq_batch(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, uint8_t* ok) { return run_tri3(n, a1, a2, b1, b2, ok, 1); }
 }
+
+// ---------------------------------------------------------------- bucket-method MSM (msm.hpp), run sequentially
+#include <algorithm>
+#include "../../crypto12381_amd/csrc/msm.hpp"
+extern "C" int sim_g1_msm_pippenger(size_t n, const uint8_t* pts96, const uint8_t* scalars32, uint8_t* out, int fmt, int force_c) {
+    const int c = force_c > 0 ? force_c : msm_window_bits(n);
+    const int W = msm_windows(c);
+    const size_t E = (size_t)2 * n * W;
+    std::vector<int32_t> pts2v((size_t)2 * n * MSM_PT_DWORDS + 4);
+    int32_t* pts2 = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(pts2v.data()) + 15) & ~(uintptr_t)15);
+    std::vector<uint32_t> keys(E), vals(E);
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t rp[24], rs[8];
+        load_raw(rp, pts96 + 96 * i, 24); load_raw(rs, scalars32 + 32 * i, 8);
+        if (!msm_prep_one(i, n, rp, rs, c, W, pts2, keys.data(), vals.data())) return -3;
+    }
+    std::vector<size_t> order(E);
+    for (size_t j = 0; j < E; ++j) order[j] = j;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return keys[a] < keys[b]; });
+    std::vector<uint32_t> ks(E), vs(E);
+    for (size_t j = 0; j < E; ++j) { ks[j] = keys[order[j]]; vs[j] = vals[order[j]]; }
+    const size_t nb = (size_t)1 << c, nbk = nb * W;
+    std::vector<size_t> lo(nbk + 1, 0), hi(nbk + 1, 0);
+    for (size_t j = 0; j < E; ++j) { if (j == 0 || ks[j] != ks[j - 1]) lo[ks[j]] = j; if (j + 1 == E || ks[j + 1] != ks[j]) hi[ks[j]] = j + 1; }
+    std::vector<int32_t> bkv(nbk * G1_ENT_DWORDS + 4);
+    int32_t* bk = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(bkv.data()) + 15) & ~(uintptr_t)15);
+    for (size_t b = 0; b < nbk; ++b) {
+        g1p acc, nn;
+        msm_bucket_one(acc, lo[b], hi[b], vs.data(), pts2);
+        g1_norm1(nn, acc);
+        tab_store_g1(bk + b * G1_ENT_DWORDS, nn);
+    }
+    const size_t chunks = (nb + MSM_CHUNK - 1) / MSM_CHUNK;
+    std::vector<int32_t> rw((size_t)3 * NL * W);
+    for (int w = 0; w < W; ++w) {
+        g1p sum; g1_set_inf(sum);
+        for (size_t ch = 0; ch < chunks; ++ch) {
+            g1p part;
+            msm_wreduce_one(part, bk + (size_t)w * nb * G1_ENT_DWORDS, (uint32_t)(ch * MSM_CHUNK), (uint32_t)nb);
+            g1_add(sum, part);
+            g1p nn; g1_norm1(nn, sum); sum = nn;
+        }
+        soa_store_g1(rw.data(), (size_t)W, (size_t)w, sum);
+    }
+    g1p acc;
+    msm_horner(acc, rw.data(), (size_t)W, W, c);
+    if (g1_is_inf(acc)) { std::memset(out, 0, fmt); return 0; }
+    fp zn, zi, ax, ay;
+    fp_norm1(zn, acc.z);
+    fp_inv(zi, zn);
+    g1_to_affine(ax, ay, acc, zi);
+    uint32_t rx[12], ry[12];
+    fp_to_raw48(rx, ax); fp_to_raw48(ry, ay);
+    if (fmt == 96) { std::memcpy(out, rx, 48); std::memcpy(out + 48, ry, 48); }
+    else { out[0] = (uint8_t)(0x02 | fp_sign(ay)); std::memcpy(out + 1, rx, 48); }
+    return 0;
+}

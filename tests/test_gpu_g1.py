@@ -109,3 +109,23 @@ def test_points_outside_the_subgroup(ctx):
     g = golden("g2")
     pts, sc = cat(g["offsubgroup_points"]), cat(g["offsubgroup_scalars"])
     assert ctx.g2_mul(pts, sc, 192) == cat(g["offsubgroup_mul192"])
+
+
+def test_msm_bucket_method_vs_naive_and_oracle(ctx, oracle_port):
+    """The bucket-method MSM (>= 2^12 terms) against the oracle and against the n-scalar-muls path."""
+    n = 5000
+    g1 = bytes.fromhex(golden("g1")["generator"])
+    pts = ctx.g1_mul(g1 * n, scalars(611, n), 96)
+    pts = pts[:96 * 7] + bytes(96) + pts[96 * 8:]            # one point at infinity
+    sc = scalars(612, n, 1 << 256)
+    sc = (0).to_bytes(32, "big") + sc[32:]                   # one zero scalar
+    got = ctx.g1_msm(pts, sc, 96)
+    assert got == oracle_port.g1_msm(pts, sc, 96, 16)
+    # sum of the individual products (GPU) folded with unit scalars must agree too
+    prods = ctx.g1_mul(pts, sc, 96)
+    assert ctx.g1_msm(prods, (1).to_bytes(32, "big") * n, 96) == got
+    # off-subgroup points: every term must follow the reference's GLV evaluation
+    g = golden("g1")
+    off, osc = cat(g["offsubgroup_points"]), cat(g["offsubgroup_scalars"])
+    reps = 700
+    assert ctx.g1_msm(off * reps, osc * reps, 96) == oracle_port.g1_msm(off * reps, osc * reps, 96, 16)

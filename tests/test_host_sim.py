@@ -166,3 +166,25 @@ def test_sim_pairing_three_lanes(sim):
     ok = ctypes.create_string_buffer(m)
     assert sim.sim_pair3_eq_batch(sz(m), a1, a2, b1, b2, ok) == 0
     assert list(ok.raw[:m]) == g["eq"]
+
+
+def test_sim_msm_pippenger(sim, oracle_port):
+    """Bucket-method MSM of msm.hpp (device routines run sequentially, std::stable_sort instead of hipCUB)."""
+    g = golden("g1")
+    pts, sc = cat(g["points"]), cat(g["scalars"])
+    n = len(pts) // 96
+    for c in (4, 7, 16):
+        out = ctypes.create_string_buffer(49)
+        assert sim.sim_g1_msm_pippenger(sz(n), pts, sc, out, 49, c) == 0
+        assert out.raw.hex() == g["msm49"], c
+    pts, sc = cat(g["offsubgroup_points"]), cat(g["offsubgroup_scalars"])
+    out = ctypes.create_string_buffer(49)
+    assert sim.sim_g1_msm_pippenger(sz(6), pts, sc, out, 49, 5) == 0
+    assert out.raw.hex() == g["offsubgroup_msm49"]
+    m = 300
+    g1 = bytes.fromhex(g["generator"])
+    p = oracle_port.g1_mul(g1 * m, scalars(801, m), 96, 4)
+    k = scalars(802, m, 1 << 256)
+    out = ctypes.create_string_buffer(96)
+    assert sim.sim_g1_msm_pippenger(sz(m), p, k, out, 96, 0) == 0
+    assert out.raw == oracle_port.g1_msm(p, k, 96, 4)
