@@ -81,16 +81,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)          # one rank per GPU on the 8-GPU node; wraps only in single-GPU rehearsals
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
+    # RCCL ("nccl") over xGMI on the GPU node; C12381_BENCH_BACKEND=gloo lets the N>1 path be rehearsed on one GPU
+    backend = os.environ.get("C12381_BENCH_BACKEND", "nccl")
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     from crypto12381_amd import Context
-    ctx = Context(local_rank)
+    ctx = Context(dev_index)
     stream = torch.cuda.Stream(device=dev)          # the library's kernels run on this torch-owned HIP stream
     ctx.set_stream(stream.cuda_stream)
 
@@ -130,7 +138,7 @@ def main():
     if ctx.sync() != 0:
         raise SystemExit("bench: invalid input point reported by the kernels")
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -165,7 +173,7 @@ def main():
         pk_ms, pk_launches = ctx.profile_read(3)
         ctx.profile(False)
         if dist:
-            t = torch.tensor([pel], dtype=torch.float64, device=dev)
+            t = torch.tensor([pel], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             pel = float(t.item())
         pair = {"npair": npair, "steps": psteps, "elapsed": pel, "kernel_ms": pk_ms, "launches": pk_launches,
@@ -187,7 +195,7 @@ def main():
                 dist.barrier()
             el = time.perf_counter() - t_a
             if dist:
-                tt = torch.tensor([el], dtype=torch.float64, device=dev)
+                tt = torch.tensor([el], dtype=torch.float64, device=red_dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 el = float(tt.item())
             return el
