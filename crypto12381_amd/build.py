@@ -1,35 +1,57 @@
-"""Build the HIP shared library in-tree (crypto12381_amd/lib/libc12381_hip.so) for gfx950."""
+"""Build the HIP shared library in-tree (crypto12381_amd/lib/libc12381_hip.so) for gfx950.
+
+One hipcc compile per translation unit (csrc/*.hip, in parallel, objects cached under lib/obj/ by mtime of the
+sources they include), then one link."""
 from __future__ import annotations
 
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "csrc", "c12381_hip.hip")
+CSRC = os.path.join(HERE, "csrc")
+UNITS = ["c12381_hip.hip", "k_g1.hip", "k_g2gt.hip", "k_pair3.hip"]
 LIB = os.path.join(HERE, "lib", "libc12381_hip.so")
+OBJ = os.path.join(HERE, "lib", "obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["-O3", "--offload-arch=gfx950", "-shared", "-fPIC", "-std=c++17"]
+CFLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17"]
 
 
-def _sources():
-    d = os.path.join(HERE, "csrc")
-    return [os.path.join(d, f) for f in os.listdir(d) if f.endswith((".hip", ".hpp", ".h"))] + [
+def _headers():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))] + [
         os.path.join(os.path.dirname(HERE), "include", "c12381_hip.h")]
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB):
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(s) > t for s in _sources())
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def needs_build() -> bool:
+    return _stale(LIB, _headers() + [os.path.join(CSRC, u) for u in UNITS])
+
+
+def _compile(unit: str, force: bool, verbose: bool) -> str:
+    src = os.path.join(CSRC, unit)
+    obj = os.path.join(OBJ, unit[:-4] + ".o")
+    if force or _stale(obj, _headers() + [src]):
+        cmd = [HIPCC, *CFLAGS, "-c", "-o", obj, src]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return obj
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or needs_build():
-        os.makedirs(os.path.dirname(LIB), exist_ok=True)
-        cmd = [HIPCC, *FLAGS, "-o", LIB, SRC]
+        os.makedirs(OBJ, exist_ok=True)
+        with ThreadPoolExecutor(max_workers=len(UNITS)) as ex:
+            objs = list(ex.map(lambda u: _compile(u, force, verbose), UNITS))
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
         if verbose:
-            print(" ".join(cmd))
+            print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
     return LIB
 

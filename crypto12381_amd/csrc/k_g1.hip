@@ -1,0 +1,265 @@
+// Kernels of the Fp / G1 family (one element per lane):
+//   fp_op_kernel / fp_mulchain_kernel   Fp test + VALU-roofline hook
+//   g1_mul_kernel      bytes -> on-curve check -> GLV windowed [k]P -> projective SoA in HBM
+//   g1_add_kernel      complete addition of two affine inputs -> projective SoA
+//   g1_finish_kernel   Montgomery's simultaneous inversion over a strided chunk per lane,
+//                      affine conversion, canonical encoding (49 B / 96 B)
+//   g1_reduce_kernel   tree sum of projective points (MSM combine)
+//   msm_*_kernel       bucket-method MSM stages (msm.hpp)
+//   g1_decompress_kernel   49-byte -> 96-byte decoding with the reference's acceptance rules
+#include "kernels_common.hpp"
+#include "msm.hpp"
+
+using namespace c12381;
+
+namespace c12381 {
+
+__global__ void __launch_bounds__(BLOCK, 2) fp_op_kernel(int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint32_t raw[12];
+    fp x, y, r;
+    load_raw48(raw, a + 48 * i); fp_from_raw48(x, raw);
+    if (b) { load_raw48(raw, b + 48 * i); fp_from_raw48(y, raw); } else { fp_zero(y); }
+    switch (op) {
+        case 0: fp_mul(r, x, y); break;
+        case 1: fp_add(r, x, y); break;
+        case 2: fp_sub(r, x, y); break;
+        case 3: fp_sqr(r, x); break;
+        case 4: fp_neg(r, x); break;
+        default: fp_inv(r, x); break;
+    }
+    fp_to_raw48(raw, r);
+    store_raw48(out + 48 * i, raw);
+}
+
+__global__ void __launch_bounds__(BLOCK, 2) fp_mulchain_kernel(size_t n, int iters, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint32_t raw[12];
+    fp x, y;
+    load_raw48(raw, a + 48 * i); fp_from_raw48(x, raw);
+    load_raw48(raw, b + 48 * i); fp_from_raw48(y, raw);
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+        fp z;
+        fp_mul(z, x, y);
+        x = y; y = z;                 // x_{n+2} = x_n * x_{n+1}: both operands stay live
+    }
+    fp_to_raw48(raw, y);
+    store_raw48(out + 48 * i, raw);
+}
+
+// proj layout: coordinate-major, limb-major SoA: proj[(c*NL + limb) * stride + element]
+// pt_stride = 96 for per-lane points, 0 to broadcast one point to every lane (fixed-base columns of BBS+)
+__global__ void __launch_bounds__(BLOCK, 2) g1_mul_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab,
+                                                       int32_t* proj, size_t proj_stride, size_t proj_off, int* bad_flag) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    fp px, py;
+    bool inf, ok;
+    g1_parse96(px, py, inf, ok, pts + pt_stride * i);
+    uint32_t raw[8], k[8];
+    load_raw32(raw, scalars + 32 * i);
+    scalar_from_raw32(k, raw);
+    g1p acc;
+    g1_scalar_mul(acc, px, py, inf || !ok, k, tab + i * (size_t)G1_TAB_DWORDS);
+    if (!ok) {
+        *bad_flag = 1;
+        // poison: Z = 0, X = 1 marks "invalid" for the finish kernel
+        fp_one(acc.x); fp_zero(acc.y); fp_zero(acc.z);
+    }
+    g1p o;
+    g1_norm1(o, acc);
+    soa_store_g1(proj, proj_stride, proj_off + i, o);
+}
+
+__global__ void __launch_bounds__(BLOCK, 2) g1_add_kernel(size_t n, const uint8_t* a, const uint8_t* b, int32_t* proj, size_t proj_stride,
+                                                       int* bad_flag) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    g1p p, q, inf_pt;
+    bool ia, oa, ib, ob;
+    g1_parse96(p.x, p.y, ia, oa, a + 96 * i); fp_one(p.z);
+    g1_parse96(q.x, q.y, ib, ob, b + 96 * i); fp_one(q.z);
+    g1_set_inf(inf_pt);
+    fp_select(p.x, ia, inf_pt.x, p.x); fp_select(p.y, ia, inf_pt.y, p.y); fp_select(p.z, ia, inf_pt.z, p.z);
+    fp_select(q.x, ib, inf_pt.x, q.x); fp_select(q.y, ib, inf_pt.y, q.y); fp_select(q.z, ib, inf_pt.z, q.z);
+    g1_add(p, q);
+    if (!(oa && ob)) { *bad_flag = 1; fp_one(p.x); fp_zero(p.y); fp_zero(p.z); }
+    g1p o;
+    g1_norm1(o, p);
+    soa_store_g1(proj, proj_stride, i, o);
+}
+
+// Simultaneous inversion (Montgomery's trick) + affine + encode.  Lane t owns elements
+// t, t+T, t+2T, ... so every global access is coalesced across the wavefront.
+__global__ void __launch_bounds__(BLOCK, 2) g1_finish_kernel(size_t n, const int32_t* proj, size_t stride, int32_t* pref, uint8_t* out,
+                                                          int fmt, size_t T) {
+    const size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= T || t >= n) return;
+    const int32_t* zbase = proj + (size_t)2 * NL * stride;
+    fp run;
+    fp_one(run);
+    size_t last = t;
+#pragma unroll 1
+    for (size_t e = t; e < n; e += T) {
+        fp z, one;
+        soa_load_fp(z, zbase, stride, e);
+        fp_one(one);
+        const bool inf = fp_is_zero(z);
+        fp_select(z, inf, one, z);
+        fp_mul(run, run, z);
+        soa_store_fp(pref, stride, e, run);
+        last = e;
+    }
+    fp inv;
+    fp_inv(inv, run);
+#pragma unroll 1
+    for (size_t e = last;; e -= T) {
+        g1p p;
+        soa_load_g1(p, proj, stride, e);
+        fp one, prev, zinv;
+        fp_one(one);
+        const bool inf = fp_is_zero(p.z);
+        fp_select(p.z, inf, one, p.z);
+        if (e >= T + t) soa_load_fp(prev, pref, stride, e - T); else prev = one;
+        fp_mul(zinv, inv, prev);
+        fp_mul(inv, inv, p.z);
+        fp ax, ay;
+        g1_to_affine(ax, ay, p, zinv);
+        uint32_t rx[12], ry[12];
+        fp_to_raw48(rx, ax);
+        uint8_t* o = out + (size_t)fmt * e;
+        // X = 1 (Montgomery), Z = 0 marks an invalid input; X = 0, Z = 0 is the point at infinity
+        const bool invalid = inf && !fp_is_zero(p.x);
+        if (fmt == 96) {
+            fp_to_raw48(ry, ay);
+            if (inf) {
+#pragma unroll
+                for (int j = 0; j < 12; ++j) { rx[j] = invalid ? 0xffffffffu : 0u; ry[j] = invalid ? 0xffffffffu : 0u; }
+            }
+            store_raw48(o, rx); store_raw48(o + 48, ry);
+        } else {
+            uint8_t tag = (uint8_t)(0x02 | fp_sign(ay));
+            if (inf) {
+                tag = invalid ? 0xff : 0x00;
+#pragma unroll
+                for (int j = 0; j < 12; ++j) rx[j] = invalid ? 0xffffffffu : 0u;
+            }
+            o[0] = tag;
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                const uint32_t v = rx[j];
+                o[1 + 4 * j] = (uint8_t)v; o[2 + 4 * j] = (uint8_t)(v >> 8); o[3 + 4 * j] = (uint8_t)(v >> 16); o[4 + 4 * j] = (uint8_t)(v >> 24);
+            }
+        }
+        if (e < T + t) break;
+    }
+}
+
+// One reduction level: out[j] = sum over i = j, j+m, j+2m, ... < n of in[i]   (projective, complete adds)
+__global__ void __launch_bounds__(BLOCK, 2) g1_reduce_kernel(size_t n, const int32_t* in, size_t in_stride, size_t m, int32_t* outp,
+                                                          size_t out_stride) {
+    const size_t j = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= m) return;
+    g1p acc;
+    g1_set_inf(acc);
+#pragma unroll 1
+    for (size_t i = j; i < n; i += m) {
+        g1p q;
+        soa_load_g1(q, in, in_stride, i);
+        g1_add(acc, q);
+        g1p nn;
+        g1_norm1(nn, acc);
+        acc = nn;
+    }
+    soa_store_g1(outp, out_stride, j, acc);
+}
+
+// proj[i] += P for one affine point P broadcast to every lane (BBS+: the constant g1 term)
+__global__ void __launch_bounds__(BLOCK, 2) g1_add_const_kernel(size_t n, int32_t* proj, size_t stride, const uint8_t* pt96, int* bad_flag) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    g1p q, inf_pt, acc;
+    bool inf, ok;
+    g1_parse96(q.x, q.y, inf, ok, pt96); fp_one(q.z);
+    g1_set_inf(inf_pt);
+    fp_select(q.x, inf, inf_pt.x, q.x); fp_select(q.y, inf, inf_pt.y, q.y); fp_select(q.z, inf, inf_pt.z, q.z);
+    if (!ok) *bad_flag = 1;
+    soa_load_g1(acc, proj, stride, i);
+    g1_add(acc, q);
+    g1p o;
+    g1_norm1(o, acc);
+    soa_store_g1(proj, stride, i, o);
+}
+
+__global__ void __launch_bounds__(BLOCK, 2) msm_prep_kernel(size_t n, const uint8_t* pts, const uint8_t* scalars, int c, int W, int32_t* pts2,
+                                                         uint32_t* keys, uint32_t* vals, int* bad_flag) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint32_t rp[24], rs[8];
+    load_raw48(rp, pts + 96 * i); load_raw48(rp + 12, pts + 96 * i + 48);
+    load_raw32(rs, scalars + 32 * i);
+    if (!msm_prep_one(i, n, rp, rs, c, W, pts2, keys, vals)) *bad_flag = 1;
+}
+
+__global__ void __launch_bounds__(BLOCK, 2) msm_ranges_kernel(size_t E, const uint32_t* keys, uint32_t* lo, uint32_t* hi) {
+    const size_t j = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= E) return;
+    const uint32_t k = keys[j];
+    if (j == 0 || keys[j - 1] != k) lo[k] = (uint32_t)j;
+    if (j + 1 == E || keys[j + 1] != k) hi[k] = (uint32_t)(j + 1);
+}
+
+__global__ void __launch_bounds__(BLOCK, 2) msm_bucket_kernel(size_t nbk, const uint32_t* lo, const uint32_t* hi, const uint32_t* vals,
+                                                           const int32_t* pts2, int32_t* bk) {
+    const size_t b = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (b >= nbk) return;
+    g1p acc, nn;
+    msm_bucket_one(acc, lo[b], hi[b], vals, pts2);
+    g1_norm1(nn, acc);
+    tab_store_g1(bk + b * G1_ENT_DWORDS, nn);
+}
+
+__global__ void __launch_bounds__(BLOCK, 2) msm_wreduce_kernel(int W, uint32_t nb, uint32_t chunks, const int32_t* bk, int32_t* out, size_t out_stride) {
+    const size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= (size_t)W * chunks) return;
+    const uint32_t w = (uint32_t)(t / chunks), ch = (uint32_t)(t % chunks);
+    g1p part;
+    msm_wreduce_one(part, bk + (size_t)w * nb * G1_ENT_DWORDS, ch * MSM_CHUNK, nb);
+    soa_store_g1(out, out_stride, (size_t)ch * W + w, part);
+}
+
+// ECP_fromOctet ecp_BLS12381.cpp:495-545 for 49-byte input (tags 02/03; a leading 00 is infinity as in
+// g1_point.hpp:89-93); status 1 ok / 0 reject; rejected and infinity lanes give 96 zero bytes.
+__global__ void __launch_bounds__(BLOCK, 2) g1_decompress_kernel(size_t n, const uint8_t* in, uint8_t* out, uint8_t* status) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* sp = in + 49 * i;
+    const uint8_t tag = sp[0];
+    uint32_t raw[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) raw[j] = (uint32_t)sp[1 + 4 * j] | ((uint32_t)sp[2 + 4 * j] << 8) | ((uint32_t)sp[3 + 4 * j] << 16) | ((uint32_t)sp[4 + 4 * j] << 24);
+    fp x, y;
+    fp_from_raw48(x, raw);
+    const bool ok_tag = tag == 2 || tag == 3;
+    const bool ok = g1_set_x(y, x, tag & 1) && ok_tag;
+    uint32_t rx[12], ry[12];
+    fp_to_raw48(rx, x); fp_to_raw48(ry, y);
+    if (!ok) {
+#pragma unroll
+        for (int j = 0; j < 12; ++j) { rx[j] = 0; ry[j] = 0; }
+    }
+    store_raw48(out + 96 * i, rx); store_raw48(out + 96 * i + 48, ry);
+    status[i] = tag == 0 ? 1 : (ok ? 1 : 0);
+}
+
+__global__ void __launch_bounds__(64, 1) msm_horner_kernel(const int32_t* rw, size_t stride, int W, int c, int32_t* out, size_t out_stride) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    g1p acc;
+    msm_horner(acc, rw, stride, W, c);
+    soa_store_g1(out, out_stride, 0, acc);
+}
+
+}  // namespace c12381

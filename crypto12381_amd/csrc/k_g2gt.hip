@@ -1,0 +1,131 @@
+// Kernels of the G2 / GT family, one element per lane:
+//   g2_mul_kernel      bytes -> on-twist check -> windowed [k]Q -> affine -> 97 B / 192 B
+//   g2_add_kernel      complete addition of two affine G2 inputs
+//   g2_decompress_kernel
+//   pair_kernel        Miller loop + final exponentiation -> 576-byte GT (one-lane variant, see k_pair3.hip)
+//   pair_eq_kernel     e(a1,a2) == e(b1,b2): two Miller loops, ONE final exponentiation, is-unity
+//   miller_kernel / gt_op_kernel / gt_is_unity_kernel   the GTMiller and GT operators of the reference
+#include "kernels_common.hpp"
+
+using namespace c12381;
+
+namespace c12381 {
+
+__global__ void __launch_bounds__(BLOCK, 2) g2_mul_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab,
+                                                       size_t tab_stride, uint8_t* out, int fmt, int* bad_flag) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    fp2 qx, qy;
+    bool inf, ok;
+    g2_parse192(qx, qy, inf, ok, pts + pt_stride * i);
+    uint32_t raw[8], k[8];
+    load_raw32(raw, scalars + 32 * i);
+    scalar_from_raw32(k, raw);
+    g2p acc;
+    g2_scalar_mul(acc, qx, qy, inf || !ok, k, tab + i * (size_t)G2_TAB_DWORDS);
+    if (!ok) *bad_flag = 1;
+    g2_store_affine(out + (size_t)fmt * i, acc, fmt, !ok);
+}
+
+__global__ void __launch_bounds__(BLOCK, 2) g2_add_kernel(size_t n, const uint8_t* a, size_t a_stride, const uint8_t* b, uint8_t* out, int fmt,
+                                                       int* bad_flag) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    g2p p, q, inf_pt;
+    bool ia, oa, ib, ob;
+    g2_parse192(p.x, p.y, ia, oa, a + a_stride * i); fp2_one(p.z);
+    g2_parse192(q.x, q.y, ib, ob, b + 192 * i); fp2_one(q.z);
+    g2_set_inf(inf_pt);
+    fp2_select(p.x, ia, inf_pt.x, p.x); fp2_select(p.y, ia, inf_pt.y, p.y); fp2_select(p.z, ia, inf_pt.z, p.z);
+    fp2_select(q.x, ib, inf_pt.x, q.x); fp2_select(q.y, ib, inf_pt.y, q.y); fp2_select(q.z, ib, inf_pt.z, q.z);
+    g2_add(p, q);
+    const bool ok = oa && ob;
+    if (!ok) *bad_flag = 1;
+    g2_store_affine(out + (size_t)fmt * i, p, fmt, !ok);
+}
+
+__global__ void __launch_bounds__(BLOCK, 2) pair_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    fp px, py; fp2 qx, qy; bool pinf, qinf, ok;
+    pair_inputs(px, py, pinf, qx, qy, qinf, ok, g1 + 96 * i, g2 + 192 * i);
+    if (!ok) { *bad_flag = 1; pinf = true; qinf = true; }
+    fp12 f;
+    miller_loop(f, px, py, pinf, qx, qy, qinf);
+    final_exp(f);
+    gt_store576(gt + 576 * i, f, !ok);
+}
+
+__global__ void __launch_bounds__(BLOCK, 2) pair_eq_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2,
+                                                        size_t b2_stride, uint8_t* out, int* bad_flag) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    fp px, py; fp2 qx, qy; bool pinf, qinf, ok, okb;
+    fp12 f, g, t;
+    pair_inputs(px, py, pinf, qx, qy, qinf, ok, a1 + 96 * i, a2 + 192 * i);
+    if (!ok) { pinf = true; qinf = true; }
+    miller_loop(f, px, py, pinf, qx, qy, qinf);
+    pair_inputs(px, py, pinf, qx, qy, qinf, okb, b1 + 96 * i, b2 + b2_stride * i);
+    if (!okb) { pinf = true; qinf = true; }
+    miller_loop(g, px, py, pinf, qx, qy, qinf);
+    fp12_conj(t, g);
+    fp12_mul(g, f, t);
+    final_exp(g);
+    const bool valid = ok && okb;
+    if (!valid) *bad_flag = 1;
+    out[i] = valid ? (fp12_is_one(g) ? 1 : 0) : 0xff;
+}
+
+// ECP2_fromOctet ecp2_BLS12381.cpp:225-266 for 97-byte input: any tag other than 04 is "compressed, sign = tag & 1"
+__global__ void __launch_bounds__(BLOCK, 2) g2_decompress_kernel(size_t n, const uint8_t* in, uint8_t* out, uint8_t* status) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* sp = in + 97 * i;
+    const uint8_t tag = sp[0];
+    uint32_t raw[24];
+#pragma unroll
+    for (int j = 0; j < 24; ++j) raw[j] = (uint32_t)sp[1 + 4 * j] | ((uint32_t)sp[2 + 4 * j] << 8) | ((uint32_t)sp[3 + 4 * j] << 16) | ((uint32_t)sp[4 + 4 * j] << 24);
+    fp2 x, y;
+    fp_from_raw48(x.b, raw); fp_from_raw48(x.a, raw + 12);
+    const bool ok = g2_set_x(y, x, tag & 1) && tag != 0 && tag != 4;
+    uint8_t* o = out + 192 * i;
+    if (ok) { fp2_store_raw96(o, x); fp2_store_raw96(o + 96, y); }
+    else { uint4* q = reinterpret_cast<uint4*>(o); for (int j = 0; j < 12; ++j) q[j] = make_uint4(0, 0, 0, 0); }
+    status[i] = tag == 0 ? 1 : (ok ? 1 : 0);
+}
+
+// pair_ate alone: the Miller value as FP12_toOctet bytes (the same field element as the reference's)
+__global__ void __launch_bounds__(BLOCK, 2) miller_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* out, int* bad_flag) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    fp px, py; fp2 qx, qy; bool pinf, qinf, ok;
+    pair_inputs(px, py, pinf, qx, qy, qinf, ok, g1 + 96 * i, g2 + 192 * i);
+    if (!ok) { *bad_flag = 1; pinf = true; qinf = true; }
+    fp12 f;
+    miller_loop(f, px, py, pinf, qx, qy, qinf);
+    gt_store576(out + 576 * i, f, !ok);
+}
+
+// op 0: a*b (FP12_mul), 1: conj(a), 2: a^e (FP12_pow, e = 32-byte exponent used as given), 3: final exponentiation
+__global__ void __launch_bounds__(BLOCK, 2) gt_op_kernel(int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    fp12 x, r;
+    gt_load576(x, a + 576 * i);
+    if (op == 0) { fp12 y; gt_load576(y, b + 576 * i); fp12_mul(r, x, y); }
+    else if (op == 1) { fp12_conj(r, x); }
+    else if (op == 2) { uint32_t raw[8], e[8]; load_raw32(raw, b + 32 * i); scalar_from_raw32(e, raw); fp12_pow_generic(r, x, e); }
+    else { r = x; final_exp(r); }
+    gt_store576(out + 576 * i, r, false);
+}
+
+// FP12_isunity per element
+__global__ void __launch_bounds__(BLOCK, 2) gt_is_unity_kernel(size_t n, const uint8_t* a, uint8_t* out) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    fp12 x;
+    gt_load576(x, a + 576 * i);
+    out[i] = fp12_is_one(x) ? 1 : 0;
+}
+
+}  // namespace c12381
