@@ -60,6 +60,15 @@ def load_library() -> ctypes.CDLL:
         lib.c12381_fexp_batch.argtypes = [vp, sz, vp, vp]
         lib.c12381_gt_op_batch.argtypes = [vp, ci, sz, vp, vp, vp]
         lib.c12381_gt_is_unity_batch.argtypes = [vp, sz, vp, vp]
+        for name in ("c12381_g1_from_hash_batch", "c12381_g1_from_hash_batch_dev"):
+            getattr(lib, name).argtypes = [vp, sz, vp, vp, ci]
+        lib.c12381_g1_map_to_point_batch.argtypes = [vp, sz, vp, vp]
+        lib.c12381_g1_clear_cofactor_batch.argtypes = [vp, sz, vp, vp]
+        for name in ("c12381_zp_op_batch", "c12381_zp_op_batch_dev"):
+            getattr(lib, name).argtypes = [vp, ci, sz, vp, vp, vp]
+        lib.c12381_zp_from_hash_batch.argtypes = [vp, sz, vp, vp]
+        for name in ("c12381_zp_inner_product", "c12381_zp_inner_product_dev"):
+            getattr(lib, name).argtypes = [vp, sz, vp, vp, vp]
         for name in ("c12381_bbs_plus_verify_batch", "c12381_bbs_plus_verify_batch_dev"):
             getattr(lib, name).argtypes = [vp, sz, sz] + [vp] * 10
         _lib = lib
@@ -180,6 +189,44 @@ class Context:
         out, st = ctypes.create_string_buffer(max(192 * n, 1)), ctypes.create_string_buffer(max(n, 1))
         self._ck(self.lib.c12381_g2_decompress_batch(self.h, n, _p(c), _p(out), _p(st)))
         return out.raw[:192 * n], st.raw[:n]
+
+    def g1_from_hash(self, digests: bytes, fmt: int = 96) -> bytes:
+        n = len(digests) // 64
+        out = ctypes.create_string_buffer(max(fmt * n, 1))
+        self._ck(self.lib.c12381_g1_from_hash_batch(self.h, n, _p(digests), _p(out), fmt))
+        return out.raw[:fmt * n]
+
+    def g1_map_to_point(self, u48: bytes) -> bytes:
+        n = len(u48) // 48
+        out = ctypes.create_string_buffer(max(96 * n, 1))
+        self._ck(self.lib.c12381_g1_map_to_point_batch(self.h, n, _p(u48), _p(out)))
+        return out.raw[:96 * n]
+
+    def g1_clear_cofactor(self, pts: bytes, strict: bool = True) -> bytes:
+        n = len(pts) // 96
+        out = ctypes.create_string_buffer(max(96 * n, 1))
+        self._ck(self.lib.c12381_g1_clear_cofactor_batch(self.h, n, _p(pts), _p(out)), allow_point=not strict)
+        return out.raw[:96 * n]
+
+    ZP_OPS = {"mul": 0, "add": 1, "sub": 2, "neg": 3, "inv": 4}
+
+    def zp_op(self, op: str, a: bytes, b: bytes | None = None) -> bytes:
+        n = len(a) // 32
+        out = ctypes.create_string_buffer(max(32 * n, 1))
+        self._ck(self.lib.c12381_zp_op_batch(self.h, self.ZP_OPS[op], n, _p(a), _p(b), _p(out)))
+        return out.raw[:32 * n]
+
+    def zp_from_hash(self, digests: bytes) -> bytes:
+        n = len(digests) // 64
+        out = ctypes.create_string_buffer(max(32 * n, 1))
+        self._ck(self.lib.c12381_zp_from_hash_batch(self.h, n, _p(digests), _p(out)))
+        return out.raw[:32 * n]
+
+    def zp_inner_product(self, a: bytes, b: bytes | None = None) -> bytes:
+        n = len(a) // 32
+        out = ctypes.create_string_buffer(32)
+        self._ck(self.lib.c12381_zp_inner_product(self.h, n, _p(a), _p(b), _p(out)))
+        return out.raw
 
     def miller(self, g1: bytes, g2: bytes) -> bytes:
         n = len(g1) // 96

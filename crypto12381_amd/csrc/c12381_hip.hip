@@ -486,6 +486,119 @@ int c12381_g1_decompress_batch(c12381_ctx* c, size_t n, const uint8_t* in49, uin
     HIPCK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
+// ---------------------------------------------------------------- hash-to-G1, Zp helpers
+static int g1_map_common(c12381_ctx* c, size_t n, const uint8_t* d_in, int mode, uint8_t* d_out, int fmt) {
+    const size_t stride = round_up(n, 64);
+    int rc;
+    if ((rc = ensure(c, c12381_ctx::WS_PROJ, (size_t)3 * NL * stride * 4))) return rc;
+    hipLaunchKernelGGL(g1_from_hash_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, d_in, mode, (int32_t*)c->ws[c12381_ctx::WS_PROJ], stride,
+                       c->d_flag);
+    HIPCK(c, hipGetLastError());
+    return g1_finish(c, n, (const int32_t*)c->ws[c12381_ctx::WS_PROJ], stride, d_out, fmt);
+}
+int c12381_g1_from_hash_batch_dev(c12381_ctx* c, size_t n, const uint8_t* digests, uint8_t* out, int fmt) {
+    int rc = bind(c); if (rc) return rc;
+    if (!digests || !out || (fmt != 49 && fmt != 96)) return C12381_E_ARG;
+    if (n == 0) return 0;
+    return g1_map_common(c, n, digests, 0, out, fmt);
+}
+int c12381_g1_from_hash_batch(c12381_ctx* c, size_t n, const uint8_t* digests, uint8_t* out, int fmt) {
+    int rc = bind(c); if (rc) return rc;
+    if (!digests || !out || (fmt != 49 && fmt != 96)) return C12381_E_ARG;
+    if (n == 0) return 0;
+    staged s;
+    if ((rc = stage_in(c, s, digests, 64 * n, nullptr, 0, (size_t)fmt * n))) return rc;
+    if ((rc = g1_map_common(c, n, s.in0, 0, s.out, fmt))) return rc;
+    if ((rc = stage_out(c, s, out, (size_t)fmt * n))) return rc;
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int c12381_g1_map_to_point_batch(c12381_ctx* c, size_t n, const uint8_t* u48, uint8_t* out96) {
+    int rc = bind(c); if (rc) return rc;
+    if (!u48 || !out96) return C12381_E_ARG;
+    if (n == 0) return 0;
+    staged s;
+    if ((rc = stage_in(c, s, u48, 48 * n, nullptr, 0, 96 * n))) return rc;
+    if ((rc = g1_map_common(c, n, s.in0, 1, s.out, 96))) return rc;
+    if ((rc = stage_out(c, s, out96, 96 * n))) return rc;
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int c12381_g1_clear_cofactor_batch(c12381_ctx* c, size_t n, const uint8_t* in96, uint8_t* out96) {
+    int rc = bind(c); if (rc) return rc;
+    if (!in96 || !out96) return C12381_E_ARG;
+    if (n == 0) return 0;
+    staged s;
+    if ((rc = stage_in(c, s, in96, 96 * n, nullptr, 0, 96 * n))) return rc;
+    if ((rc = g1_map_common(c, n, s.in0, 2, s.out, 96))) return rc;
+    if ((rc = stage_out(c, s, out96, 96 * n))) return rc;
+    return read_flag(c);
+}
+int c12381_zp_op_batch_dev(c12381_ctx* c, int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    int rc = bind(c); if (rc) return rc;
+    if (op < 0 || op > 4 || !a || !out || (op <= 2 && !b)) return C12381_E_ARG;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(zp_op_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, op, n, a, op <= 2 ? b : nullptr, out);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+int c12381_zp_op_batch(c12381_ctx* c, int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    int rc = bind(c); if (rc) return rc;
+    if (op < 0 || op > 4 || !a || !out || (op <= 2 && !b)) return C12381_E_ARG;
+    if (n == 0) return 0;
+    staged s;
+    if ((rc = stage_in(c, s, a, 32 * n, op <= 2 ? b : nullptr, op <= 2 ? 32 * n : 0, 32 * n))) return rc;
+    if ((rc = c12381_zp_op_batch_dev(c, op, n, s.in0, s.in1, s.out))) return rc;
+    if ((rc = stage_out(c, s, out, 32 * n))) return rc;
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int c12381_zp_from_hash_batch(c12381_ctx* c, size_t n, const uint8_t* digests, uint8_t* out) {
+    int rc = bind(c); if (rc) return rc;
+    if (!digests || !out) return C12381_E_ARG;
+    if (n == 0) return 0;
+    staged s;
+    if ((rc = stage_in(c, s, digests, 64 * n, nullptr, 0, 32 * n))) return rc;
+    hipLaunchKernelGGL(zp_from_hash_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, s.in0, s.out);
+    HIPCK(c, hipGetLastError());
+    if ((rc = stage_out(c, s, out, 32 * n))) return rc;
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+// strided partial sums, 64 terms per lane and stage, ping-pong between two reduction slots
+int c12381_zp_inner_product_dev(c12381_ctx* c, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    int rc = bind(c); if (rc) return rc;
+    if (!out || (n && !a)) return C12381_E_ARG;
+    if (n == 0) { HIPCK(c, hipMemsetAsync(out, 0, 32, c->stream)); return 0; }
+    const uint8_t *cur_a = a, *cur_b = b;
+    size_t cur_n = n;
+    int slot = c12381_ctx::WS_RED0;
+    for (;;) {
+        const size_t T = (cur_n + 63) / 64;
+        uint8_t* dst = out;
+        if (T > 1) {
+            if ((rc = ensure(c, slot, round_up(32 * T, 256)))) return rc;
+            dst = (uint8_t*)c->ws[slot];
+        }
+        hipLaunchKernelGGL(zp_fold_kernel, dim3(grid_for(T)), dim3(BLOCK), 0, c->stream, cur_n, cur_a, cur_b, T, dst);
+        HIPCK(c, hipGetLastError());
+        if (T == 1) return 0;
+        cur_a = dst; cur_b = nullptr; cur_n = T;
+        slot = slot == c12381_ctx::WS_RED0 ? c12381_ctx::WS_RED1 : c12381_ctx::WS_RED0;
+    }
+}
+int c12381_zp_inner_product(c12381_ctx* c, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    int rc = bind(c); if (rc) return rc;
+    if (!out || (n && !a)) return C12381_E_ARG;
+    if (n == 0) { std::memset(out, 0, 32); return 0; }
+    staged s;
+    if ((rc = stage_in(c, s, a, 32 * n, b, b ? 32 * n : 0, 32))) return rc;
+    if ((rc = c12381_zp_inner_product_dev(c, n, s.in0, b ? s.in1 : nullptr, s.out))) return rc;
+    if ((rc = stage_out(c, s, out, 32))) return rc;
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int c12381_g2_decompress_batch(c12381_ctx* c, size_t n, const uint8_t* in97, uint8_t* out192, uint8_t* status) {
     int rc = bind(c); if (rc) return rc;
     if (!in97 || !out192 || !status) return C12381_E_ARG;

@@ -206,6 +206,51 @@ C12381_HD void g1_add_digit(g1p& acc, const int32_t* lane_tab, int d, bool endo)
     }
 }
 
+// p <- [|x|]p, plain double-and-add over the 64-bit curve parameter (weight 6)
+C12381_HDN void g1_mul_absx(g1p& p) {
+    g1p base, acc;
+    g1_norm1(base, p);
+    acc = base;
+#pragma unroll 1
+    for (int i = 62; i >= 0; --i) {
+        g1_dbl(acc);
+        if ((BLS_X_W[i >> 5] >> (i & 31)) & 1u) g1_add(acc, base);
+    }
+    p = acc;
+}
+// The reference's glv() (pair_BLS12381.cpp:793-805) returns u1 = r - (k div x^2), and PAIR_G1mul's sign minimisation
+// (:899-906) maps that back to k div x^2 — except when k div x^2 == 0: then u1 stays r and ECP_mul2 adds [r]phi(P),
+// phi(P) = (beta x, y).  That term is the point at infinity for P in G1 and a point of the cofactor part otherwise.
+// Reproduced here (lanes with k < x^2 only, a divergent branch) so results agree with `multiply` on every curve point.
+// phi(P) is in G1 iff phi(phi(P)) = [-x^2]phi(P); off the subgroup [r]Q = [x^2]([x^2]Q) - [x^2]Q + Q  (r = x^4 - x^2 + 1).
+C12381_HDN void g1_glv_small_scalar_term(g1p& acc, const g1p& base) {
+    fp beta;
+    fp_set_const(beta, FP_BETA_A);
+    g1p q, s1, t;
+    fp_mul(q.x, base.x, beta); q.y = base.y; q.z = base.z;            // phi(P)
+    g1_norm1(q, q);
+    s1 = q;
+    g1_mul_absx(s1); g1_mul_absx(s1);                                  // [x^2]phi(P)
+    g1_norm1(s1, s1);
+    fp_mul(t.x, q.x, beta); t.y = q.y; t.z = q.z;                      // phi(phi(P))
+    g1_norm1(t, t);
+    {
+        g1p u = s1;
+        g1_add(u, t);
+        if (g1_is_inf(u)) return;                                      // P in G1: the extra term vanishes
+    }
+    g1p s2 = s1;
+    g1_mul_absx(s2); g1_mul_absx(s2);                                  // [x^4]phi(P)
+    fp_neg(t.y, s1.y); t.x = s1.x; t.z = s1.z;
+    g1_norm1(t, t);
+    g1_add(s2, t);
+    g1_norm1(s2, s2);
+    g1_add(s2, q);
+    g1_norm1(s2, s2);
+    g1_norm1(acc, acc);
+    g1_add(acc, s2);
+}
+
 // [k]P for an AFFINE input point (x, y) or infinity.  `lane_tab` = this lane's 1408-byte table record.
 C12381_HD void g1_scalar_mul(g1p& acc, const fp& px, const fp& py, bool p_is_inf, const uint32_t (&kin)[8], int32_t* lane_tab) {
     uint32_t k[8];
@@ -252,6 +297,7 @@ C12381_HD void g1_scalar_mul(g1p& acc, const fp& px, const fp& py, bool p_is_inf
         g1_add_digit(acc, lane_tab, glv_digit(kb0, w), false);
         g1_add_digit(acc, lane_tab, glv_digit(kb1, w), true);
     }
+    if ((k1[0] | k1[1] | k1[2] | k1[3]) == 0u) g1_glv_small_scalar_term(acc, base);
 }
 
 // ------------------------------------------------------------------ affine output

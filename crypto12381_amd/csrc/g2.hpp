@@ -187,6 +187,53 @@ C12381_HD void g2_add_digit(g2p& acc, const int32_t* lane_tab, int d) {
     g2_add(acc, e);
 }
 
+C12381_HD bool g2_is_inf(const g2p& p) { return fp2_is_zero(p.z); }
+// p <- [|x|]p, plain double-and-add over the 64-bit curve parameter
+C12381_HDN void g2_mul_absx(g2p& p) {
+    g2p base, acc;
+    g2_norm1(base, p);
+    acc = base;
+#pragma unroll 1
+    for (int i = 62; i >= 0; --i) {
+        g2_dbl(acc);
+        if ((BLS_X_W[i >> 5] >> (i & 31)) & 1u) g2_add(acc, base);
+    }
+    p = acc;
+}
+// gs() negates the odd digits mod r (pair_BLS12381.cpp:868-871) and BIG_modneg(0) = r; PAIR_G2mul's sign minimisation
+// (:962-971) undoes the negation for non-zero digits only, so a ZERO odd digit u_i makes ECP2_mul4 add [r]psi^i(Q):
+// infinity for Q in G2, a point of the cofactor part otherwise.  Reproduced here (lanes with u1 == 0 or u3 == 0 only,
+// a divergent branch) so results agree with `multiply` on every point of the twist.
+// Q is in G2 iff psi(Q) = [x]Q = -[|x|]Q; off the subgroup [r]Q = [x^4]Q - [x^2]Q + Q and [r]psi^i(Q) = psi^i([r]Q).
+C12381_HDN void g2_gs_zero_digit_terms(g2p& acc, const g2p& base, bool z1, bool z3) {
+    g2p q, a1, a2, a4, t;
+    g2_norm1(q, base);
+    a1 = q;
+    g2_mul_absx(a1);
+    g2_norm1(a1, a1);
+    g2_psi<1>(t, q);
+    g2_norm1(t, t);
+    {
+        g2p u = a1;
+        g2_add(u, t);
+        if (g2_is_inf(u)) return;                  // Q in G2: the extra terms vanish
+    }
+    a2 = a1;
+    g2_mul_absx(a2);
+    g2_norm1(a2, a2);
+    a4 = a2;
+    g2_mul_absx(a4); g2_mul_absx(a4);
+    g2_neg(t, a2);
+    g2_norm1(t, t);
+    g2_add(a4, t);
+    g2_norm1(a4, a4);
+    g2_add(a4, q);
+    g2_norm1(a4, a4);                              // [r]Q
+    g2_norm1(acc, acc);
+    if (z1) { g2_psi<1>(t, a4); g2_norm1(t, t); g2_add(acc, t); g2_norm1(acc, acc); }
+    if (z3) { g2_psi<3>(t, a4); g2_norm1(t, t); g2_add(acc, t); }
+}
+
 // PAIR_G2mul pair_BLS12381.cpp:927-983: R = u0 Q - u1 psi(Q) + u2 psi^2(Q) - u3 psi^3(Q) for the base-|x| digits of
 // k mod r — exactly what the reference evaluates (ECP2_mul4 after gs() and the sign minimisation), on ANY point of
 // the twist; for Q in G2 it equals [k]Q.  64 doublings + 68 additions on one 8-entry table of multiples of Q.
@@ -231,6 +278,8 @@ C12381_HDN void g2_scalar_mul(g2p& acc, const fp2& qx, const fp2& qy, bool q_is_
         g2_add_digit<2>(acc, lane_tab, gs_digit(ub[2], w));
         g2_add_digit<3>(acc, lane_tab, gs_digit(ub[3], w));
     }
+    const bool z1 = (u[1][0] | u[1][1]) == 0u, z3 = (u[3][0] | u[3][1]) == 0u;
+    if (z1 || z3) g2_gs_zero_digit_terms(acc, base, z1, z3);
 }
 
 // ECP2_setx ecp2_BLS12381.cpp:322-344: y = sqrt(x^3 + 4(1+i)) with FP2_sign(y) == s.

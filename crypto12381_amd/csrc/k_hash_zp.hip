@@ -1,0 +1,115 @@
+// Kernels either side of the point arithmetic, one element per lane:
+//   g1_from_hash_kernel   64-byte digest -> point of G1, or field element -> point of E (h2c.hpp); projective SoA
+//                         for g1_finish_kernel
+//   zp_op_kernel          scalar-field mul / add / sub / neg / inverse on canonical 32-byte values (fr.hpp)
+//   zp_from_hash_kernel   64-byte digest -> scalar mod r
+//   zp_fold_kernel        strided partial sums of a[i] * b[i] (or of a[i]) mod r: inner products and sums
+#include "kernels_common.hpp"
+#include "fr.hpp"
+#include "h2c.hpp"
+
+using namespace c12381;
+
+namespace {
+
+__device__ __forceinline__ void store_raw32(uint8_t* p, const uint32_t* w) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+__device__ __forceinline__ void fr_load32(fr& r, const uint8_t* p) {
+    uint32_t raw[8], k[8];
+    load_raw32(raw, p);
+    scalar_from_raw32(k, raw);
+    fr_from_words(r, k);
+}
+__device__ __forceinline__ void fr_store32(uint8_t* p, const fr& a) {
+    uint32_t k[8], raw[8];
+    fr_to_words(k, a);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) raw[i] = bswap32(k[7 - i]);
+    store_raw32(p, raw);
+}
+
+}  // namespace
+
+namespace c12381 {
+
+// mode 0: 64-byte digests -> from_hash (map + cofactor);  mode 1: 48-byte field elements -> map_to_point only;
+// mode 2: 96-byte affine points -> multiply_cofactor only
+__global__ void __launch_bounds__(BLOCK, 2) g1_from_hash_kernel(size_t n, const uint8_t* in, int mode, int32_t* proj, size_t proj_stride,
+                                                             int* bad_flag) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    g1p p, o;
+    if (mode == 0) {
+        uint32_t raw[16];
+        load_raw32(raw, in + 64 * i);
+        load_raw32(raw + 8, in + 64 * i + 32);
+        g1_from_digest(p, raw);
+    } else if (mode == 1) {
+        uint32_t raw[12];
+        fp u;
+        load_raw48(raw, in + 48 * i);
+        fp_from_raw48(u, raw);
+        g1_map_to_point(p, u);
+    } else {
+        bool inf, ok;
+        g1_parse96(p.x, p.y, inf, ok, in + 96 * i);
+        fp_one(p.z);
+        if (inf) g1_set_inf(p);
+        g1_clear_cofactor(p);
+        if (!ok) { *bad_flag = 1; fp_one(p.x); fp_zero(p.y); fp_zero(p.z); }      // poison, as g1_mul_kernel does
+    }
+    g1_norm1(o, p);
+    soa_store_g1(proj, proj_stride, i, o);
+}
+
+// op: 0 mul, 1 add, 2 sub, 3 neg, 4 inverse (0 -> 0)
+__global__ void __launch_bounds__(BLOCK, 2) zp_op_kernel(int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    fr x, y, r;
+    fr_load32(x, a + 32 * i);
+    if (b) fr_load32(y, b + 32 * i); else y = x;
+    switch (op) {
+        case 0: fr_mul(r, x, y); break;
+        case 1: fr_add(r, x, y); break;
+        case 2: fr_sub(r, x, y); break;
+        case 3: fr_neg(r, x); break;
+        default: fr_inv(r, x); break;
+    }
+    fr_store32(out + 32 * i, r);
+}
+
+__global__ void __launch_bounds__(BLOCK, 2) zp_from_hash_kernel(size_t n, const uint8_t* digests, uint8_t* out) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint32_t raw[16], w[16];
+    load_raw32(raw, digests + 64 * i);
+    load_raw32(raw + 8, digests + 64 * i + 32);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) w[j] = bswap32(raw[j]);
+    fr r;
+    fr_from_digest_words(r, w);
+    fr_store32(out + 32 * i, r);
+}
+
+// out[t] = sum over i = t (mod T) of a[i] * b[i] (b == nullptr: of a[i]), canonical bytes
+__global__ void __launch_bounds__(BLOCK, 2) zp_fold_kernel(size_t n, const uint8_t* a, const uint8_t* b, size_t T, uint8_t* out) {
+    const size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= T) return;
+    fr acc;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc.w[j] = 0;
+#pragma unroll 1
+    for (size_t i = t; i < n; i += T) {
+        fr x;
+        fr_load32(x, a + 32 * i);
+        if (b) { fr y; fr_load32(y, b + 32 * i); fr_mul(x, x, y); }
+        fr_add(acc, acc, x);
+    }
+    fr_store32(out + 32 * t, acc);
+}
+
+}  // namespace c12381

@@ -2,6 +2,7 @@
 //   k_g1.hip     Fp hooks, G1 scalar multiplication / addition / finish / tree sum, MSM stages, G1 decompression
 //   k_g2gt.hip   G2 scalar multiplication / addition / decompression, one-lane pairing kernels, GT arithmetic
 //   k_pair3.hip  three-lanes-per-pairing Miller loop + final exponentiation
+//   k_hash_zp.hip  hash-to-G1 and the scalar-field (Zp) helpers
 // c12381_hip.hip (context, workspaces, C ABI) launches them.  Every kernel is built for 2 waves per SIMD
 // (__launch_bounds__(BLOCK, 2)): the field routines are not inlined and get the full 256-VGPR budget.
 #pragma once
@@ -38,5 +39,9 @@ __global__ void __launch_bounds__(BLOCK, 2) gt_op_kernel(int op, size_t n, const
 __global__ void __launch_bounds__(BLOCK, 2) gt_is_unity_kernel(size_t n, const uint8_t* a, uint8_t* out);
 __global__ void __launch_bounds__(BLOCK, 2) pair3_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, size_t b2_stride, uint8_t* out, int* bad_flag);
+__global__ void __launch_bounds__(BLOCK, 2) g1_from_hash_kernel(size_t n, const uint8_t* in, int mode, int32_t* proj, size_t proj_stride, int* bad_flag);
+__global__ void __launch_bounds__(BLOCK, 2) zp_op_kernel(int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out);
+__global__ void __launch_bounds__(BLOCK, 2) zp_from_hash_kernel(size_t n, const uint8_t* digests, uint8_t* out);
+__global__ void __launch_bounds__(BLOCK, 2) zp_fold_kernel(size_t n, const uint8_t* a, const uint8_t* b, size_t T, uint8_t* out);
 
 }  // namespace c12381

@@ -6,7 +6,7 @@
 // src/miracl_core_interface.cpp:109-289 forwards to MIRACL — and forwards them to the C ABI of
 // include/c12381_hip.h instead.  It is compiled INSIDE the reference tree (it includes the reference's
 // header from there; nothing of the reference is vendored here).  The hash / big / random functions of the
-// seam (miracl_core_interface.hpp:16-64) are scalar-field glue and stay with the reference's own file.
+// seam (miracl_core_interface.hpp:16-64) are host-side scalar glue and stay with the reference's own file.
 //
 // The seam's PODs are opaque to the headers, so they are used as byte containers:
 //   point1 (192 B): bytes 0..95  = x||y big-endian canonical, all zero = infinity
@@ -77,6 +77,17 @@ void scalar32(uint8_t out[32], const chunk_t (&k)[7]) {
     }
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 8; ++j) out[31 - (8 * i + j)] = (uint8_t)(w[i] >> (8 * j));
 }
+// normalised big (value < 2^384) -> 48 big-endian bytes
+void big48(uint8_t out[48], const chunk_t (&k)[7]) {
+    uint64_t w[8] = {0};
+    for (int i = 0; i < 7; ++i) {
+        const int wi = (58 * i) / 64, bo = (58 * i) % 64;
+        const unsigned __int128 v = (unsigned __int128)((uint64_t)k[i] & 0x3ffffffffffffffull) << bo;
+        w[wi] |= (uint64_t)v;
+        w[wi + 1] |= (uint64_t)(v >> 64);
+    }
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 8; ++j) out[47 - (8 * i + j)] = (uint8_t)(w[i] >> (8 * j));
+}
 inline void ck(int rc) { (void)rc; }                   // boundary functions are noexcept and total
 
 const char* G1_GEN_HEX =
@@ -131,6 +142,19 @@ int get_default_generator(point1& result) noexcept {
     std::memset(&result, 0, sizeof result);
     from_hex(raw(result), G1_GEN_HEX, 96);
     return 1;
+}
+// hash-to-G1 pieces (G1Point::from_hash, g1_point.hpp:219-234).  `fp` is opaque to the headers: bytes 0..47 = the
+// canonical value, big-endian.
+void residue(fp& result, const big& value) noexcept {                             // was FP_nres
+    std::memset(&result, 0, sizeof result);
+    big48(reinterpret_cast<uint8_t*>(&result), value);
+}
+void map_to_point(point1& result, const fp& value) noexcept {                     // was ECP_map2point
+    std::memset(&result, 0, sizeof result);
+    ck(c12381_g1_map_to_point_batch(ctx(), 1, reinterpret_cast<const uint8_t*>(&value), raw(result)));
+}
+void multiply_cofactor(point1& object) noexcept {                                 // was ECP_cfp: [1 - x]P
+    ck(c12381_g1_clear_cofactor_batch(ctx(), 1, raw(object), raw(object)));
 }
 void multiply(point1& object, const big& value) noexcept {                        // was PAIR_G1mul
     uint8_t k[32];

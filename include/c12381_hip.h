@@ -145,6 +145,35 @@ int c12381_bbs_plus_verify_batch_dev(c12381_ctx* ctx, size_t n, size_t nmsg, con
                                      const uint8_t* h0_96, const uint8_t* h_96, const uint8_t* w_192, const uint8_t* A_96,
                                      const uint8_t* x_32, const uint8_t* r_32, const uint8_t* m_32, uint8_t* ok);
 
+/* hash-to-G1 ------------------------------------------------------------------- */
+/* G1Point::from_hash (include/crypto12381/g1_point.hpp:219-234) from the 64-byte SHA3-512 digest on: the digest as a
+ * big-endian integer mod p (fixed_time_mod :55 -> 94-97), residue (:110 -> 149-152 -> FP_nres), map_to_point
+ * (:113 -> 154-157 -> ECP_map2point: simplified SWU + 11-isogeny), multiply_cofactor (:116 -> 159-162 -> ECP_cfp),
+ * encoded like to_bytes.  Hashing the caller's serialisation (hash_state, set.hpp:317-392) stays on the host.
+ * out_fmt 49 or 96.  Not RFC 9380 hash_to_curve: one field element per digest, as the reference defines it. */
+int c12381_g1_from_hash_batch(c12381_ctx* ctx, size_t n, const uint8_t* digests64, uint8_t* out, int out_fmt);
+int c12381_g1_from_hash_batch_dev(c12381_ctx* ctx, size_t n, const uint8_t* digests64, uint8_t* out, int out_fmt);
+/* map_to_point(point1&, const fp&) alone (:113 -> 154-157 -> ECP_map2point): 48-byte field elements (taken mod p, as
+ * residue/FP_nres does) -> 96-byte affine points of E, NOT yet multiplied by the cofactor. */
+int c12381_g1_map_to_point_batch(c12381_ctx* ctx, size_t n, const uint8_t* u48, uint8_t* out96);
+/* multiply_cofactor(point1&) alone (:116 -> 159-162 -> ECP_cfp): P -> [1 - x]P = [0xd201000000010001]P as a plain
+ * multiple.  (Not c12381_g1_mul_batch: `multiply` is PAIR_G1mul, whose GLV evaluation differs from the plain
+ * multiple for points outside the subgroup — which is what map_to_point produces.) */
+int c12381_g1_clear_cofactor_batch(c12381_ctx* ctx, size_t n, const uint8_t* in96, uint8_t* out96);
+
+/* scalar-field (Zp) batch helpers ----------------------------------------------- */
+/* Element-wise arithmetic mod r on canonical 32-byte big-endian values (inputs < 2^256 are reduced first); what
+ * zp_number.hpp evaluates per element through multiply(big2&,..) :47 + mod :63 (operator*, :295-380), mod_negate :57,
+ * mod_inverse :59 -> 84-87 -> BIG_invmodp (inverse(), zp_number.hpp:420-425; the inverse of 0 is 0).
+ * op 0: a*b, 1: a+b, 2: a-b, 3: -a, 4: 1/a (b ignored for 3 and 4, may be NULL). */
+int c12381_zp_op_batch(c12381_ctx* ctx, int op, size_t n, const uint8_t* a32, const uint8_t* b32, uint8_t* out32);
+int c12381_zp_op_batch_dev(c12381_ctx* ctx, int op, size_t n, const uint8_t* a32, const uint8_t* b32, uint8_t* out32);
+/* Zp from_hash (zp_number.hpp:540-548): 64-byte digest as a big-endian integer mod r (fixed_time_mod). */
+int c12381_zp_from_hash_batch(c12381_ctx* ctx, size_t n, const uint8_t* digests64, uint8_t* out32);
+/* sum over i of a[i]*b[i] mod r (b == NULL: sum of a[i]) — sum()/inner products of zp_number.hpp:549-615; n = 0 -> 0. */
+int c12381_zp_inner_product(c12381_ctx* ctx, size_t n, const uint8_t* a32, const uint8_t* b32, uint8_t out32[32]);
+int c12381_zp_inner_product_dev(c12381_ctx* ctx, size_t n, const uint8_t* a32, const uint8_t* b32, uint8_t* out32);
+
 #ifdef __cplusplus
 }
 #endif

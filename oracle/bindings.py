@@ -171,6 +171,35 @@ class Oracle:
         self._ck(self._f("gt_op_batch")(self.GT_OPS[op], _sz(n), a, b, o), "gt_op_batch")
         return o.raw[:576 * n]
 
+    # ---- hash-to-G1 and Zp helpers
+    def g1_from_hash(self, digests: bytes, fmt: int = 96) -> bytes:
+        n = len(digests) // 64
+        o = self._buf(fmt * n)
+        self._ck(self._f("g1_from_hash_batch")(_sz(n), digests, o, fmt), "g1_from_hash_batch")
+        return o.raw[:fmt * n]
+
+    def g1_map_to_point(self, u48: bytes) -> bytes:
+        if self.kind == "port":
+            raise RuntimeError("map_to_point alone is exposed by the reference build only")
+        n = len(u48) // 48
+        o = self._buf(96 * n)
+        self._ck(self.lib.ref_g1_map_to_point_batch(_sz(n), u48, o), "g1_map_to_point_batch")
+        return o.raw[:96 * n]
+
+    ZP_OPS = {"mul": 0, "add": 1, "sub": 2, "neg": 3, "inv": 4}
+
+    def zp_op(self, op: str, a: bytes, b: bytes | None = None) -> bytes:
+        n = len(a) // 32
+        o = self._buf(32 * n)
+        self._ck(self._f("zp_op_batch")(self.ZP_OPS[op], _sz(n), a, b, o), "zp_op_batch")
+        return o.raw[:32 * n]
+
+    def zp_from_hash(self, digests: bytes) -> bytes:
+        n = len(digests) // 64
+        o = self._buf(32 * n)
+        self._ck(self._f("zp_from_hash_batch")(_sz(n), digests, o), "zp_from_hash_batch")
+        return o.raw[:32 * n]
+
     # ---- reference-only helpers
     def random_scalars(self, seed: bytes, n: int) -> bytes:
         if self.kind != "reference":

@@ -421,8 +421,8 @@ static fp BETA;      /* CRu (rom_field_BLS12381.cpp:54): (beta x, y) = [-x^2](x,
 /* PAIR_G1mul pair_BLS12381.cpp:876-924 with glv() :793-805: u0 = k mod x^2, u1 = r - (k div x^2); the sign
  * minimisation (:896-914) then replaces (u1, phi(P)) by (k div x^2, -phi(P)), so what ECP_mul2 evaluates — with
  * complete formulas, i.e. as exact group operations on ANY curve point, in or out of the order-r subgroup — is
- *     R = [k mod x^2] P + [k div x^2] (-phi(P)),   phi(x, y) = (beta x, y).
- * (For P in G1 this is [k]P.)  The joint window schedule of ECP_clmul2 is an evaluation strategy. */
+ *     R = [k mod x^2] P + [k div x^2] (-phi(P)),   phi(x, y) = (beta x, y),
+ * and R = [k] P + [r] phi(P) when k div x^2 = 0 (see below).  (For P in G1 this is [k]P.)  The joint window schedule of ECP_clmul2 is an evaluation strategy. */
 static void g1_mul(g1p* P, const uint64_t k[4]) {
     if (g1_is_inf(P)) return;
     u128 x2 = (u128)BNX * BNX;
@@ -431,9 +431,15 @@ static void g1_mul(g1p* P, const uint64_t k[4]) {
     g1p A = *P, Q = *P;
     g1_affine(&Q);
     fp_mul(&Q.x, &Q.x, &BETA);
-    fp_neg(&Q.y, &Q.y);
     g1_mul_plain(&A, u0, 2);
-    g1_mul_plain(&Q, q, 2);
+    if ((q[0] | q[1]) == 0) {
+        /* k < x^2: u1 = r - 0 = r survives the sign minimisation (BIG_modneg(r) = r, no fewer bits), so ECP_mul2 adds
+         * [r] phi(P) — infinity for P in G1, a cofactor-part point otherwise */
+        g1_mul_plain(&Q, RORD, 4);
+    } else {
+        fp_neg(&Q.y, &Q.y);
+        g1_mul_plain(&Q, q, 2);
+    }
     g1_add(&A, &Q);
     *P = A;
 }
@@ -526,8 +532,8 @@ static void g2_frob(g2p* P) {
 /* PAIR_G2mul pair_BLS12381.cpp:927-983 with gs() :814-873 (BLS branch): k mod r is written in base |x|,
  * k = u0 + u1|x| + u2|x|^2 + u3|x|^3; x < 0 makes the odd digits negative (:868-871) and the sign minimisation
  * (:962-971) turns that into negated points, so ECP2_mul4 evaluates — exactly, on any point of the twist —
- *     R = u0 Q - u1 psi(Q) + u2 psi^2(Q) - u3 psi^3(Q).
- * (For Q in G2, psi(Q) = [x]Q and this is [k]Q.) */
+ *     R = u0 Q - u1 psi(Q) + u2 psi^2(Q) - u3 psi^3(Q),
+ * with -u_i psi^i(Q) replaced by +[r] psi^i(Q) when an odd digit u_i is 0.  (For Q in G2, psi(Q) = [x]Q and this is [k]Q.) */
 static void g2_mul(g2p* P, const uint64_t k[4]) {
     if (g2_is_inf(P)) return;
     uint64_t w[4], u[4];
@@ -541,9 +547,15 @@ static void g2_mul(g2p* P, const uint64_t k[4]) {
     g2p acc, Q = *P; g2_inf(&acc);
     for (int i = 0; i < 4; i++) {
         g2p T = Q;
-        if (i & 1) g2_neg(&T);
-        uint64_t e[1] = {u[i]};
-        g2_mul_plain(&T, e, 1);
+        if ((i & 1) && u[i] == 0) {
+            /* BIG_modneg(0) = r (:868-871) and the sign minimisation keeps it: the term is [r] psi^i(Q), not negated —
+             * infinity for Q in G2, a cofactor-part point otherwise */
+            g2_mul_plain(&T, RORD, 4);
+        } else {
+            if (i & 1) g2_neg(&T);
+            uint64_t e[1] = {u[i]};
+            g2_mul_plain(&T, e, 1);
+        }
         g2_add(&acc, &T);
         g2_frob(&Q);
     }
@@ -907,5 +919,142 @@ int orc_gt_op_batch(int op, size_t n, const uint8_t* a576, const uint8_t* b, uin
         } else return -1;
         fp12_to_bytes(out576 + 576 * i, &r);
     }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ hash-to-G1
+ * G1Point::from_hash, include/crypto12381/g1_point.hpp:219-234, from the digest on:
+ * ECP_map2point ecp_BLS12381.cpp:1495-1626 (simplified SWU on E' + 11-isogeny, hint-sharing FP_qr/FP_inv/FP_sqrt
+ * fp_BLS12381.cpp:800-876 with PM1D2 = 1) and ECP_cfp :1252-1273 (multiply by CURVE_Cof = 1 - x). */
+#include "h2c_consts.h"
+static fp SSWU_A, SSWU_B, SSWU_HINTZ, ISO_XN[12], ISO_XD[10], ISO_YN[16], ISO_YD[15];
+static uint64_t E_PM3D4[6];
+static pthread_once_t once_h2c = PTHREAD_ONCE_INIT;
+static void fp_from_hex(fp* r, const char* h) { uint8_t b[48]; hex48(b, h); fp_from_bytes(r, b); }
+static void init_h2c(void) {
+    INIT();
+    uint64_t pm3[6]; memcpy(pm3, P, 48); pm3[0] -= 3;
+    bn_div_small(E_PM3D4, pm3, 6, 4);
+    fp_from_hex(&SSWU_A, SSWU_A_HEX); fp_from_hex(&SSWU_B, SSWU_B_HEX);
+    for (int i = 0; i < 12; i++) fp_from_hex(&ISO_XN[i], ISO11_XNUM_HEX[i]);
+    for (int i = 0; i < 10; i++) fp_from_hex(&ISO_XD[i], ISO11_XDEN_HEX[i]);
+    for (int i = 0; i < 16; i++) fp_from_hex(&ISO_YN[i], ISO11_YNUM_HEX[i]);
+    for (int i = 0; i < 15; i++) fp_from_hex(&ISO_YD[i], ISO11_YDEN_HEX[i]);
+    fp z; fp_set_int(&z, 11);
+    fp_pow(&SSWU_HINTZ, &z, E_PM3D4, 6);                 /* CURVE_HTPC = Z^((p-3)/4) */
+}
+/* FP_progen :782-797 with e = 1 */
+static void fp_progen(fp* r, const fp* x) { fp_pow(r, x, E_PM3D4, 6); }
+/* FP_qr :800-813 with hint */
+static int fp_qr_hint(const fp* x, fp* h) { fp r; fp_progen(&r, x); *h = r; fp_sqr(&r, &r); fp_mul(&r, x, &r); return fp_eq(&r, &ONE); }
+/* FP_inv :817-840 with hint: x * hint^4 */
+static void fp_inv_hint(fp* r, const fp* x, const fp* h) { fp t; fp_sqr(&t, h); fp_sqr(&t, &t); fp_mul(r, &t, x); }
+/* FP_sqrt :842-876 with hint, e = 1: hint * a, then the even ("positive") root */
+static void fp_sqrt_hint(fp* r, const fp* a, const fp* h) { fp v; fp_mul(r, h, a); if (fp_sign(r)) { fp_neg(&v, r); *r = v; } }
+static void horner(fp* r, const fp* cs, int n, const fp* x, int monic) {
+    fp acc;
+    if (monic) fp_add(&acc, x, &cs[n - 1]); else acc = cs[n - 1];
+    for (int i = n - 2; i >= 0; i--) { fp_mul(&acc, &acc, x); fp_add(&acc, &acc, &cs[i]); }
+    *r = acc;
+}
+static void g1_map2point(g1p* P, const fp* h) {
+    fp X1, X2, X3, t, w, D, D2, hint, GX1, Y;
+    int sgn = fp_sign(h);
+    fp_sqr(&t, h); fp_imul(&t, &t, 11);
+    fp_add(&w, &t, &ONE);
+    fp_mul(&w, &w, &t);
+    fp_mul(&D, &SSWU_A, &w);
+    fp_add(&w, &w, &ONE); fp_mul(&w, &w, &SSWU_B); fp_neg(&w, &w);
+    X2 = w; fp_mul(&X3, &t, &X2);
+    fp_sqr(&GX1, &X2);
+    fp_sqr(&D2, &D); fp_mul(&w, &SSWU_A, &D2); fp_add(&GX1, &GX1, &w); fp_mul(&GX1, &GX1, &X2);
+    fp_mul(&D2, &D2, &D); fp_mul(&w, &SSWU_B, &D2); fp_add(&GX1, &GX1, &w);
+    fp_mul(&w, &GX1, &D);
+    int qr = fp_qr_hint(&w, &hint);
+    fp_inv_hint(&D, &w, &hint);
+    fp_mul(&D, &D, &GX1);
+    fp_mul(&X2, &X2, &D); fp_mul(&X3, &X3, &D);
+    fp_mul(&t, &t, h);
+    fp_sqr(&D2, &D);
+    fp_mul(&D, &D2, &t);
+    fp_imul(&t, &w, 11);
+    fp_mul(&X1, &SSWU_HINTZ, &hint);
+    if (!qr) { X2 = X3; D2 = D; w = t; hint = X1; }
+    fp_sqrt_hint(&Y, &w, &hint);
+    fp_mul(&Y, &Y, &D2);
+    if (fp_sign(&Y) ^ sgn) fp_neg(&Y, &Y);
+    fp xnum, xden, ynum, yden;
+    horner(&xnum, ISO_XN, 12, &X2, 0); horner(&xden, ISO_XD, 10, &X2, 1);
+    horner(&ynum, ISO_YN, 16, &X2, 0); horner(&yden, ISO_YD, 15, &X2, 1);
+    fp_mul(&ynum, &ynum, &Y);
+    fp_mul(&P->x, &xnum, &yden); fp_mul(&P->y, &ynum, &xden); fp_mul(&P->z, &xden, &yden);
+}
+int orc_g1_from_hash_batch(size_t n, const uint8_t* digests64, uint8_t* out, int out_fmt) {
+    pthread_once(&once_h2c, init_h2c);
+    for (size_t i = 0; i < n; i++) {
+        /* 512-bit big-endian integer mod p (fixed_time_mod), in Montgomery form (residue -> FP_nres) */
+        fp u, b; memset(&u, 0, sizeof u);
+        for (int j = 0; j < 64; j++) { fp_imul(&u, &u, 256); fp_set_int(&b, digests64[64 * i + j]); fp_add(&u, &u, &b); }
+        g1p Q; g1_map2point(&Q, &u);
+        uint64_t cof[1] = {BNX + 1};                       /* CURVE_Cof = 1 - x (x negative) */
+        g1_mul_plain(&Q, cof, 1);
+        g1_store(out + (size_t)out_fmt * i, &Q, out_fmt);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ Zp helpers: arithmetic mod r
+ * on canonical 32-byte values, zp_number.hpp:295-380 (operator*), :420-425 (inverse -> BIG_invmodp), :540-548 (from_hash) */
+typedef struct { uint64_t w[4]; } zr;
+static int zr_geq(const uint64_t* a) { for (int i = 3; i >= 0; i--) { if (a[i] > RORD[i]) return 1; if (a[i] < RORD[i]) return 0; } return 1; }
+static void zr_subr(uint64_t* a) { u128 bw = 0; for (int i = 0; i < 4; i++) { u128 d = (u128)a[i] - RORD[i] - bw; a[i] = (uint64_t)d; bw = (d >> 64) & 1; } }
+static void zr_add(zr* r, const zr* a, const zr* b) {
+    u128 c = 0; uint64_t t[4];
+    for (int i = 0; i < 4; i++) { c += (u128)a->w[i] + b->w[i]; t[i] = (uint64_t)c; c >>= 64; }
+    if (c || zr_geq(t)) zr_subr(t);
+    memcpy(r->w, t, 32);
+}
+static void zr_mul(zr* r, const zr* a, const zr* b) {           /* double-and-add: slow and obviously right */
+    zr acc; memset(&acc, 0, sizeof acc);
+    for (int i = 255; i >= 0; i--) { zr_add(&acc, &acc, &acc); if ((b->w[i / 64] >> (i % 64)) & 1) zr_add(&acc, &acc, a); }
+    *r = acc;
+}
+static void zr_from_be(zr* r, const uint8_t* s, int len) {      /* big-endian integer of any length mod r */
+    zr acc; memset(&acc, 0, sizeof acc);
+    for (int j = 0; j < len; j++) {
+        for (int k = 0; k < 8; k++) zr_add(&acc, &acc, &acc);
+        zr b; memset(&b, 0, sizeof b); b.w[0] = s[j]; zr_add(&acc, &acc, &b);
+    }
+    *r = acc;
+}
+static void zr_to_be(uint8_t* out, const zr* a) { for (int i = 0; i < 32; i++) out[i] = (uint8_t)(a->w[(31 - i) / 8] >> (8 * ((31 - i) % 8))); }
+int orc_zp_op_batch(int op, size_t n, const uint8_t* a32, const uint8_t* b32, uint8_t* out32) {
+    for (size_t i = 0; i < n; i++) {
+        zr a, b, r; zr_from_be(&a, a32 + 32 * i, 32);
+        if (b32 && op <= 2) zr_from_be(&b, b32 + 32 * i, 32); else b = a;
+        zr nb; memset(&nb, 0, sizeof nb);
+        switch (op) {
+            case 0: zr_mul(&r, &a, &b); break;
+            case 1: zr_add(&r, &a, &b); break;
+            case 2: case 3: {
+                const zr* v = op == 2 ? &b : &a;
+                if (v->w[0] | v->w[1] | v->w[2] | v->w[3]) { u128 bw = 0; for (int k = 0; k < 4; k++) { u128 d = (u128)RORD[k] - v->w[k] - bw; nb.w[k] = (uint64_t)d; bw = (d >> 64) & 1; } }
+                if (op == 2) zr_add(&r, &a, &nb); else r = nb;
+                break;
+            }
+            case 4: {                                            /* a^(r-2); 0 -> 0 */
+                uint64_t e[4]; memcpy(e, RORD, 32); e[0] -= 2;
+                zr acc; memset(&acc, 0, sizeof acc); acc.w[0] = 1;
+                for (int k = 254; k >= 0; k--) { zr_mul(&acc, &acc, &acc); if ((e[k / 64] >> (k % 64)) & 1) zr_mul(&acc, &acc, &a); }
+                r = acc; break;
+            }
+            default: return -1;
+        }
+        zr_to_be(out32 + 32 * i, &r);
+    }
+    return 0;
+}
+int orc_zp_from_hash_batch(size_t n, const uint8_t* digests64, uint8_t* out32) {
+    for (size_t i = 0; i < n; i++) { zr r; zr_from_be(&r, digests64 + 64 * i, 64); zr_to_be(out32 + 32 * i, &r); }
     return 0;
 }

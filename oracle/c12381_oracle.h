@@ -29,6 +29,9 @@ int orc_fexp_batch(size_t n, const uint8_t* in576, uint8_t* out576);
 int orc_pair_eq_batch(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, uint8_t* ok, int nthreads);
 int orc_pair2_batch(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, uint8_t* gt576);
 int orc_gt_op_batch(int op, size_t n, const uint8_t* a576, const uint8_t* b, uint8_t* out576);
+int orc_g1_from_hash_batch(size_t n, const uint8_t* digests64, uint8_t* out, int out_fmt);
+int orc_zp_op_batch(int op, size_t n, const uint8_t* a32, const uint8_t* b32, uint8_t* out32);
+int orc_zp_from_hash_batch(size_t n, const uint8_t* digests64, uint8_t* out32);
 
 #ifdef __cplusplus
 }

@@ -107,6 +107,13 @@ def main():
     g1j["offsubgroup_points"], g1j["offsubgroup_scalars"] = hx(off, 96), hx(off_sc, 32)
     g1j["offsubgroup_mul96"] = hx(ref.g1_mul(off, off_sc, 96), 96)
     g1j["offsubgroup_msm49"] = ref.g1_msm(off, off_sc, 49, 2).hex()
+    # ... and scalars below x^2: glv() leaves u1 = r there, so the reference adds [r]phi(P) (pair_BLS12381.cpp:793-805, :899-906)
+    X2 = 0xd201000000010000 ** 2
+    small = [0, 1, 2, 0xd201000000010001, X2 - 1, X2, X2 + 1, R - 1, R, R + 1, 3 * X2, (1 << 127), 12345, R + 7]
+    off_small_pts = b"".join(off[96 * (i % 6):96 * (i % 6) + 96] for i in range(len(small)))
+    off_small_sc = b"".join(v.to_bytes(32, "big") for v in small)
+    g1j["offsubgroup_small_points"], g1j["offsubgroup_small_scalars"] = hx(off_small_pts, 96), hx(off_small_sc, 32)
+    g1j["offsubgroup_small_mul96"] = hx(ref.g1_mul(off_small_pts, off_small_sc, 96), 96)
     g1j["generator"] = g1.hex()
     json.dump(g1j, open(os.path.join(OUT, "g1.json"), "w"), indent=0)
 
@@ -146,6 +153,13 @@ def main():
     off2_sc = scalars(34, 6, 1 << 256)
     g2j["offsubgroup_points"], g2j["offsubgroup_scalars"] = hx(off2, 192), hx(off2_sc, 32)
     g2j["offsubgroup_mul192"] = hx(ref.g2_mul(off2, off2_sc, 192), 192)   # = u0 Q - u1 psi(Q) + u2 psi^2(Q) - u3 psi^3(Q)
+    # zero odd digits in base |x|: gs() turns them into r (BIG_modneg(0) = r, pair_BLS12381.cpp:868-871), adding [r]psi^i(Q)
+    XA = 0xd201000000010000
+    small2 = [0, 1, XA - 1, XA, XA + 1, XA ** 2, XA ** 2 + 5, XA ** 3, XA ** 3 + XA, XA ** 3 + 9, 7 * XA ** 2 + 3 * XA + 1, R - 1, R + 2, 1 << 190]
+    off2_small_pts = b"".join(off2[192 * (i % 6):192 * (i % 6) + 192] for i in range(len(small2)))
+    off2_small_sc = b"".join(v.to_bytes(32, "big") for v in small2)
+    g2j["offsubgroup_small_points"], g2j["offsubgroup_small_scalars"] = hx(off2_small_pts, 192), hx(off2_small_sc, 32)
+    g2j["offsubgroup_small_mul192"] = hx(ref.g2_mul(off2_small_pts, off2_small_sc, 192), 192)
     g2j["generator"] = g2.hex()
     json.dump(g2j, open(os.path.join(OUT, "g2.json"), "w"), indent=0)
 
@@ -190,6 +204,18 @@ def main():
     json.dump({"seed": seed.decode(), "scalars": hx(rs, 32), "P": Pp.hex(), "Q": Qq.hex(),
                "pair_Px_Qy": lhs.hex(), "xy": xy.hex()},
               open(os.path.join(OUT, "config1_bilinearity.json"), "w"), indent=0)
+
+    # ---------------- hash-to-G1 (g1_point.hpp:219-234) and Zp helpers (zp_number.hpp) — SURVEY.md 8(f) rows 3, 4
+    edge = [0, P, 1, P - 1, P + 1, (1 << 512) - 1, 2 * P, 11, R, 1 << 381]
+    dig = b"".join(x.to_bytes(64, "big") for x in edge) + b"".join(hashlib.sha3_512(b"c12381 h2c|%d" % i).digest() for i in range(22))
+    zedge = [0, 1, 2, R - 1, R, R + 1, (1 << 256) - 1, R - 2]
+    za = b"".join(x.to_bytes(32, "big") for x in zedge) + scalars(31, 24, 1 << 256)
+    zb = scalars(32, 8, 1 << 256) + b"".join(x.to_bytes(32, "big") for x in zedge) + scalars(33, 16, 1 << 256)
+    json.dump({"digests": hx(dig, 64), "g1_from_hash_96": hx(ref.g1_from_hash(dig, 96), 96), "g1_from_hash_49": hx(ref.g1_from_hash(dig, 49), 49),
+               "zp_from_hash": hx(ref.zp_from_hash(dig), 32),
+               "zp_a": hx(za, 32), "zp_b": hx(zb, 32),
+               **{"zp_" + op: hx(ref.zp_op(op, za, zb if op in ("mul", "add", "sub") else None), 32) for op in ("mul", "add", "sub", "neg", "inv")}},
+              open(os.path.join(OUT, "hash_zp.json"), "w"), indent=0)
     print("golden vectors written to", OUT)
 
 

@@ -408,4 +408,104 @@ int ref_sha3_512(const uint8_t* msg, size_t len, uint8_t out[64]) {
     return 0;
 }
 
+// G1Point::from_hash from the digest on (include/crypto12381/g1_point.hpp:219-234): from_bytes(big2) ->
+// fixed_time_mod(x, dbig, p, 512 - 381) -> residue -> map_to_point -> multiply_cofactor -> to_bytes.
+int ref_g1_from_hash_batch(size_t n, const uint8_t* digests64, uint8_t* out, int out_fmt) {
+    static const uint8_t P_BE[48] = {
+        0x1a, 0x01, 0x11, 0xea, 0x39, 0x7f, 0xe6, 0x9a, 0x4b, 0x1b, 0xa7, 0xb6, 0x43, 0x4b, 0xac, 0xd7,
+        0x64, 0x77, 0x4b, 0x84, 0xf3, 0x85, 0x12, 0xbf, 0x67, 0x30, 0xd2, 0xa0, 0xf6, 0xb0, 0xf6, 0x24,
+        0x1e, 0xab, 0xff, 0xfe, 0xb1, 0x53, 0xff, 0xff, 0xb9, 0xfe, 0xff, 0xff, 0xff, 0xff, 0xaa, 0xab};
+    mc::big modulus;
+    mc::from_bytes(modulus, (const char*)P_BE);
+    for (size_t i = 0; i < n; ++i) {
+        mc::big2 dbig;
+        mc::from_bytes(dbig, (const char*)digests64 + 64 * i, 64);
+        mc::big x;
+        mc::fixed_time_mod(x, dbig, modulus, 64 * 8 - 381);
+        mc::fp f;
+        mc::residue(f, x);
+        mc::point1 P;
+        mc::map_to_point(P, f);
+        mc::multiply_cofactor(P);
+        g1_store(out + (size_t)out_fmt * i, P, out_fmt);
+    }
+    return 0;
+}
+
+// residue + map_to_point alone (no cofactor): 48-byte field element -> affine point of E
+int ref_g1_map_to_point_batch(size_t n, const uint8_t* u48, uint8_t* out96) {
+    for (size_t i = 0; i < n; ++i) {
+        mc::big x;
+        mc::from_bytes(x, (const char*)u48 + 48 * i);
+        mc::fp f;
+        mc::residue(f, x);
+        mc::point1 P;
+        mc::map_to_point(P, f);
+        g1_store(out96 + 96 * i, P, 96);
+    }
+    return 0;
+}
+
+// Zp helpers as zp_number.hpp evaluates them through the boundary: operands are reduced mod r first.
+// op 0 mul (multiply + mod), 1 add, 2 sub, 3 neg (mod_negate), 4 inverse (mod_inverse, 0 -> 0)
+static void zp_load(mc::big& k, const uint8_t* s32, const mc::big& order) {
+    scalar_from32(k, s32);
+    mc::big2 d;
+    char buf[96];
+    std::memset(buf, 0, 96);
+    std::memcpy(buf + 64, s32, 32);
+    mc::from_bytes(d, buf, 96);
+    mc::mod(k, d, order);
+}
+static void zp_store(uint8_t* out32, const mc::big& k) {
+    char buf[48];
+    mc::to_bytes(buf, k);
+    std::memcpy(out32, buf + 16, 32);
+}
+static void zp_order(mc::big& order) {
+    static const uint8_t R_BE[48] = {
+        0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+        0x73, 0xed, 0xa7, 0x53, 0x29, 0x9d, 0x7d, 0x48, 0x33, 0x39, 0xd8, 0x08, 0x09, 0xa1, 0xd8, 0x05,
+        0x53, 0xbd, 0xa4, 0x02, 0xff, 0xfe, 0x5b, 0xfe, 0xff, 0xff, 0xff, 0xff, 0x00, 0x00, 0x00, 0x01};
+    mc::from_bytes(order, (const char*)R_BE);
+}
+int ref_zp_op_batch(int op, size_t n, const uint8_t* a32, const uint8_t* b32, uint8_t* out32) {
+    mc::big order;
+    zp_order(order);
+    for (size_t i = 0; i < n; ++i) {
+        mc::big a, b, r;
+        zp_load(a, a32 + 32 * i, order);
+        if (b32 && op <= 2) zp_load(b, b32 + 32 * i, order);
+        mc::big2 d;
+        switch (op) {
+            case 0: mc::multiply(d, a, b); mc::mod(r, d, order); break;
+            case 1: case 2: {
+                if (op == 2) mc::mod_negate(b, b, order);
+                for (int j = 0; j < 7; ++j) r[j] = a[j] + b[j];
+                mc::normalize(r);
+                if (mc::compare(r, order) >= 0) { for (int j = 0; j < 7; ++j) r[j] -= order[j]; mc::normalize(r); }
+                break;
+            }
+            case 3: mc::mod_negate(r, a, order); if (mc::compare(r, order) >= 0) { for (int j = 0; j < 7; ++j) r[j] -= order[j]; mc::normalize(r); } break;
+            case 4: mc::mod_inverse(r, a, order); break;
+            default: return -1;
+        }
+        zp_store(out32 + 32 * i, r);
+    }
+    return 0;
+}
+// Zp from_hash (zp_number.hpp:540-548)
+int ref_zp_from_hash_batch(size_t n, const uint8_t* digests64, uint8_t* out32) {
+    mc::big order;
+    zp_order(order);
+    for (size_t i = 0; i < n; ++i) {
+        mc::big2 dbig;
+        mc::from_bytes(dbig, (const char*)digests64 + 64 * i, 64);
+        mc::big x;
+        mc::fixed_time_mod(x, dbig, order, 64 * 8 - 255);
+        zp_store(out32 + 32 * i, x);
+    }
+    return 0;
+}
+
 } // extern "C"

@@ -367,3 +367,76 @@ extern "C" int sim_g1_msm_pippenger(size_t n, const uint8_t* pts96, const uint8_
     else { out[0] = (uint8_t)(0x02 | fp_sign(ay)); std::memcpy(out + 1, rx, 48); }
     return 0;
 }
+
+// ---------------------------------------------------------------- hash-to-G1, Zp helpers
+#include "../../crypto12381_amd/csrc/fr.hpp"
+#include "../../crypto12381_amd/csrc/h2c.hpp"
+
+static void fr_from_bytes32(fr& r, const uint8_t* p) {
+    uint32_t raw[8], k[8];
+    load_raw(raw, p, 8);
+    scalar_from_raw32(k, raw);
+    fr_from_words(r, k);
+}
+static void fr_to_bytes32(uint8_t* p, const fr& a) {
+    uint32_t k[8], raw[8];
+    fr_to_words(k, a);
+    for (int i = 0; i < 8; ++i) raw[i] = bswap32(k[7 - i]);
+    std::memcpy(p, raw, 32);
+}
+
+extern "C" {
+
+int sim_g1_from_hash_batch(size_t n, const uint8_t* digests64, uint8_t* out, int fmt) {
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t raw[16];
+        load_raw(raw, digests64 + 64 * i, 16);
+        g1p acc;
+        g1_from_digest(acc, raw);
+        uint8_t* o = out + (size_t)fmt * i;
+        if (g1_is_inf(acc)) { std::memset(o, 0, fmt); continue; }
+        fp zn, zi, ax, ay;
+        fp_norm1(zn, acc.z);
+        fp_inv(zi, zn);
+        g1p an;
+        g1_norm1(an, acc);
+        g1_to_affine(ax, ay, an, zi);
+        uint32_t rx[12], ry[12];
+        fp_to_raw48(rx, ax); fp_to_raw48(ry, ay);
+        if (fmt == 96) { std::memcpy(o, rx, 48); std::memcpy(o + 48, ry, 48); }
+        else { o[0] = (uint8_t)(0x02 | fp_sign(ay)); std::memcpy(o + 1, rx, 48); }
+    }
+    return 0;
+}
+
+int sim_zp_op_batch(int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    for (size_t i = 0; i < n; ++i) {
+        fr x, y, r;
+        fr_from_bytes32(x, a + 32 * i);
+        if (b) fr_from_bytes32(y, b + 32 * i); else y = x;
+        switch (op) {
+            case 0: fr_mul(r, x, y); break;
+            case 1: fr_add(r, x, y); break;
+            case 2: fr_sub(r, x, y); break;
+            case 3: fr_neg(r, x); break;
+            case 4: fr_inv(r, x); break;
+            default: return -1;
+        }
+        fr_to_bytes32(out + 32 * i, r);
+    }
+    return 0;
+}
+
+int sim_zp_from_hash_batch(size_t n, const uint8_t* digests64, uint8_t* out) {
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t raw[16], w[16];
+        load_raw(raw, digests64 + 64 * i, 16);
+        for (int j = 0; j < 16; ++j) w[j] = bswap32(raw[j]);
+        fr r;
+        fr_from_digest_words(r, w);
+        fr_to_bytes32(out + 32 * i, r);
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -109,6 +109,10 @@ def test_points_outside_the_subgroup(ctx):
     g = golden("g2")
     pts, sc = cat(g["offsubgroup_points"]), cat(g["offsubgroup_scalars"])
     assert ctx.g2_mul(pts, sc, 192) == cat(g["offsubgroup_mul192"])
+    # scalars below x^2 / zero odd base-|x| digits: the reference adds [r]phi(P) / [r]psi^i(Q) there
+    assert ctx.g2_mul(cat(g["offsubgroup_small_points"]), cat(g["offsubgroup_small_scalars"]), 192) == cat(g["offsubgroup_small_mul192"])
+    g = golden("g1")
+    assert ctx.g1_mul(cat(g["offsubgroup_small_points"]), cat(g["offsubgroup_small_scalars"]), 96) == cat(g["offsubgroup_small_mul96"])
 
 
 def test_msm_bucket_method_vs_naive_and_oracle(ctx, oracle_port):

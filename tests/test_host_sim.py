@@ -103,6 +103,33 @@ def test_sim_points_outside_the_subgroup(sim):
     assert sim.sim_g2_mul_batch(sz(6), pts, sc, out, 192) == 0 and out.raw == cat(g["offsubgroup_mul192"])
 
 
+def test_sim_small_scalars_outside_the_subgroup(sim):
+    """k < x^2 (G1) / a zero odd base-|x| digit (G2): the reference's decomposition keeps r as a sub-scalar and adds
+    [r]phi(P) / [r]psi^i(Q); the device code reproduces that term (it vanishes on the subgroup)."""
+    g = golden("g1")
+    pts, sc = cat(g["offsubgroup_small_points"]), cat(g["offsubgroup_small_scalars"])
+    n = len(sc) // 32
+    out = ctypes.create_string_buffer(96 * n)
+    assert sim.sim_g1_mul_batch(sz(n), pts, sc, out, 96) == 0
+    exp = cat(g["offsubgroup_small_mul96"])
+    assert [out.raw[96 * i:96 * i + 96] == exp[96 * i:96 * i + 96] for i in range(n)] == [True] * n
+    gen = bytes.fromhex(g["generator"])
+    out2 = ctypes.create_string_buffer(96 * n)           # on the subgroup the same scalars give plain multiples
+    assert sim.sim_g1_mul_batch(sz(n), gen * n, sc, out2, 96) == 0
+    assert out2.raw[96:192] == gen and out2.raw[:96] == bytes(96)
+    g = golden("g2")
+    pts, sc = cat(g["offsubgroup_small_points"]), cat(g["offsubgroup_small_scalars"])
+    n = len(sc) // 32
+    out = ctypes.create_string_buffer(192 * n)
+    assert sim.sim_g2_mul_batch(sz(n), pts, sc, out, 192) == 0
+    exp = cat(g["offsubgroup_small_mul192"])
+    assert [out.raw[192 * i:192 * i + 192] == exp[192 * i:192 * i + 192] for i in range(n)] == [True] * n
+    gen = bytes.fromhex(g["generator"])
+    out2 = ctypes.create_string_buffer(192 * n)
+    assert sim.sim_g2_mul_batch(sz(n), gen * n, sc, out2, 192) == 0
+    assert out2.raw[192:384] == gen and out2.raw[:192] == bytes(192)
+
+
 def test_sim_pairing_golden(sim):
     """Miller loop + final exponentiation of the device headers, incl. infinity arguments."""
     g = golden("pairing")
@@ -188,3 +215,23 @@ def test_sim_msm_pippenger(sim, oracle_port):
     out = ctypes.create_string_buffer(96)
     assert sim.sim_g1_msm_pippenger(sz(m), p, k, out, 96, 0) == 0
     assert out.raw == oracle_port.g1_msm(p, k, 96, 4)
+
+
+def test_sim_hash_to_g1_and_zp(sim):
+    """h2c.hpp / fr.hpp as the kernels run them, against the reference's vectors (degenerate digests included)"""
+    g = golden("hash_zp")
+    d = cat(g["digests"])
+    n = len(d) // 64
+    for fmt in (96, 49):
+        out = ctypes.create_string_buffer(fmt * n)
+        assert sim.sim_g1_from_hash_batch(sz(n), d, out, fmt) == 0
+        assert out.raw == cat(g["g1_from_hash_%d" % fmt])
+    out = ctypes.create_string_buffer(32 * n)
+    assert sim.sim_zp_from_hash_batch(sz(n), d, out) == 0
+    assert out.raw == cat(g["zp_from_hash"])
+    a, b = cat(g["zp_a"]), cat(g["zp_b"])
+    m = len(a) // 32
+    for op, name in enumerate(("mul", "add", "sub", "neg", "inv")):
+        out = ctypes.create_string_buffer(32 * m)
+        assert sim.sim_zp_op_batch(op, sz(m), a, b if op <= 2 else None, out) == 0
+        assert out.raw == cat(g["zp_" + name]), name

@@ -73,6 +73,9 @@ def test_points_outside_the_subgroup(orc):
     g = golden("g2")
     pts, sc = cat(g["offsubgroup_points"]), cat(g["offsubgroup_scalars"])
     assert orc.g2_mul(pts, sc, 192) == cat(g["offsubgroup_mul192"])
+    assert orc.g2_mul(cat(g["offsubgroup_small_points"]), cat(g["offsubgroup_small_scalars"]), 192) == cat(g["offsubgroup_small_mul192"])
+    g = golden("g1")
+    assert orc.g1_mul(cat(g["offsubgroup_small_points"]), cat(g["offsubgroup_small_scalars"]), 96) == cat(g["offsubgroup_small_mul96"])
 
 
 def test_g1_edge_semantics(orc):
@@ -151,3 +154,25 @@ def test_port_matches_reference_on_fresh_inputs(oracle_port, oracle_ref):
     assert oracle_port.g1_mul(pts, sc, 49, 2) == oracle_ref.g1_mul(pts, sc, 49, 2)
     assert oracle_port.g2_mul(q, sc, 97, 2) == oracle_ref.g2_mul(q, sc, 97, 2)
     assert oracle_port.pair(pts[:96 * 4], q[:192 * 4], 2) == oracle_ref.pair(pts[:96 * 4], q[:192 * 4], 2)
+
+
+def test_hash_to_g1_and_zp_golden(orc):
+    g = golden("hash_zp")
+    d = cat(g["digests"])
+    assert orc.g1_from_hash(d, 96) == cat(g["g1_from_hash_96"])
+    assert orc.g1_from_hash(d, 49) == cat(g["g1_from_hash_49"])
+    assert orc.zp_from_hash(d) == cat(g["zp_from_hash"])
+    a, b = cat(g["zp_a"]), cat(g["zp_b"])
+    for op in ("mul", "add", "sub", "neg", "inv"):
+        assert orc.zp_op(op, a, b if op in ("mul", "add", "sub") else None) == cat(g["zp_" + op]), op
+
+
+def test_zp_golden_against_python_ints():
+    g = golden("hash_zp")
+    for i, (x, y) in enumerate(zip(g["zp_a"], g["zp_b"])):
+        x, y = int(x, 16) % R, int(y, 16) % R
+        assert int(g["zp_mul"][i], 16) == x * y % R
+        assert int(g["zp_sub"][i], 16) == (x - y) % R
+        assert int(g["zp_inv"][i], 16) == pow(x, R - 2, R)
+    for dg, z in zip(g["digests"], g["zp_from_hash"]):
+        assert int(z, 16) == int(dg, 16) % R
