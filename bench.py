@@ -227,6 +227,19 @@ def main():
         extras["bbs_plus"] = {"metric": "BBS+ signature verifications/s (2^18 per GPU, 1 message block)", "value": world * nb * 2 / el,
                               "unit": "verifications/s", "ms_per_batch": el / 2 * 1e3}
         ctx.sync()
+        # hash-to-G1 from 2^20 digests; 2^20 scalar-field inversions; inner product of 2^22 pairs
+        nh = 1 << 20
+        dg = torch.from_numpy(np.frombuffer(make_scalars(6000 + rank, 2 * nh).tobytes(), dtype=np.uint8).copy()).to(dev)
+        ho = torch.empty(96 * nh, dtype=torch.uint8, device=dev)
+        el = timed_steps(lambda: ctx.g1_from_hash_dev(nh, dg.data_ptr(), ho.data_ptr(), 96), 2)
+        extras["hash_to_g1"] = {"metric": "hash-to-G1 points/s (2^20 SHA3-512 digests per GPU -> affine G1)", "value": world * nh * 2 / el,
+                                "unit": "points/s", "ms_per_batch": el / 2 * 1e3}
+        za = dg[: 32 * nh]
+        zo = torch.empty(32 * nh, dtype=torch.uint8, device=dev)
+        el = timed_steps(lambda: ctx.zp_op_dev("inv", nh, za.data_ptr(), None, zo.data_ptr()), 2)
+        extras["zp_inverse"] = {"metric": "scalar-field inversions/s (2^20 per GPU)", "value": world * nh * 2 / el, "unit": "inversions/s",
+                                "ms_per_batch": el / 2 * 1e3}
+        ctx.sync()
 
     # ---- parity (outside the timed region): sampled lanes vs the CPU oracle, all edge lanes included
     from oracle.bindings import Oracle, have_reference

@@ -269,6 +269,15 @@ class Context:
                                                            _p(m), _p(ok)))
 
     # ---- device-pointer entry points (ints = device addresses, e.g. torch tensor.data_ptr())
+    def g1_from_hash_dev(self, n, digests_ptr, out_ptr, fmt=96):
+        self._ck(self.lib.c12381_g1_from_hash_batch_dev(self.h, n, _p(digests_ptr), _p(out_ptr), fmt))
+
+    def zp_op_dev(self, op, n, a_ptr, b_ptr, out_ptr):
+        self._ck(self.lib.c12381_zp_op_batch_dev(self.h, self.ZP_OPS[op], n, _p(a_ptr), _p(b_ptr), _p(out_ptr)))
+
+    def zp_inner_product_dev(self, n, a_ptr, b_ptr, out_ptr):
+        self._ck(self.lib.c12381_zp_inner_product_dev(self.h, n, _p(a_ptr), _p(b_ptr), _p(out_ptr)))
+
     def g2_mul_dev(self, n, pts_ptr, sc_ptr, out_ptr, fmt=97):
         self._ck(self.lib.c12381_g2_mul_batch_dev(self.h, n, _p(pts_ptr), _p(sc_ptr), _p(out_ptr), fmt))
 

@@ -221,7 +221,7 @@ C12381_HDN void g1_mul_absx(g1p& p) {
 // The reference's glv() (pair_BLS12381.cpp:793-805) returns u1 = r - (k div x^2), and PAIR_G1mul's sign minimisation
 // (:899-906) maps that back to k div x^2 — except when k div x^2 == 0: then u1 stays r and ECP_mul2 adds [r]phi(P),
 // phi(P) = (beta x, y).  That term is the point at infinity for P in G1 and a point of the cofactor part otherwise.
-// Reproduced here (lanes with k < x^2 only, a divergent branch) so results agree with `multiply` on every curve point.
+// Reproduced (lanes with k < x^2 only; see scalar_below_x2) so results agree with `multiply` on every curve point.
 // phi(P) is in G1 iff phi(phi(P)) = [-x^2]phi(P); off the subgroup [r]Q = [x^2]([x^2]Q) - [x^2]Q + Q  (r = x^4 - x^2 + 1).
 C12381_HDN void g1_glv_small_scalar_term(g1p& acc, const g1p& base) {
     fp beta;
@@ -297,7 +297,18 @@ C12381_HD void g1_scalar_mul(g1p& acc, const fp& px, const fp& py, bool p_is_inf
         g1_add_digit(acc, lane_tab, glv_digit(kb0, w), false);
         g1_add_digit(acc, lane_tab, glv_digit(kb1, w), true);
     }
-    if ((k1[0] | k1[1] | k1[2] | k1[3]) == 0u) g1_glv_small_scalar_term(acc, base);
+}
+// k mod r < x^2, i.e. k div x^2 == 0: the lanes that owe g1_glv_small_scalar_term (evaluated by a separate, almost always
+// empty fix-up kernel so that the main loop's register allocation does not pay for the rare branch)
+C12381_HD bool scalar_below_x2(const uint32_t (&kin)[8]) {
+    uint32_t k[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) k[i] = kin[i];
+    scalar_mod_r(k);
+    uint64_t bw = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { uint64_t t = (uint64_t)k[i] - GLV_X2[i] - bw; bw = (t >> 32) & 1; }
+    return (k[4] | k[5] | k[6] | k[7]) == 0u && bw == 1;
 }
 
 // ------------------------------------------------------------------ affine output

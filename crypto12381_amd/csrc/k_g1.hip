@@ -74,6 +74,28 @@ __global__ void __launch_bounds__(BLOCK, 2) g1_mul_kernel(size_t n, const uint8_
     soa_store_g1(proj, proj_stride, proj_off + i, o);
 }
 
+// Fix-up pass after g1_mul_kernel: lanes whose scalar is below x^2 add the reference's [r]phi(P) term (g1.hpp).  Every
+// other lane — with random scalars: all of them — leaves after reading its scalar.
+__global__ void __launch_bounds__(BLOCK, 2) g1_small_scalar_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars,
+                                                                int32_t* proj, size_t proj_stride, size_t proj_off) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint32_t raw[8], k[8];
+    load_raw32(raw, scalars + 32 * i);
+    scalar_from_raw32(k, raw);
+    if (!scalar_below_x2(k)) return;
+    g1p base, acc;
+    bool inf, ok;
+    g1_parse96(base.x, base.y, inf, ok, pts + pt_stride * i);
+    if (inf || !ok) return;
+    fp_one(base.z);
+    soa_load_g1(acc, proj, proj_stride, proj_off + i);
+    g1_glv_small_scalar_term(acc, base);
+    g1p o;
+    g1_norm1(o, acc);
+    soa_store_g1(proj, proj_stride, proj_off + i, o);
+}
+
 __global__ void __launch_bounds__(BLOCK, 2) g1_add_kernel(size_t n, const uint8_t* a, const uint8_t* b, int32_t* proj, size_t proj_stride,
                                                        int* bad_flag) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;

@@ -19,6 +19,7 @@ constexpr int TRI_PER_WAVE = 21;                 // pairings per 64-lane wave in
 __global__ void __launch_bounds__(BLOCK, 2) fp_op_kernel(int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out);
 __global__ void __launch_bounds__(BLOCK, 2) fp_mulchain_kernel(size_t n, int iters, const uint8_t* a, const uint8_t* b, uint8_t* out);
 __global__ void __launch_bounds__(BLOCK, 2) g1_mul_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab, int32_t* proj, size_t proj_stride, size_t proj_off, int* bad_flag);
+__global__ void __launch_bounds__(BLOCK, 2) g1_small_scalar_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* proj, size_t proj_stride, size_t proj_off);
 __global__ void __launch_bounds__(BLOCK, 2) g1_add_kernel(size_t n, const uint8_t* a, const uint8_t* b, int32_t* proj, size_t proj_stride, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) g1_finish_kernel(size_t n, const int32_t* proj, size_t stride, int32_t* pref, uint8_t* out, int fmt, size_t T);
 __global__ void __launch_bounds__(BLOCK, 2) g1_reduce_kernel(size_t n, const int32_t* in, size_t in_stride, size_t m, int32_t* outp, size_t out_stride);

@@ -55,6 +55,13 @@ int sim_g1_mul_batch(size_t n, const uint8_t* pts96, const uint8_t* scalars32, u
         scalar_from_raw32(k, rs);
         g1p acc;
         g1_scalar_mul(acc, px, py, inf, k, tab);
+        if (scalar_below_x2(k) && !inf) {                 // g1_small_scalar_kernel
+            g1p base, n;
+            base.x = px; base.y = py; fp_one(base.z);
+            g1_norm1(n, acc);
+            g1_glv_small_scalar_term(n, base);
+            acc = n;
+        }
         uint8_t* o = out + (size_t)fmt * i;
         if (g1_is_inf(acc)) { std::memset(o, 0, fmt); continue; }
         fp zn, zi, ax, ay;
