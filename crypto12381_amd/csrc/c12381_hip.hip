@@ -29,7 +29,8 @@ struct c12381_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t side = nullptr;           // rare fix-up passes run here, overlapped with the next chunk on `stream`
-    hipEvent_t ev_main = nullptr, ev_side = nullptr;
+    hipEvent_t ev_side = nullptr;
+    std::vector<hipEvent_t> ev_chunk;     // one per chunk of a scalar-mul batch (main -> side dependencies)
     char err[256] = {0};
     enum { WS_TAB, WS_PROJ, WS_PREF, WS_IN0, WS_IN1, WS_OUT, WS_RED0, WS_RED1, WS_BBS_Q, WS_BBS_B, WS_BBS_IN,
            WS_MSM_PTS, WS_MSM_K0, WS_MSM_K1, WS_MSM_V0, WS_MSM_V1, WS_MSM_TMP, WS_MSM_RNG, WS_MSM_BK, WS_COUNT };
@@ -99,8 +100,14 @@ int g1_mul_to_proj(c12381_ctx* c, size_t n, const uint8_t* d_pts, const uint8_t*
         }
         // the reference's small-scalar term (g1.hpp) for this chunk: empty unless some k mod r < x^2, and then a few lanes
         // at single-wavefront latency (~1 ms) — on the side stream, so it overlaps the next chunk
-        HIPCK(c, hipEventRecord(c->ev_main, c->stream));
-        HIPCK(c, hipStreamWaitEvent(c->side, c->ev_main, 0));
+        const size_t ci = off / chunk;
+        while (c->ev_chunk.size() <= ci) {
+            hipEvent_t e;
+            HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c->ev_chunk.push_back(e);
+        }
+        HIPCK(c, hipEventRecord(c->ev_chunk[ci], c->stream));
+        HIPCK(c, hipStreamWaitEvent(c->side, c->ev_chunk[ci], 0));
         hipLaunchKernelGGL(g1_small_scalar_kernel, dim3(grid_for(m)), dim3(BLOCK), 0, c->side, m, d_pts + pt_stride * off, pt_stride, d_sc + 32 * off,
                            (int32_t*)c->ws[c12381_ctx::WS_PROJ], stride, proj_off + off);
         HIPCK(c, hipGetLastError());
@@ -226,7 +233,7 @@ int c12381_create(int device, c12381_ctx** out) {
     c->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return C12381_E_HIP; }
     c->own_stream = true;
-    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) != hipSuccess ||
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming) != hipSuccess) { c12381_destroy(c); return C12381_E_HIP; }
     if (hipMalloc((void**)&c->d_flag, sizeof(int)) != hipSuccess || hipHostMalloc((void**)&c->h_flag, sizeof(int)) != hipSuccess ||
         hipMemset(c->d_flag, 0, sizeof(int)) != hipSuccess) { c12381_destroy(c); return C12381_E_HIP; }
@@ -244,7 +251,7 @@ void c12381_destroy(c12381_ctx* c) {
     if (c->h_flag) (void)hipHostFree(c->h_flag);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     if (c->side) (void)hipStreamDestroy(c->side);
-    if (c->ev_main) (void)hipEventDestroy(c->ev_main);
+    for (hipEvent_t e : c->ev_chunk) (void)hipEventDestroy(e);
     if (c->ev_side) (void)hipEventDestroy(c->ev_side);
     delete c;
 }

@@ -53,16 +53,23 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_kernel(size_t n, const uint
     if ((((size_t)blockIdx.x * BLOCK + threadIdx.x) >> 6) * TRI_PER_WAVE >= n) return;
     tri t; size_t i; bool active;
     tri_setup(t, i, active, n);
-    fp px, py; fp2 qx, qy; bool pinf, qinf, ok, okb;
-    fp4 F, G, Gc;
+    // e(a1, a2) == e(b1, b2)  <=>  e(a1, a2) * e(-b1, b2) == 1: one joint Miller loop (shared squarings), one final
+    // exponentiation.  liner_pair.hpp:339-350 forms ate(a) * conj(ate(b)) from two separate loops; after the final
+    // exponentiation both are e(a) / e(b) (conj and negating the G1 argument both invert the pairing value; the
+    // Miller values differ by factors in Fp6, which the easy part kills), so the boolean is the same for all
+    // curve points, infinity arguments included.
+    fp px, py, px2, py2; fp2 qx, qy, qx2, qy2; bool pinf, qinf, pinf2, qinf2, ok, okb;
+    fp4 F;
     pair_inputs(px, py, pinf, qx, qy, qinf, ok, a1 + 96 * i, a2 + 192 * i);
     if (!ok) { pinf = true; qinf = true; }
-    miller3_loop(F, px, py, pinf, qx, qy, qinf, t);
-    pair_inputs(px, py, pinf, qx, qy, qinf, okb, b1 + 96 * i, b2 + b2_stride * i);
-    if (!okb) { pinf = true; qinf = true; }
-    miller3_loop(G, px, py, pinf, qx, qy, qinf, t);
-    f12t_conj(Gc, G, t);
-    f12t_mul(F, F, Gc, t);
+    pair_inputs(px2, py2, pinf2, qx2, qy2, qinf2, okb, b1 + 96 * i, b2 + b2_stride * i);
+    if (!okb) { pinf2 = true; qinf2 = true; }
+    {
+        fp ny;
+        fp_neg(ny, py2);
+        fp_norm1(py2, ny);
+    }
+    miller3_loop2(F, px, py, pinf, qx, qy, qinf, px2, py2, pinf2, qx2, qy2, qinf2, t);
     f12t_final_exp(F, t);
     const bool one = f12t_is_one(F, t);
     const bool valid = ok && okb;

@@ -316,4 +316,59 @@ C12381_HDN void miller3_loop(fp4& F, const fp& px, const fp& py, bool p_inf, con
     fp4_select(F, p_inf, (t.role == 0 ? one4 : zero4), c);
 }
 
+// Two Miller loops with SHARED squarings: F = conj(M(Q1, P1) * M(Q2, P2)) — the product the reference forms from two
+// pair_ate results (liner_pair.hpp:339-350) costs one Fp12 squaring per iteration instead of two.  As a field element
+// the result is exactly the product of the two single-loop values (f <- f^2 * l distributes over the product).
+// A pair whose G1 argument is infinity contributes 1 (PAIR_ate :448-449): its lines are replaced by the identity.
+C12381_HDN void miller3_loop2(fp4& F, const fp& px1, const fp& py1, bool p_inf1, const fp2& qx1, const fp2& qy1, bool q_inf1,
+                              const fp& px2, const fp& py2, bool p_inf2, const fp2& qx2, const fp2& qy2, bool q_inf2, const tri& t) {
+    g2p Q1, Q2, inf;
+    g2_set_inf(inf);
+    Q1.x = qx1; Q1.y = qy1; fp2_one(Q1.z);
+    Q2.x = qx2; Q2.y = qy2; fp2_one(Q2.z);
+    fp2_select(Q1.x, q_inf1, inf.x, Q1.x); fp2_select(Q1.y, q_inf1, inf.y, Q1.y); fp2_select(Q1.z, q_inf1, inf.z, Q1.z);
+    fp2_select(Q2.x, q_inf2, inf.x, Q2.x); fp2_select(Q2.y, q_inf2, inf.y, Q2.y); fp2_select(Q2.z, q_inf2, inf.z, Q2.z);
+    fp2 tc1, tc2, one2, zero2;
+    fp2_one(one2); fp2_zero(zero2);
+    fp2_select(tc1, t.role == 0, Q1.x, Q1.y); fp2_select(tc1, t.role == 2, Q1.z, tc1);
+    fp2_select(tc2, t.role == 0, Q2.x, Q2.y); fp2_select(tc2, t.role == 2, Q2.z, tc2);
+    fp4 one4, zero4;
+    fp4_zero(zero4); one4 = zero4; fp_one(one4.a.a);
+    fp4_select(F, t.role == 0, one4, zero4);
+    constexpr unsigned __int128 N1 = (unsigned __int128)BLS_X;
+    constexpr unsigned __int128 N3 = N1 * 3;
+#pragma unroll 1
+    for (int i = 64; i >= 1; --i) {
+        f12t_sqr(F, F, t);
+        fp2 l0, l1, l2;
+        miller3_dbl_step(tc1, l0, l1, l2, px1, py1, t);
+        fp2_select(l0, p_inf1, one2, l0); fp2_select(l1, p_inf1, zero2, l1); fp2_select(l2, p_inf1, zero2, l2);
+        f12t_mul_line(F, l0, l1, l2, t);
+        miller3_dbl_step(tc2, l0, l1, l2, px2, py2, t);
+        fp2_select(l0, p_inf2, one2, l0); fp2_select(l1, p_inf2, zero2, l1); fp2_select(l2, p_inf2, zero2, l2);
+        f12t_mul_line(F, l0, l1, l2, t);
+        const int bt = (int)((N3 >> i) & 1) - (int)((N1 >> i) & 1);
+        if (bt != 0) {                                     // wave-uniform; 5 of 64 iterations
+            g2p T, S;
+            S = Q1;
+            tri_fetch_fp2(T.x, tc1, 0, t); tri_fetch_fp2(T.y, tc1, 1, t); tri_fetch_fp2(T.z, tc1, 2, t);
+            if (bt < 0) g2_neg(S, Q1);
+            miller_add_step(T, S, l0, l1, l2, px1, py1);
+            fp2_select(tc1, t.role == 0, T.x, T.y); fp2_select(tc1, t.role == 2, T.z, tc1);
+            fp2_select(l0, p_inf1, one2, l0); fp2_select(l1, p_inf1, zero2, l1); fp2_select(l2, p_inf1, zero2, l2);
+            f12t_mul_line(F, l0, l1, l2, t);
+            S = Q2;
+            tri_fetch_fp2(T.x, tc2, 0, t); tri_fetch_fp2(T.y, tc2, 1, t); tri_fetch_fp2(T.z, tc2, 2, t);
+            if (bt < 0) g2_neg(S, Q2);
+            miller_add_step(T, S, l0, l1, l2, px2, py2);
+            fp2_select(tc2, t.role == 0, T.x, T.y); fp2_select(tc2, t.role == 2, T.z, tc2);
+            fp2_select(l0, p_inf2, one2, l0); fp2_select(l1, p_inf2, zero2, l1); fp2_select(l2, p_inf2, zero2, l2);
+            f12t_mul_line(F, l0, l1, l2, t);
+        }
+    }
+    fp4 c;
+    f12t_conj(c, F, t);
+    F = c;
+}
+
 }  // namespace c12381

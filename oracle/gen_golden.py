@@ -183,6 +183,19 @@ def main():
     eq_b2 = xQ + xQ[:192] + q1
     pj["eq_a1"], pj["eq_a2"], pj["eq_b1"], pj["eq_b2"] = hx(eq_a1, 96), hx(eq_a2, 192), hx(eq_b1, 96), hx(eq_b2, 192)
     pj["eq"] = list(ref.pair_eq(eq_a1, eq_a2, eq_b1, eq_b2))
+    # equality, degenerate and adversarial rows: infinity on one side only, both sides trivial, negated arguments,
+    # identical arguments, points outside the subgroups (the reference checks none of this, it just evaluates)
+    def neg1(pt):
+        y = int.from_bytes(pt[48:], "big")
+        return pt[:48] + ((P - y) % P).to_bytes(48, "big")
+    Pa, Pb, Qa, Qb = pts[:96], pts[96:192], pts2[:192], pts2[192:384]
+    offp, offq = off[:96], off2[:192]
+    rows = [(Pa, inf2, inf1, Qa), (Pa, inf2, Pa, Qa), (inf1, Qa, Pa, Qa), (Pa, Qa, Pa, Qa), (Pa, Qa, neg1(Pa), neg2(Qa)),
+            (Pa, Qa, neg1(Pa), Qa), (Pa, Qa, Pb, Qa), (offp, Qa, offp, Qa), (offp, Qa, Pa, Qa), (Pa, offq, Pa, offq),
+            (Pa, offq, Pb, offq), (offp, offq, neg1(offp), neg2(offq)), (inf1, inf2, Pa, inf2), (Pa, Qb, Pb, Qa)]
+    e1, e2, e3, e4 = (b"".join(r[k] for r in rows) for k in range(4))
+    pj["eq2_a1"], pj["eq2_a2"], pj["eq2_b1"], pj["eq2_b2"] = hx(e1, 96), hx(e2, 192), hx(e3, 96), hx(e4, 192)
+    pj["eq2"] = list(ref.pair_eq(e1, e2, e3, e4))
     # GT ops
     gta, gtb = gt[:576 * 4], gt[576 * 4:]
     pj["gt_mul"] = hx(ref.gt_op("mul", gta, gtb), 576)

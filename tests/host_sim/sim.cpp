@@ -286,17 +286,16 @@ void* tri3_worker(void* arg) {
         fp px, py; fp2 qx, qy; bool pinf, qinf;
         fp4 F;
         pair_load(px, py, pinf, qx, qy, qinf, jb->a1 + 96 * i, jb->a2 + 192 * i);
-        miller3_loop(F, px, py, pinf, qx, qy, qinf, t);
-        if (jb->mode == 1) {          // equality: f * conj(g), one final exponentiation, is-unity
-            fp4 G, Gc;
-            pair_load(px, py, pinf, qx, qy, qinf, jb->b1 + 96 * i, jb->b2 + 192 * i);
-            miller3_loop(G, px, py, pinf, qx, qy, qinf, t);
-            f12t_conj(Gc, G, t);
-            f12t_mul(F, F, Gc, t);
+        if (jb->mode == 1) {          // equality as pair3_eq_kernel evaluates it: joint loop on (a1, a2), (-b1, b2)
+            fp px2, py2, ny; fp2 qx2, qy2; bool pinf2, qinf2;
+            pair_load(px2, py2, pinf2, qx2, qy2, qinf2, jb->b1 + 96 * i, jb->b2 + 192 * i);
+            fp_neg(ny, py2); fp_norm1(py2, ny);
+            miller3_loop2(F, px, py, pinf, qx, qy, qinf, px2, py2, pinf2, qx2, qy2, qinf2, t);
             f12t_final_exp(F, t);
             const bool ok = f12t_is_one(F, t);
             if (jb->role == 0) jb->out[i] = ok ? 1 : 0;
         } else {
+            miller3_loop(F, px, py, pinf, qx, qy, qinf, t);
             f12t_final_exp(F, t);
             gt_store_coeff(jb->out + 576 * i, F, jb->role);
         }

@@ -39,6 +39,7 @@ def test_pairing_golden(ctx):
     gt = ctx.pair(g1, g2)
     assert gt == cat(g["gt"])
     assert list(ctx.pair_eq(cat(g["eq_a1"]), cat(g["eq_a2"]), cat(g["eq_b1"]), cat(g["eq_b2"]))) == g["eq"]
+    assert list(ctx.pair_eq(cat(g["eq2_a1"]), cat(g["eq2_a2"]), cat(g["eq2_b1"]), cat(g["eq2_b2"]))) == g["eq2"]
 
 
 def test_config1_bilinearity_on_gpu(ctx):

@@ -143,6 +143,11 @@ def test_sim_pairing_golden(sim):
     ok = ctypes.create_string_buffer(m)
     assert sim.sim_pair_eq_batch(sz(m), a1, a2, b1, b2, ok) == 0
     assert list(ok.raw[:m]) == g["eq"]
+    a1, a2, b1, b2 = cat(g["eq2_a1"]), cat(g["eq2_a2"]), cat(g["eq2_b1"]), cat(g["eq2_b2"])
+    m = len(a1) // 96
+    ok = ctypes.create_string_buffer(m)
+    assert sim.sim_pair_eq_batch(sz(m), a1, a2, b1, b2, ok) == 0
+    assert list(ok.raw[:m]) == g["eq2"]
 
 
 def test_sim_decompress(sim):
@@ -193,6 +198,12 @@ def test_sim_pairing_three_lanes(sim):
     ok = ctypes.create_string_buffer(m)
     assert sim.sim_pair3_eq_batch(sz(m), a1, a2, b1, b2, ok) == 0
     assert list(ok.raw[:m]) == g["eq"]
+    # degenerate / adversarial rows through the joint Miller loop (one-sided infinity, negated and off-subgroup arguments)
+    a1, a2, b1, b2 = cat(g["eq2_a1"]), cat(g["eq2_a2"]), cat(g["eq2_b1"]), cat(g["eq2_b2"])
+    m = len(a1) // 96
+    ok = ctypes.create_string_buffer(m)
+    assert sim.sim_pair3_eq_batch(sz(m), a1, a2, b1, b2, ok) == 0
+    assert list(ok.raw[:m]) == g["eq2"]
 
 
 def test_sim_msm_pippenger(sim, oracle_port):

@@ -118,6 +118,7 @@ def test_pairing_golden(orc):
     a1, a2, b1, b2 = g1[:96 * 4], g2[:192 * 4], g1[96 * 4:], g2[192 * 4:]
     assert orc.pair2(a1, a2, b1, b2) == cat(g["pair2"])
     assert list(orc.pair_eq(cat(g["eq_a1"]), cat(g["eq_a2"]), cat(g["eq_b1"]), cat(g["eq_b2"]))) == g["eq"]
+    assert list(orc.pair_eq(cat(g["eq2_a1"]), cat(g["eq2_a2"]), cat(g["eq2_b1"]), cat(g["eq2_b2"]))) == g["eq2"]
     gta, gtb = gt[:576 * 4], gt[576 * 4:]
     assert orc.gt_op("mul", gta, gtb) == cat(g["gt_mul"])
     assert orc.gt_op("conj", gta) == cat(g["gt_conj"])
