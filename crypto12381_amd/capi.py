@@ -62,6 +62,7 @@ def load_library() -> ctypes.CDLL:
         lib.c12381_gt_is_unity_batch.argtypes = [vp, sz, vp, vp]
         for name in ("c12381_g1_from_hash_batch", "c12381_g1_from_hash_batch_dev"):
             getattr(lib, name).argtypes = [vp, sz, vp, vp, ci]
+        lib.c12381_g1_msm_multi.argtypes = [ctypes.POINTER(vp), ci, sz, vp, vp, vp, ci]
         lib.c12381_g1_map_to_point_batch.argtypes = [vp, sz, vp, vp]
         lib.c12381_g1_clear_cofactor_batch.argtypes = [vp, sz, vp, vp]
         for name in ("c12381_zp_op_batch", "c12381_zp_op_batch_dev"):
@@ -298,3 +299,15 @@ class Context:
 
     def g1_msm_dev(self, n, pts_ptr, sc_ptr, out_ptr, fmt=49):
         self._ck(self.lib.c12381_g1_msm_dev(self.h, n, _p(pts_ptr), _p(sc_ptr), _p(out_ptr), fmt))
+
+
+def g1_msm_multi(contexts, pts: bytes, scalars: bytes, fmt: int = 49) -> bytes:
+    """c12381_g1_msm_multi: one host process, one Context per GPU."""
+    lib = contexts[0].lib
+    n = len(pts) // 96
+    arr = (ctypes.c_void_p * len(contexts))(*[c.h for c in contexts])
+    out = ctypes.create_string_buffer(fmt)
+    rc = lib.c12381_g1_msm_multi(arr, len(contexts), n, _p(pts), _p(scalars), _p(out), fmt)
+    if rc != 0:
+        raise C12381Error(rc, "c12381_g1_msm_multi")
+    return out.raw[:fmt]

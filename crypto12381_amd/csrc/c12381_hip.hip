@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/c12381_hip.h"
@@ -391,6 +392,26 @@ int c12381_g1_msm(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc
     if ((rc = c12381_g1_msm_dev(c, n, s.in0, s.in1, s.out, fmt))) return rc;
     if ((rc = stage_out(c, s, out, (size_t)fmt))) return rc;
     return read_flag(c);
+}
+// One host process driving several GPUs: terms are split contiguously over the contexts, every
+// context runs its local MSM on its own device from its own host thread, and the partial points (96 B each) are
+// summed on the first context — the elliptic-curve "all-reduce" has no RCCL reduction op, the payload is ngpu x 96 B.
+// (One process per GPU with torch.distributed does the same through an all-gather: crypto12381_amd/distributed.py.)
+int c12381_g1_msm_multi(c12381_ctx** ctxs, int ngpu, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
+    if (!ctxs || ngpu <= 0 || !out || (n && (!pts || !sc)) || (fmt != 49 && fmt != 96)) return C12381_E_ARG;
+    for (int g = 0; g < ngpu; ++g) if (!ctxs[g]) return C12381_E_ARG;
+    if (ngpu == 1) return c12381_g1_msm(ctxs[0], n, pts, sc, out, fmt);
+    std::vector<uint8_t> partial((size_t)96 * ngpu, 0), ones((size_t)32 * ngpu, 0);
+    std::vector<int> rcs(ngpu, 0);
+    std::vector<std::thread> th;
+    for (int g = 0; g < ngpu; ++g) {
+        const size_t lo = n * (size_t)g / (size_t)ngpu, hi = n * (size_t)(g + 1) / (size_t)ngpu;
+        ones[(size_t)32 * g + 31] = 1;
+        th.emplace_back([=, &partial, &rcs] { rcs[g] = c12381_g1_msm(ctxs[g], hi - lo, pts + 96 * lo, sc + 32 * lo, &partial[(size_t)96 * g], 96); });
+    }
+    for (auto& t : th) t.join();
+    for (int g = 0; g < ngpu; ++g) if (rcs[g]) return rcs[g];
+    return c12381_g1_msm(ctxs[0], (size_t)ngpu, partial.data(), ones.data(), out, fmt);
 }
 
 // ---------------------------------------------------------------- G2

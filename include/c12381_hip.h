@@ -85,6 +85,10 @@ int c12381_g1_add_batch(c12381_ctx* ctx, size_t n, const uint8_t* a96, const uin
  * sum_of_products(point1&, int, point1*, const big*) :134-137 -> ECP_muln). */
 int c12381_g1_msm(c12381_ctx* ctx, size_t n, const uint8_t* pts96, const uint8_t* scalars32, uint8_t* out, int out_fmt);
 int c12381_g1_msm_dev(c12381_ctx* ctx, size_t n, const uint8_t* pts96, const uint8_t* scalars32, uint8_t* out, int out_fmt);
+/* the same product over several GPUs driven by ONE host process: terms split contiguously over ctxs[0..ngpu-1] (one
+ * context per device, created by the caller), local MSMs run concurrently, the ngpu partial points are summed on
+ * ctxs[0] (the combine is an elliptic-curve addition, 96 B per GPU). */
+int c12381_g1_msm_multi(c12381_ctx** ctxs, int ngpu, size_t n, const uint8_t* points96, const uint8_t* scalars32, uint8_t* out, int out_fmt);
 
 /* G2 ------------------------------------------------------------------------------------- */
 /* out[i] = scalars[i] * pts[i].  Batched multiply(point2&, const big&) (miracl_core_interface.hpp:152,

@@ -58,3 +58,26 @@ def test_msm_sharded_two_ranks_on_gpu(oracle_port):
         assert p.exitcode == 0
     got = dict(q.get(timeout=5) for _ in range(2))
     assert got == {0: True, 1: True}
+
+
+def test_msm_multi_one_process_several_contexts(oracle_port):
+    """c12381_g1_msm_multi: one host process, one context per GPU; on the one-GPU test box the three contexts share
+    device 0 (separate streams and workspaces), which exercises the same splitting, threading and combine."""
+    from crypto12381_amd import Context
+    from crypto12381_amd.capi import g1_msm_multi
+    n = 9001                                       # 3 shards, bucket path in each (>= 2^12 would need 12288; mixed paths below)
+    g1 = bytes.fromhex(golden("g1")["generator"])
+    ctxs = [Context(0) for _ in range(3)]
+    pts = ctxs[0].g1_mul(g1 * n, scalars(611, n), 96)
+    sc = scalars(612, n)
+    expect = oracle_port.g1_msm(pts, sc, 49, 16)
+    assert g1_msm_multi(ctxs, pts, sc, 49) == expect
+    assert g1_msm_multi(ctxs[:1], pts, sc, 49) == expect
+    m = 3 * 5000                                   # every shard above the bucket threshold
+    pts2 = (pts * 2)[:96 * m]
+    sc2 = scalars(613, m)
+    assert g1_msm_multi(ctxs, pts2, sc2, 96) == ctxs[1].g1_msm(pts2, sc2, 96)
+    assert g1_msm_multi(ctxs, pts[:96 * 2], sc[:64], 49) == oracle_port.g1_msm(pts[:96 * 2], sc[:64], 49, 1)   # a shard with 0 terms
+    assert g1_msm_multi(ctxs, b"", b"", 49) == bytes(49)
+    for c in ctxs:
+        c.close()
