@@ -22,6 +22,13 @@ using namespace c12381;
 namespace {
 constexpr size_t G1_CHUNK = (size_t)1 << 17;     // elements per scalar-mul launch = resident lanes at 2 waves/SIMD; table slab 176 MiB (fits the 256 MiB Infinity Cache)
 constexpr size_t G2_CHUNK = (size_t)1 << 17;     // G2 table slab = 352 MiB (2688-byte record per lane)
+// terms per bucket-method pass (2 * n * windows sort items < 2^31); C12381_MSM_MAX_TERMS lowers it so that tests reach
+// the multi-part path with small inputs
+const size_t MSM_MAX_TERMS = [] {
+    const char* e = std::getenv("C12381_MSM_MAX_TERMS");
+    const size_t v = e ? (size_t)std::strtoull(e, nullptr, 10) : 0;
+    return v >= 64 && v < ((size_t)1 << 26) ? v : (size_t)1 << 26;
+}();
 }  // namespace
 
 // ====================================================================== host side
@@ -367,6 +374,23 @@ int c12381_g1_msm_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t
     int rc = bind(c); if (rc) return rc;
     if (!out || (n && (!pts || !sc)) || (fmt != 49 && fmt != 96)) return C12381_E_ARG;
     if (n == 0) { HIPCK(c, hipMemsetAsync(out, 0, fmt, c->stream)); return 0; }
+    if (n > MSM_MAX_TERMS) {
+        // the sort works on 32-bit item counts and (term, half) values: larger products are cut into parts whose
+        // partial points (affine, WS_BBS_B as a small staging slot) are summed by a second, tiny product with unit scalars
+        const size_t parts = (n + MSM_MAX_TERMS - 1) / MSM_MAX_TERMS;
+        if ((rc = ensure(c, c12381_ctx::WS_BBS_B, round_up(parts * 128, 256)))) return rc;
+        uint8_t* pp = (uint8_t*)c->ws[c12381_ctx::WS_BBS_B];
+        uint8_t* ones = pp + round_up(parts * 96, 32);
+        std::vector<uint8_t> h1(parts * 32, 0);
+        for (size_t p = 0; p < parts; ++p) h1[32 * p + 31] = 1;
+        HIPCK(c, hipMemcpyAsync(ones, h1.data(), h1.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));              // h1 goes out of scope below
+        for (size_t p = 0; p < parts; ++p) {
+            const size_t lo = p * MSM_MAX_TERMS, m = n - lo < MSM_MAX_TERMS ? n - lo : MSM_MAX_TERMS;
+            if ((rc = g1_msm_pippenger(c, m, pts + 96 * lo, sc + 32 * lo, pp + 96 * p, 96))) return rc;
+        }
+        return c12381_g1_msm_dev(c, parts, pp, ones, out, fmt);
+    }
     if (msm_use_buckets(n)) return g1_msm_pippenger(c, n, pts, sc, out, fmt);
     const size_t stride = round_up(n, 64);
     if ((rc = g1_mul_to_proj(c, n, pts, sc, stride))) return rc;

@@ -81,3 +81,28 @@ def test_msm_multi_one_process_several_contexts(oracle_port):
     assert g1_msm_multi(ctxs, b"", b"", 49) == bytes(49)
     for c in ctxs:
         c.close()
+
+
+def test_msm_in_parts(oracle_port):
+    """Products above the per-pass limit are cut into parts (limit lowered through the environment in a child process)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, 'tests'); sys.path.insert(0, '.')\n"
+        "from util import golden, scalars\n"
+        "from crypto12381_amd import Context\n"
+        "g1 = bytes.fromhex(golden('g1')['generator']); n = 11000\n"
+        "c = Context(0); pts = c.g1_mul(g1 * n, scalars(621, n), 96); sc = scalars(622, n)\n"
+        "print(c.g1_msm(pts, sc, 49).hex())\n")
+    env = dict(os.environ)
+    ref = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1]
+    env["C12381_MSM_MAX_TERMS"] = "4500"
+    parts = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1]
+    assert parts == ref
+    from crypto12381_amd import Context
+    g1 = bytes.fromhex(golden("g1")["generator"])
+    c = Context(0)
+    n = 11000
+    pts, sc = c.g1_mul(g1 * n, scalars(621, n), 96), scalars(622, n)
+    c.close()
+    assert ref == oracle_port.g1_msm(pts, sc, 49, 16).hex()
