@@ -14,7 +14,10 @@ UNITS = ["c12381_hip.hip", "k_g1.hip", "k_g2gt.hip", "k_pair3.hip", "k_hash_zp.h
 LIB = os.path.join(HERE, "lib", "libc12381_hip.so")
 OBJ = os.path.join(HERE, "lib", "obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-CFLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17"]
+# -fno-optimize-sibling-calls: LLVM drops the "callee saves nothing" treatment of an internal function as soon as one
+# call site carries a `tail` marker (which every call passing only non-stack pointers gets); without the marker the
+# big out-of-line field routines do not save ~65 callee-saved VGPRs in their prologues (130 scratch instructions a call)
+CFLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-fno-optimize-sibling-calls"]
 
 
 def _headers():

@@ -28,6 +28,11 @@ __device__ __forceinline__ void gt_store_coeff(uint8_t* o576, const fp4& x, int 
     fp_to_raw48(raw, x.a.a); store_raw48(o + 144, raw);
 }
 
+// One Fp4 per lane in LDS (240-byte stride: 16-byte aligned, lanes spread over the banks): the running Miller value and
+// the accumulator of the exponentiations by x live here, so the out-of-line tower routines read and write their hot
+// operand at LDS latency.  60 KB per workgroup, two workgroups per CU.
+struct alignas(16) fp4_slot { fp4 v; int32_t pad[4]; };
+
 }  // namespace
 
 namespace c12381 {
@@ -39,9 +44,11 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_kernel(size_t n, const uint8_t
     fp px, py; fp2 qx, qy; bool pinf, qinf, ok;
     pair_inputs(px, py, pinf, qx, qy, qinf, ok, g1 + 96 * i, g2 + 192 * i);
     if (!ok) { if (active) *bad_flag = 1; pinf = true; qinf = true; }
-    fp4 F;
-    miller3_loop(F, px, py, pinf, qx, qy, qinf, t);
-    f12t_final_exp(F, t);
+    __shared__ fp4_slot slots[BLOCK];
+    fp4& H = slots[threadIdx.x].v;
+    miller3_loop(H, px, py, pinf, qx, qy, qinf, t);
+    fp4 F = H;
+    f12t_final_exp_ws(F, H, t);
     if (active) {
         if (!ok) { uint4* q = reinterpret_cast<uint4*>(gt + 576 * i + (t.role == 0 ? 384 : (t.role == 1 ? 192 : 0))); for (int j = 0; j < 12; ++j) q[j] = make_uint4(~0u, ~0u, ~0u, ~0u); }
         else gt_store_coeff(gt + 576 * i, F, t.role);
@@ -59,7 +66,8 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_kernel(size_t n, const uint
     // Miller values differ by factors in Fp6, which the easy part kills), so the boolean is the same for all
     // curve points, infinity arguments included.
     fp px, py, px2, py2; fp2 qx, qy, qx2, qy2; bool pinf, qinf, pinf2, qinf2, ok, okb;
-    fp4 F;
+    __shared__ fp4_slot slots[BLOCK];
+    fp4& H = slots[threadIdx.x].v;
     pair_inputs(px, py, pinf, qx, qy, qinf, ok, a1 + 96 * i, a2 + 192 * i);
     if (!ok) { pinf = true; qinf = true; }
     pair_inputs(px2, py2, pinf2, qx2, qy2, qinf2, okb, b1 + 96 * i, b2 + b2_stride * i);
@@ -69,8 +77,9 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_kernel(size_t n, const uint
         fp_neg(ny, py2);
         fp_norm1(py2, ny);
     }
-    miller3_loop2(F, px, py, pinf, qx, qy, qinf, px2, py2, pinf2, qx2, qy2, qinf2, t);
-    f12t_final_exp(F, t);
+    miller3_loop2(H, px, py, pinf, qx, qy, qinf, px2, py2, pinf2, qx2, qy2, qinf2, t);
+    fp4 F = H;
+    f12t_final_exp_ws(F, H, t);
     const bool one = f12t_is_one(F, t);
     const bool valid = ok && okb;
     if (active && t.role == 0) {

@@ -63,26 +63,34 @@ C12381_HD void fp4_mul_core(fp4& w, const fp4& x, const fp4& y) {
 // combine step shared by product and square: given this lane's z = x_r y_r and e = x_r y_{r+1} + x_{r+1} y_r,
 //   w_a = z_a + s e_b,   w_b = e_a + s z_c,   w_c = e_c + z_b
 C12381_HD void f12t_combine(fp4& w, const fp4& z, const fp4& zn, const fp4& e, const tri& t) {
-    fp4 v1, v2, sa, sb, ra, rb, rc, r;
+    // role a: z + s e_b;  role b: e_a + s z_c (= s zn);  role c: e + z_b   ==   P + (role c ? Q : s Q)
+    fp4 v1, v2, P, Q, sQ, r;
     const int s1 = t.role == 0 ? tri_next(t) : (t.role == 1 ? tri_prev(t) : t.role);
     tri_fetch_fp4(v1, e, s1, t);                         // a <- e_b, b <- e_a
     const int s2 = t.role == 2 ? tri_prev(t) : t.role;
     tri_fetch_fp4(v2, z, s2, t);                         // c <- z_b
-    fp4_times_i(sa, v1); fp4_add(ra, z, sa);
-    fp4_times_i(sb, zn); fp4_add(rb, v1, sb);
-    fp4_add(rc, e, v2);
-    fp4_select(r, t.role == 0, ra, rb);
-    fp4_select(r, t.role == 2, rc, r);
+    fp4_select(P, t.role == 0, z, v1); fp4_select(P, t.role == 2, e, P);
+    fp4_select(Q, t.role == 0, v1, zn); fp4_select(Q, t.role == 2, v2, Q);
+    fp4_times_i(sQ, Q);
+    fp4_select(Q, t.role == 2, Q, sQ);
+    fp4_add(r, P, Q);
     fp4_norm1(w, r);
 }
+// One Fp4 product as a real call: an Fp4 product alone fills the 256-VGPR budget (two operands, four Fp2 temporaries,
+// the column accumulators), so keeping a second pair of operands alive across it costs ~600 single-dword spills;
+// two calls exchange 2 x 56 dwords through memory instead.
+C12381_HDN void fp4_mul_call(fp4& w, const fp4& x, const fp4& y) { fp4_mul_core(w, x, y); }
 // w = x * y  (FP12_mul fp12_BLS12381.cpp:246-299).  Two Fp4 products per lane.  w may alias x or y.
 C12381_HDN void f12t_mul(fp4& w, const fp4& x, const fp4& y, const tri& t) {
-    fp4 xn, yn, z, zc, zn, e, sx, sy;
-    tri_fetch_fp4(xn, x, tri_next(t), t);
-    tri_fetch_fp4(yn, y, tri_next(t), t);
-    fp4_mul_core(z, x, y);
-    fp4_addn(sx, x, xn); fp4_addn(sy, y, yn);
-    fp4_mul_core(zc, sx, sy);
+    fp4 z, zc, zn, e;
+    {
+        fp4 xn, yn, sx, sy;
+        tri_fetch_fp4(xn, x, tri_next(t), t);
+        tri_fetch_fp4(yn, y, tri_next(t), t);
+        fp4_addn(sx, x, xn); fp4_addn(sy, y, yn);
+        fp4_mul_call(zc, sx, sy);
+    }
+    fp4_mul_call(z, x, y);
     tri_fetch_fp4(zn, z, tri_next(t), t);
     fp4_sub(e, zc, z); fp4_sub(e, e, zn); fp4_norm1(e, e);
     f12t_combine(w, z, zn, e, t);
@@ -187,33 +195,39 @@ C12381_HDN void f12t_mul_line(fp4& x, const fp2& l0, const fp2& l1, const fp2& l
     fp2_add(p.b, p.b, ib);
     fp4_norm1(x, p);
 }
-C12381_HDN void f12t_pow_x(fp4& r, const fp4& a, const tri& t) {      // a^x for unitary a, x < 0; r must not alias a
-    fp4 w = a;
+// w <- a^x for unitary a, x < 0, computed IN w (w must not alias a): the running value never leaves `w`, which the
+// kernels place in LDS — the 63 squarings then exchange their operand at LDS latency instead of through private memory
+C12381_HDN void f12t_pow_x(fp4& w, const fp4& a, const tri& t) {
+    w = a;
 #pragma unroll 1
     for (int i = 62; i >= 0; --i) {
         f12t_usqr(w, w, (i & 1) == 0, t);
         if ((BLS_X >> i) & 1ull) f12t_mul(w, w, a, t);
     }
-    f12t_conj(r, w, t);
+    f12t_conj(w, w, t);
 }
-// PAIR_fexp :629-755
-C12381_HDN void f12t_final_exp(fp4& r, const tri& t) {
-    fp4 t0, y0, y1;
+// PAIR_fexp :629-755.  `h` is working storage for the exponentiations by x (kernels: an LDS slot).
+C12381_HDN void f12t_final_exp_ws(fp4& r, fp4& h, const tri& t) {
+    fp4 t0, y1;
     f12t_inv(t0, r, t);
     f12t_conj(r, r, t);
     f12t_mul(r, r, t0, t);
     f12t_frob(t0, r, t); f12t_frob(t0, t0, t);
     f12t_mul(r, t0, r, t);
     f12t_usqr(y1, r, false, t); f12t_mul(y1, y1, r, t);                       // r^3
-    f12t_pow_x(y0, r, t); f12t_conj(t0, r, t); f12t_mul(r, y0, t0, t);        // r^(x-1)
-    f12t_pow_x(y0, r, t); f12t_conj(t0, r, t); f12t_mul(r, y0, t0, t);        // r^(x-1)
-    f12t_pow_x(y0, r, t); f12t_frob(t0, r, t); f12t_mul(r, y0, t0, t);        // ^(x+p)
-    f12t_pow_x(t0, r, t); f12t_pow_x(y0, t0, t);                              // r^(x^2)
+    f12t_pow_x(h, r, t); f12t_conj(t0, r, t); f12t_mul(r, h, t0, t);          // r^(x-1)
+    f12t_pow_x(h, r, t); f12t_conj(t0, r, t); f12t_mul(r, h, t0, t);          // r^(x-1)
+    f12t_pow_x(h, r, t); f12t_frob(t0, r, t); f12t_mul(r, h, t0, t);          // ^(x+p)
+    f12t_pow_x(h, r, t); t0 = h; f12t_pow_x(h, t0, t);                        // r^(x^2)
     f12t_frob(t0, r, t); f12t_frob(t0, t0, t);                                // r^(p^2)
-    f12t_mul(y0, y0, t0, t);
+    f12t_mul(h, h, t0, t);
     f12t_conj(t0, r, t);
-    f12t_mul(r, y0, t0, t);                                                   // ^(x^2+p^2-1)
+    f12t_mul(r, h, t0, t);                                                    // ^(x^2+p^2-1)
     f12t_mul(r, r, y1, t);
+}
+C12381_HD void f12t_final_exp(fp4& r, const tri& t) {
+    fp4 h;
+    f12t_final_exp_ws(r, h, t);
 }
 // FP12_isunity: every lane tests its own coefficient, the verdict is combined over the triple
 C12381_HD bool f12t_is_one(const fp4& x, const tri& t) {
