@@ -176,7 +176,7 @@ C12381_HDN void f12t_inv(fp4& w, const fp4& x, const tri& t) {
     fp4_mul_core(w, f, f3i);
 }
 // f *= line(l0, l1, l2)  (sparse M-type line, see fp12_mul_line).  One dense-by-sparse product per lane.
-C12381_HDN void f12t_mul_line(fp4& x, const fp2& l0, const fp2& l1, const fp2& l2, const tri& t) {
+C12381_HD void f12t_mul_line_core(fp4& x, const fp2& l0, const fp2& l1, const fp2& l2, const tri& t) {
     fp4 la; la.a = l0; la.b = l1;
     fp4 p;
     fp2 q0, q1, qn0, qn1, ia, ib;
@@ -195,6 +195,7 @@ C12381_HDN void f12t_mul_line(fp4& x, const fp2& l0, const fp2& l1, const fp2& l
     fp2_add(p.b, p.b, ib);
     fp4_norm1(x, p);
 }
+C12381_HDN void f12t_mul_line(fp4& x, const fp2& l0, const fp2& l1, const fp2& l2, const tri& t) { f12t_mul_line_core(x, l0, l1, l2, t); }
 // w <- a^x for unitary a, x < 0, computed IN w (w must not alias a): the running value never leaves `w`, which the
 // kernels place in LDS — the 63 squarings then exchange their operand at LDS latency instead of through private memory
 C12381_HDN void f12t_pow_x(fp4& w, const fp4& a, const tri& t) {
@@ -243,7 +244,7 @@ C12381_HD bool f12t_is_one(const fp4& x, const tri& t) {
 // ------------------------------------------------------------------ Miller loop on a triple
 // Doubling step: role 0/1/2 holds X/Y/Z of T in `tc`.  Three Fp2 products per lane (PAIR_double :40-78 +
 // ECP2_dbl ecp2_BLS12381.cpp:358-409); the three line coefficients are then shared with all lanes.
-C12381_HDN void miller3_dbl_step(fp2& tc, fp2& l0, fp2& l1, fp2& l2, const fp& px, const fp& py, const tri& t) {
+C12381_HD void miller3_dbl_step_core(fp2& tc, fp2& l0, fp2& l1, fp2& l2, const fp& px, const fp& py, const tri& t) {
     fp2 yt, zt, s0, t0, t2b, z8, a, b, p2, u, y3p, p3, own, piece;
     tri_fetch_fp2(yt, tc, 1, t);                           // Y to everyone
     tri_fetch_fp2(zt, tc, 2, t);                           // Z to everyone
@@ -291,6 +292,19 @@ C12381_HDN void miller3_dbl_step(fp2& tc, fp2& l0, fp2& l1, fp2& l2, const fp& p
     tri_fetch_fp2(sw, own, src, t);
     tc = sw;
 }
+C12381_HDN void miller3_dbl_step(fp2& tc, fp2& l0, fp2& l1, fp2& l2, const fp& px, const fp& py, const tri& t) {
+    miller3_dbl_step_core(tc, l0, l1, l2, px, py, t);
+}
+// doubling step and the multiplication of f by its line in ONE out-of-line routine: the three line coefficients stay in
+// registers instead of crossing two call boundaries through memory (42 stores + 42 loads per iteration).
+// skip: the G1 argument of this pair is infinity — its line is replaced by 1 (PAIR_ate returns 1 for it, :448-449).
+C12381_HDN void miller3_dbl_line(fp4& F, fp2& tc, const fp& px, const fp& py, bool skip, const tri& t) {
+    fp2 l0, l1, l2, one2, zero2;
+    miller3_dbl_step_core(tc, l0, l1, l2, px, py, t);
+    fp2_one(one2); fp2_zero(zero2);
+    fp2_select(l0, skip, one2, l0); fp2_select(l1, skip, zero2, l1); fp2_select(l2, skip, zero2, l2);
+    f12t_mul_line_core(F, l0, l1, l2, t);
+}
 // f = conj(Miller_{|x|}(Q, P)) on a triple.  Returns this lane's coefficient.
 C12381_HDN void miller3_loop(fp4& F, const fp& px, const fp& py, bool p_inf, const fp2& qx, const fp2& qy, bool q_inf, const tri& t) {
     g2p Q;
@@ -313,8 +327,7 @@ C12381_HDN void miller3_loop(fp4& F, const fp& px, const fp& py, bool p_inf, con
     for (int i = 64; i >= 1; --i) {
         f12t_sqr(F, F, t);
         fp2 l0, l1, l2;
-        miller3_dbl_step(tc, l0, l1, l2, px, py, t);
-        f12t_mul_line(F, l0, l1, l2, t);
+        miller3_dbl_line(F, tc, px, py, false, t);
         const int bt = (int)((N3 >> i) & 1) - (int)((N1 >> i) & 1);
         if (bt != 0) {                                     // wave-uniform; 5 of 64 iterations
             g2p T, S = Q;
@@ -355,12 +368,8 @@ C12381_HDN void miller3_loop2(fp4& F, const fp& px1, const fp& py1, bool p_inf1,
     for (int i = 64; i >= 1; --i) {
         f12t_sqr(F, F, t);
         fp2 l0, l1, l2;
-        miller3_dbl_step(tc1, l0, l1, l2, px1, py1, t);
-        fp2_select(l0, p_inf1, one2, l0); fp2_select(l1, p_inf1, zero2, l1); fp2_select(l2, p_inf1, zero2, l2);
-        f12t_mul_line(F, l0, l1, l2, t);
-        miller3_dbl_step(tc2, l0, l1, l2, px2, py2, t);
-        fp2_select(l0, p_inf2, one2, l0); fp2_select(l1, p_inf2, zero2, l1); fp2_select(l2, p_inf2, zero2, l2);
-        f12t_mul_line(F, l0, l1, l2, t);
+        miller3_dbl_line(F, tc1, px1, py1, p_inf1, t);
+        miller3_dbl_line(F, tc2, px2, py2, p_inf2, t);
         const int bt = (int)((N3 >> i) & 1) - (int)((N1 >> i) & 1);
         if (bt != 0) {                                     // wave-uniform; 5 of 64 iterations
             g2p T, S;
