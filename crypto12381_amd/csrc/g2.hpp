@@ -18,7 +18,7 @@ C12381_HD void g2_neg(g2p& r, const g2p& p) { r.x = p.x; fp2_neg(r.y, p.y); r.z 
 C12381_HD void fp2_mul_b3(fp2& r, const fp2& x) { fp2 t; fp2_mul_small(t, x, 12); fp2_mul_ip(r, t); }
 
 // ECP2_dbl :358-409.  Also returns t0 = Y^2, t1 = Y*Z, t2b = 3b' Z^2 for the Miller-loop line.
-C12381_HDN void g2_dbl_ex(g2p& p, fp2& t0, fp2& t1, fp2& t2b) {
+C12381_HD void g2_dbl_core(g2p& p, fp2& t0, fp2& t1, fp2& t2b) {
     fp2 t2, x3, y3, z3, u;
     fp2_sqr(t0, p.y);
     fp2_mul(t1, p.y, p.z);
@@ -39,7 +39,15 @@ C12381_HDN void g2_dbl_ex(g2p& p, fp2& t0, fp2& t1, fp2& t2b) {
     fp2_dbl(x3, x3);
     p.x = x3; p.y = y3; p.z = z3;
 }
-C12381_HD void g2_dbl(g2p& p) { fp2 a, b, c; g2_dbl_ex(p, a, b, c); }
+C12381_HDN void g2_dbl_ex(g2p& p, fp2& t0, fp2& t1, fp2& t2b) { g2_dbl_core(p, t0, t1, t2b); }
+C12381_HDN void g2_dbl(g2p& p) { fp2 a, b, c; g2_dbl_core(p, a, b, c); }
+// n successive doublings with the point held in registers (one load and one store of the 84 dwords per call)
+C12381_HDN void g2_dbl_n(g2p& p, int n) {
+    g2p q = p;
+#pragma unroll 1
+    for (int i = 0; i < n; ++i) { fp2 a, b, c; g2_dbl_core(q, a, b, c); }
+    p = q;
+}
 
 // ECP2_add :413-502 (complete).  P limb bound <= 2^29, Q normalised.
 C12381_HDN void g2_add(g2p& p, const g2p& q) {
@@ -272,7 +280,7 @@ C12381_HDN void g2_scalar_mul(g2p& acc, const fp2& qx, const fp2& qy, bool q_is_
     g2_set_inf(acc);
 #pragma unroll 1
     for (int w = 16; w >= 0; --w) {
-        if (w != 16) { g2_dbl(acc); g2_dbl(acc); g2_dbl(acc); g2_dbl(acc); }
+        if (w != 16) g2_dbl_n(acc, 4);
         g2_add_digit<0>(acc, lane_tab, gs_digit(ub[0], w));
         g2_add_digit<1>(acc, lane_tab, gs_digit(ub[1], w));
         g2_add_digit<2>(acc, lane_tab, gs_digit(ub[2], w));

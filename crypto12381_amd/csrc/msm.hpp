@@ -112,11 +112,21 @@ C12381_HD bool msm_prep_one(size_t i, size_t n, const uint32_t* raw_pt /*24 word
     return ok;
 }
 // bucket: sum of the points whose (sorted) entries lie in [lo, hi)
+// The gather (index -> 112-byte record somewhere in a table of 2n records) is a two-step dependent load of a few
+// microseconds; it is software-pipelined: while point j is added, point j+1 and index j+2 are already in flight.
 C12381_HD void msm_bucket_one(g1p& acc, size_t lo, size_t hi, const uint32_t* vals_sorted, const int32_t* pts2) {
     g1_set_inf(acc);
+    if (lo >= hi) return;
+    fp xn, yn;
+    msm_load_pt(xn, yn, pts2 + (size_t)vals_sorted[lo] * MSM_PT_DWORDS);
+    uint32_t idx_next = lo + 1 < hi ? vals_sorted[lo + 1] : 0u;
+#pragma unroll 1
     for (size_t j = lo; j < hi; ++j) {
-        fp x, y;
-        msm_load_pt(x, y, pts2 + (size_t)vals_sorted[j] * MSM_PT_DWORDS);
+        const fp x = xn, y = yn;
+        if (j + 1 < hi) {
+            msm_load_pt(xn, yn, pts2 + (size_t)idx_next * MSM_PT_DWORDS);
+            idx_next = j + 2 < hi ? vals_sorted[j + 2] : 0u;
+        }
         g1_add_affine(acc, x, y);
     }
 }
