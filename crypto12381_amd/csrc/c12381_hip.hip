@@ -15,6 +15,7 @@
 #include "g1.hpp"
 #include "g2.hpp"
 #include "msm.hpp"
+#include "fixed_base.hpp"
 #include "kernels.hpp"
 
 using namespace c12381;
@@ -41,7 +42,7 @@ struct c12381_ctx {
     std::vector<hipEvent_t> ev_chunk;     // one per chunk of a scalar-mul batch (main -> side dependencies)
     char err[256] = {0};
     enum { WS_TAB, WS_PROJ, WS_PREF, WS_IN0, WS_IN1, WS_OUT, WS_RED0, WS_RED1, WS_BBS_Q, WS_BBS_B, WS_BBS_IN,
-           WS_MSM_PTS, WS_MSM_K0, WS_MSM_K1, WS_MSM_V0, WS_MSM_V1, WS_MSM_TMP, WS_MSM_RNG, WS_MSM_BK, WS_COUNT };
+           WS_FB_G2, WS_FB_G1_0, WS_FB_G1_1, WS_FB_G1_2, WS_FB_G1_3, WS_MSM_PTS, WS_MSM_K0, WS_MSM_K1, WS_MSM_V0, WS_MSM_V1, WS_MSM_TMP, WS_MSM_RNG, WS_MSM_BK, WS_COUNT };
     void* ws[WS_COUNT] = {nullptr};
     size_t ws_bytes[WS_COUNT] = {0};
     int* d_flag = nullptr;
@@ -93,7 +94,7 @@ struct timed {
 // scalar multiplication of n elements into the projective SoA workspace (stride = padded n)
 // (results land at proj[proj_off + i]; pt_stride 96 = per-lane points, 0 = one broadcast point)
 int g1_mul_to_proj(c12381_ctx* c, size_t n, const uint8_t* d_pts, const uint8_t* d_sc, size_t stride, size_t pt_stride = 96,
-                   size_t proj_off = 0) {
+                   size_t proj_off = 0, const int32_t* skip_if = nullptr) {
     const size_t chunk = n < G1_CHUNK ? round_up(n, 64) : G1_CHUNK;
     int rc;
     if ((rc = ensure(c, c12381_ctx::WS_TAB, (size_t)G1_TAB_DWORDS * chunk * 4))) return rc;
@@ -103,7 +104,7 @@ int g1_mul_to_proj(c12381_ctx* c, size_t n, const uint8_t* d_pts, const uint8_t*
         {
             timed tm(c, 0);
             hipLaunchKernelGGL(g1_mul_kernel, dim3(grid_for(m)), dim3(BLOCK), 0, c->stream, m, d_pts + pt_stride * off, pt_stride, d_sc + 32 * off,
-                               (int32_t*)c->ws[c12381_ctx::WS_TAB], (int32_t*)c->ws[c12381_ctx::WS_PROJ], stride, proj_off + off, c->d_flag);
+                               (int32_t*)c->ws[c12381_ctx::WS_TAB], (int32_t*)c->ws[c12381_ctx::WS_PROJ], stride, proj_off + off, c->d_flag, skip_if);
             HIPCK(c, hipGetLastError());
         }
         // the reference's small-scalar term (g1.hpp) for this chunk: empty unless some k mod r < x^2, and then a few lanes
@@ -117,7 +118,7 @@ int g1_mul_to_proj(c12381_ctx* c, size_t n, const uint8_t* d_pts, const uint8_t*
         HIPCK(c, hipEventRecord(c->ev_chunk[ci], c->stream));
         HIPCK(c, hipStreamWaitEvent(c->side, c->ev_chunk[ci], 0));
         hipLaunchKernelGGL(g1_small_scalar_kernel, dim3(grid_for(m)), dim3(BLOCK), 0, c->side, m, d_pts + pt_stride * off, pt_stride, d_sc + 32 * off,
-                           (int32_t*)c->ws[c12381_ctx::WS_PROJ], stride, proj_off + off);
+                           (int32_t*)c->ws[c12381_ctx::WS_PROJ], stride, proj_off + off, skip_if);
         HIPCK(c, hipGetLastError());
     }
     HIPCK(c, hipEventRecord(c->ev_side, c->side));
@@ -439,11 +440,13 @@ int c12381_g1_msm_multi(c12381_ctx** ctxs, int ngpu, size_t n, const uint8_t* pt
 }
 
 // ---------------------------------------------------------------- G2
-static int g2_mul_dev_strided(c12381_ctx* c, size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* sc, uint8_t* out, int fmt);
+static int g2_mul_dev_strided(c12381_ctx* c, size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* sc, uint8_t* out, int fmt,
+                              const int32_t* skip_if = nullptr);
 int c12381_g2_mul_batch_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
     return g2_mul_dev_strided(c, n, pts, 192, sc, out, fmt);
 }
-static int g2_mul_dev_strided(c12381_ctx* c, size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* sc, uint8_t* out, int fmt) {
+static int g2_mul_dev_strided(c12381_ctx* c, size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* sc, uint8_t* out, int fmt,
+                              const int32_t* skip_if) {
     int rc = bind(c); if (rc) return rc;
     if (!pts || !sc || !out || (fmt != 97 && fmt != 192)) return C12381_E_ARG;
     if (n == 0) return 0;
@@ -453,7 +456,7 @@ static int g2_mul_dev_strided(c12381_ctx* c, size_t n, const uint8_t* pts, size_
         const size_t m = n - off < chunk ? n - off : chunk;
         timed tm(c, 2);
         hipLaunchKernelGGL(g2_mul_kernel, dim3(grid_for(m)), dim3(BLOCK), 0, c->stream, m, pts + pt_stride * off, pt_stride, sc + 32 * off,
-                           (int32_t*)c->ws[c12381_ctx::WS_TAB], chunk, out + (size_t)fmt * off, fmt, c->d_flag);
+                           (int32_t*)c->ws[c12381_ctx::WS_TAB], chunk, out + (size_t)fmt * off, fmt, c->d_flag, skip_if);
         HIPCK(c, hipGetLastError());
     }
     return 0;
@@ -474,7 +477,7 @@ int c12381_g2_add_batch(c12381_ctx* c, size_t n, const uint8_t* a, const uint8_t
     if (n == 0) return 0;
     staged s;
     if ((rc = stage_in(c, s, a, 192 * n, b, 192 * n, (size_t)fmt * n))) return rc;
-    hipLaunchKernelGGL(g2_add_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, s.in0, (size_t)192, s.in1, s.out, fmt, c->d_flag);
+    hipLaunchKernelGGL(g2_add_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, s.in0, (size_t)192, s.in1, s.out, fmt, c->d_flag, (const int32_t*)nullptr);
     HIPCK(c, hipGetLastError());
     if ((rc = stage_out(c, s, out, (size_t)fmt * n))) return rc;
     return read_flag(c);
@@ -720,6 +723,29 @@ int c12381_gt_is_unity_batch(c12381_ctx* c, size_t n, const uint8_t* a576, uint8
     return 0;
 }
 
+// Fixed-base tables (fixed_base.hpp): make sure slot `slot` holds the table of the point at `d_base`; everything is
+// queued on the stream (the "same base as last time?" comparison runs on the device), nothing waits for the host.
+static int fixed_table(c12381_ctx* c, int slot, const uint8_t* d_base, bool is_g2) {
+    const size_t entries = (size_t)(is_g2 ? FB_G2_WINDOWS : FB_G1_WINDOWS) * FB_ENTRIES;
+    const size_t dwords = FB_HEADER_DWORDS + entries * (size_t)(is_g2 ? FB_G2_DWORDS : FB_G1_DWORDS);
+    int rc;
+    if (c->ws_bytes[slot] < dwords * 4) {
+        if ((rc = ensure(c, slot, dwords * 4))) return rc;
+        HIPCK(c, hipMemsetAsync(c->ws[slot], 0, FB_HEADER_DWORDS * 4, c->stream));      // no magic yet: first use is a miss
+    }
+    int32_t* buf = (int32_t*)c->ws[slot];
+    hipLaunchKernelGGL(fixed_cache_check_kernel, dim3(1), dim3(64), 0, c->stream, d_base, is_g2 ? 192 : 96, buf);
+    HIPCK(c, hipGetLastError());
+    if (is_g2) hipLaunchKernelGGL(g2_fixed_table_kernel, dim3(grid_for(entries)), dim3(BLOCK), 0, c->stream, d_base, buf);
+    else hipLaunchKernelGGL(g1_fixed_table_kernel, dim3(grid_for(entries)), dim3(BLOCK), 0, c->stream, d_base, buf);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+static bool fixed_base_enabled() {
+    static const bool on = [] { const char* e = std::getenv("C12381_FIXED_BASE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 // ---------------------------------------------------------------- BBS+ batch verification
 // ok[j] = [ e(A_j, w + x_j g2) == e(g1 + r_j h0 + sum_i m_{i,j} h_i, g2) ]   — the verification equation of the
 // reference's examples/bbs-plus/src/bbs+.cpp:57-73, evaluated as liner_pair.hpp:339-350 does (two Miller loops,
@@ -736,14 +762,36 @@ int c12381_bbs_plus_verify_batch_dev(c12381_ctx* c, size_t n, size_t nmsg, const
     if ((rc = ensure(c, c12381_ctx::WS_BBS_B, 192 * n))) return rc;
     uint8_t* d_q = (uint8_t*)c->ws[c12381_ctx::WS_BBS_Q];
     uint8_t* d_b = (uint8_t*)c->ws[c12381_ctx::WS_BBS_B];
-    if ((rc = g2_mul_dev_strided(c, n, g2_192, 0, x_32, d_b, 192))) return rc;
-    hipLaunchKernelGGL(g2_add_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, w_192, (size_t)0, d_b, d_q, 192, c->d_flag);
+    // g2 is one public point: its multiples come from a table when it is a subgroup point (32 additions, no doubling);
+    // otherwise the table stays invalid and the generic kernels below do the work — exactly one of the two paths runs
+    const bool fb = fixed_base_enabled();
+    const int32_t* skip_g2 = nullptr;
+    if (fb) {
+        if ((rc = fixed_table(c, c12381_ctx::WS_FB_G2, g2_192, true))) return rc;
+        skip_g2 = (const int32_t*)c->ws[c12381_ctx::WS_FB_G2];
+        hipLaunchKernelGGL(g2_fixed_eval_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, skip_g2, x_32, w_192, d_q, c->d_flag);
+        HIPCK(c, hipGetLastError());
+    }
+    if ((rc = g2_mul_dev_strided(c, n, g2_192, 0, x_32, d_b, 192, skip_g2))) return rc;
+    hipLaunchKernelGGL(g2_add_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, w_192, (size_t)0, d_b, d_q, 192, c->d_flag, skip_g2);
     HIPCK(c, hipGetLastError());
     // B_j = g1 + r_j h0 + sum_i m_ij h_i : (nmsg + 1) fixed-base columns of n scalar multiplications, summed per lane
     const size_t cols = nmsg + 1, total = cols * n, stride = round_up(total, 64);
-    if ((rc = g1_mul_to_proj(c, n, h0_96, r_32, stride, 0, 0))) return rc;
-    for (size_t i = 0; i < nmsg; ++i)
-        if ((rc = g1_mul_to_proj(c, n, h_96 + 96 * i, m_32 + 32 * n * i, stride, 0, (i + 1) * n))) return rc;
+    if ((rc = ensure(c, c12381_ctx::WS_PROJ, (size_t)3 * NL * stride * 4))) return rc;
+    for (size_t col = 0; col < cols; ++col) {
+        const uint8_t* base = col == 0 ? h0_96 : h_96 + 96 * (col - 1);
+        const uint8_t* sc = col == 0 ? r_32 : m_32 + 32 * n * (col - 1);
+        const int32_t* skip = nullptr;
+        if (fb && col < 4) {                                   // table slots for h0 and the first three h_i
+            const int slot = c12381_ctx::WS_FB_G1_0 + (int)col;
+            if ((rc = fixed_table(c, slot, base, false))) return rc;
+            skip = (const int32_t*)c->ws[slot];
+            hipLaunchKernelGGL(g1_fixed_eval_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, skip, sc, (int32_t*)c->ws[c12381_ctx::WS_PROJ],
+                               stride, col * n);
+            HIPCK(c, hipGetLastError());
+        }
+        if ((rc = g1_mul_to_proj(c, n, base, sc, stride, 0, col * n, skip))) return rc;
+    }
     const size_t rstride = round_up(n, 64);
     if ((rc = ensure(c, c12381_ctx::WS_RED0, (size_t)3 * NL * rstride * 4))) return rc;
     int32_t* red = (int32_t*)c->ws[c12381_ctx::WS_RED0];

@@ -53,7 +53,8 @@ __global__ void __launch_bounds__(BLOCK, 2) fp_mulchain_kernel(size_t n, int ite
 // proj layout: coordinate-major, limb-major SoA: proj[(c*NL + limb) * stride + element]
 // pt_stride = 96 for per-lane points, 0 to broadcast one point to every lane (fixed-base columns of BBS+)
 __global__ void __launch_bounds__(BLOCK, 2) g1_mul_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab,
-                                                       int32_t* proj, size_t proj_stride, size_t proj_off, int* bad_flag) {
+                                                       int32_t* proj, size_t proj_stride, size_t proj_off, int* bad_flag, const int32_t* skip_if) {
+    if (skip_if && skip_if[48] != 0) return;          // this column is served by a valid fixed-base table (k_fixed.hip)
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     fp px, py;
@@ -77,7 +78,8 @@ __global__ void __launch_bounds__(BLOCK, 2) g1_mul_kernel(size_t n, const uint8_
 // Fix-up pass after g1_mul_kernel: lanes whose scalar is below x^2 add the reference's [r]phi(P) term (g1.hpp).  Every
 // other lane — with random scalars: all of them — leaves after reading its scalar.
 __global__ void __launch_bounds__(BLOCK, 2) g1_small_scalar_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars,
-                                                                int32_t* proj, size_t proj_stride, size_t proj_off) {
+                                                                int32_t* proj, size_t proj_stride, size_t proj_off, const int32_t* skip_if) {
+    if (skip_if && skip_if[48] != 0) return;
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     uint32_t raw[8], k[8];

@@ -3,6 +3,7 @@
 //   k_g2gt.hip   G2 scalar multiplication / addition / decompression, one-lane pairing kernels, GT arithmetic
 //   k_pair3.hip  three-lanes-per-pairing Miller loop + final exponentiation
 //   k_hash_zp.hip  hash-to-G1 and the scalar-field (Zp) helpers
+//   k_fixed.hip  fixed-base tables and their evaluation (public-parameter columns of BBS+)
 // c12381_hip.hip (context, workspaces, C ABI) launches them.  Every kernel is built for 2 waves per SIMD
 // (__launch_bounds__(BLOCK, 2)): the field routines are not inlined and get the full 256-VGPR budget.
 #pragma once
@@ -18,8 +19,8 @@ constexpr int TRI_PER_WAVE = 21;                 // pairings per 64-lane wave in
 
 __global__ void __launch_bounds__(BLOCK, 2) fp_op_kernel(int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out);
 __global__ void __launch_bounds__(BLOCK, 2) fp_mulchain_kernel(size_t n, int iters, const uint8_t* a, const uint8_t* b, uint8_t* out);
-__global__ void __launch_bounds__(BLOCK, 2) g1_mul_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab, int32_t* proj, size_t proj_stride, size_t proj_off, int* bad_flag);
-__global__ void __launch_bounds__(BLOCK, 2) g1_small_scalar_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* proj, size_t proj_stride, size_t proj_off);
+__global__ void __launch_bounds__(BLOCK, 2) g1_mul_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab, int32_t* proj, size_t proj_stride, size_t proj_off, int* bad_flag, const int32_t* skip_if);
+__global__ void __launch_bounds__(BLOCK, 2) g1_small_scalar_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* proj, size_t proj_stride, size_t proj_off, const int32_t* skip_if);
 __global__ void __launch_bounds__(BLOCK, 2) g1_add_kernel(size_t n, const uint8_t* a, const uint8_t* b, int32_t* proj, size_t proj_stride, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) g1_finish_kernel(size_t n, const int32_t* proj, size_t stride, int32_t* pref, uint8_t* out, int fmt, size_t T);
 __global__ void __launch_bounds__(BLOCK, 2) g1_reduce_kernel(size_t n, const int32_t* in, size_t in_stride, size_t m, int32_t* outp, size_t out_stride);
@@ -30,8 +31,8 @@ __global__ void __launch_bounds__(BLOCK, 2) msm_bucket_kernel(size_t nbk, const 
 __global__ void __launch_bounds__(BLOCK, 2) msm_wreduce_kernel(int W, uint32_t nb, uint32_t chunks, const int32_t* bk, int32_t* out, size_t out_stride);
 __global__ void __launch_bounds__(BLOCK, 2) g1_decompress_kernel(size_t n, const uint8_t* in, uint8_t* out, uint8_t* status);
 __global__ void __launch_bounds__(64, 1) msm_horner_kernel(const int32_t* rw, size_t stride, int W, int c, int32_t* out, size_t out_stride);
-__global__ void __launch_bounds__(BLOCK, 2) g2_mul_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab, size_t tab_stride, uint8_t* out, int fmt, int* bad_flag);
-__global__ void __launch_bounds__(BLOCK, 2) g2_add_kernel(size_t n, const uint8_t* a, size_t a_stride, const uint8_t* b, uint8_t* out, int fmt, int* bad_flag);
+__global__ void __launch_bounds__(BLOCK, 2) g2_mul_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab, size_t tab_stride, uint8_t* out, int fmt, int* bad_flag, const int32_t* skip_if);
+__global__ void __launch_bounds__(BLOCK, 2) g2_add_kernel(size_t n, const uint8_t* a, size_t a_stride, const uint8_t* b, uint8_t* out, int fmt, int* bad_flag, const int32_t* skip_if);
 __global__ void __launch_bounds__(BLOCK, 2) pair_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) pair_eq_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, size_t b2_stride, uint8_t* out, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) g2_decompress_kernel(size_t n, const uint8_t* in, uint8_t* out, uint8_t* status);
@@ -44,5 +45,10 @@ __global__ void __launch_bounds__(BLOCK, 2) g1_from_hash_kernel(size_t n, const 
 __global__ void __launch_bounds__(BLOCK, 2) zp_op_kernel(int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out);
 __global__ void __launch_bounds__(BLOCK, 2) zp_from_hash_kernel(size_t n, const uint8_t* digests, uint8_t* out);
 __global__ void __launch_bounds__(BLOCK, 2) zp_fold_kernel(size_t n, const uint8_t* a, const uint8_t* b, size_t T, uint8_t* out);
+__global__ void __launch_bounds__(64, 1) fixed_cache_check_kernel(const uint8_t* base, int nbytes, int32_t* header);
+__global__ void __launch_bounds__(BLOCK, 2) g1_fixed_table_kernel(const uint8_t* base96, int32_t* buf);
+__global__ void __launch_bounds__(BLOCK, 2) g1_fixed_eval_kernel(size_t n, const int32_t* buf, const uint8_t* scalars, int32_t* proj, size_t proj_stride, size_t proj_off);
+__global__ void __launch_bounds__(BLOCK, 2) g2_fixed_table_kernel(const uint8_t* base192, int32_t* buf);
+__global__ void __launch_bounds__(BLOCK, 2) g2_fixed_eval_kernel(size_t n, const int32_t* buf, const uint8_t* scalars, const uint8_t* addend192, uint8_t* out, int* bad_flag);
 
 }  // namespace c12381

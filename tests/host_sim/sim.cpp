@@ -446,3 +446,107 @@ int sim_zp_from_hash_batch(size_t n, const uint8_t* digests64, uint8_t* out) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------- fixed-base columns (fixed_base.hpp)
+#include "../../crypto12381_amd/csrc/fixed_base.hpp"
+
+extern "C" {
+
+// [k_i]B through the table path (entries built lazily with g1_fixed_entry, exactly as the table kernel computes them);
+// returns -2 if the base is not a subgroup point (the library then runs the generic path)
+int sim_g1_fixed_mul_batch(size_t n, const uint8_t* base96, const uint8_t* scalars32, uint8_t* out96) {
+    uint32_t rp[24];
+    load_raw(rp, base96, 24);
+    if (raw_all_zero(rp, 24)) return -2;
+    g1p base;
+    fp_from_raw48(base.x, rp); fp_from_raw48(base.y, rp + 12); fp_one(base.z);
+    if (!g1_in_subgroup(base)) return -2;
+    const size_t entries = (size_t)FB_G1_WINDOWS * FB_ENTRIES;
+    std::vector<int32_t> tabv(entries * FB_G1_DWORDS + 4, 0);
+    int32_t* tab = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(tabv.data()) + 15) & ~(uintptr_t)15);
+    std::vector<char> done(entries, 0);
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t rs[8], k[8], kk[8], k0[4], k1[4];
+        load_raw(rs, scalars32 + 32 * i, 8);
+        scalar_from_raw32(k, rs);
+        for (int w = 0; w < 8; ++w) kk[w] = k[w];
+        scalar_mod_r(kk);
+        scalar_glv_split(k0, k1, kk);
+        for (int j = 0; j < FB_G1_WINDOWS; ++j)
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t d = ((h ? k1 : k0)[j >> 2] >> (8 * (j & 3))) & 255u;
+                if (!d) continue;
+                const size_t L = (size_t)j * FB_ENTRIES + (d - 1);
+                if (done[L]) continue;
+                g1p acc, an;
+                g1_fixed_entry(acc, base, d, 8 * j);
+                fp zn, zi, ax, ay;
+                fp_norm1(zn, acc.z); fp_inv(zi, zn);
+                g1_norm1(an, acc);
+                g1_to_affine(ax, ay, an, zi);
+                fp axn, ayn;
+                fp_norm1(axn, ax); fp_norm1(ayn, ay);
+                msm_store_pt(tab + L * FB_G1_DWORDS, axn, ayn);
+                done[L] = 1;
+            }
+        g1p acc;
+        g1_fixed_eval(acc, tab, k);
+        uint8_t* o = out96 + 96 * i;
+        if (g1_is_inf(acc)) { std::memset(o, 0, 96); continue; }
+        fp zn, zi, ax, ay;
+        fp_norm1(zn, acc.z); fp_inv(zi, zn);
+        g1p an; g1_norm1(an, acc);
+        g1_to_affine(ax, ay, an, zi);
+        uint32_t rx[12], ry[12];
+        fp_to_raw48(rx, ax); fp_to_raw48(ry, ay);
+        std::memcpy(o, rx, 48); std::memcpy(o + 48, ry, 48);
+    }
+    return 0;
+}
+
+int sim_g2_fixed_mul_batch(size_t n, const uint8_t* base192, const uint8_t* scalars32, uint8_t* out192) {
+    uint32_t rp[48];
+    load_raw(rp, base192, 48);
+    if (raw_all_zero(rp, 48)) return -2;
+    g2p base;
+    fp2_from_bytes96(base.x, base192); fp2_from_bytes96(base.y, base192 + 96); fp2_one(base.z);
+    if (!g2_in_subgroup(base)) return -2;
+    const size_t entries = (size_t)FB_G2_WINDOWS * FB_ENTRIES;
+    std::vector<int32_t> tabv(entries * FB_G2_DWORDS + 4, 0);
+    int32_t* tab = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(tabv.data()) + 15) & ~(uintptr_t)15);
+    std::vector<char> done(entries, 0);
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t rs[8], k[8], kk[8], u[4][2];
+        load_raw(rs, scalars32 + 32 * i, 8);
+        scalar_from_raw32(k, rs);
+        for (int w = 0; w < 8; ++w) kk[w] = k[w];
+        scalar_mod_r(kk);
+        scalar_gs_split(u, kk);
+        for (int a = 0; a < 4; ++a)
+            for (int j = 0; j < FB_G2_WINDOWS; ++j) {
+                const uint32_t d = (u[a][j >> 2] >> (8 * (j & 3))) & 255u;
+                if (!d) continue;
+                const size_t L = (size_t)j * FB_ENTRIES + (d - 1);
+                if (done[L]) continue;
+                g2p acc;
+                g2_fixed_entry(acc, base, d, 8 * j);
+                fp2 zn, zi, ax, ay;
+                fp2_norm1(zn, acc.z); fp2_inv(zi, zn);
+                fp2_mul(ax, acc.x, zi); fp2_mul(ay, acc.y, zi);
+                fp2_norm1(ax, ax); fp2_norm1(ay, ay);
+                fb_store_g2(tab + L * FB_G2_DWORDS, ax, ay);
+                done[L] = 1;
+            }
+        g2p acc;
+        g2_fixed_eval(acc, tab, k);
+        uint8_t* o = out192 + 192 * i;
+        if (g2_is_inf(acc)) { std::memset(o, 0, 192); continue; }
+        fp2 zn, zi, ax, ay;
+        fp2_norm1(zn, acc.z); fp2_inv(zi, zn);
+        fp2_mul(ax, acc.x, zi); fp2_mul(ay, acc.y, zi);
+        fp2_to_bytes96(o, ax); fp2_to_bytes96(o + 96, ay);
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -71,3 +71,37 @@ def test_bbs_plus_verify_batch(oracle_port):
     ok = ctx.bbs_plus_verify(G1p, G2p, h0, b"", w, a0 * 2, (11).to_bytes(32, "big") + (12).to_bytes(32, "big"), (22).to_bytes(32, "big") * 2, b"")
     assert ok == b"\x01\x00"
     ctx.close()
+
+
+def test_bbs_plus_fixed_base_fallbacks(oracle_port):
+    """Public parameters are served from fixed-base tables only when they are subgroup points; parameters outside the
+    subgroup (the reference checks nothing) must go through the generic kernels and still match the oracle's evaluation,
+    and changing a parameter between calls must rebuild its table (the cache is keyed by the parameter's bytes)."""
+    from crypto12381_amd import Context
+    from util import cat
+    orc = oracle_port
+    nmsg, n = 5, 40                                         # five message columns: four table slots + one generic column
+    G1p, G2p, h0, h, gamma, w = _setup(orc, nmsg)
+    off1 = cat(golden("g1")["offsubgroup_points"])
+    off2 = cat(golden("g2")["offsubgroup_points"])
+    X, Rr = scalars(731, n), scalars(732, n)
+    Mm = b"".join(scalars(740 + i, n) for i in range(nmsg))
+    A = orc.g1_mul(G1p * n, scalars(733, n), 96)
+
+    def oracle_eval(G2v, h0v, hv):
+        Q = orc.g2_add(w * n, orc.g2_mul(G2v * n, X, 192, 8), 192)
+        Bv = b""
+        for j in range(n):
+            acc = orc.g1_add(G1p, orc.g1_mul(h0v, Rr[32 * j:32 * j + 32], 96), 96)
+            for i in range(nmsg):
+                acc = orc.g1_add(acc, orc.g1_mul(hv[96 * i:96 * i + 96], Mm[32 * (n * i + j):32 * (n * i + j) + 32], 96), 96)
+            Bv += acc
+        return orc.pair_eq(A, Q, Bv, G2v * n, 8)
+
+    ctx = Context(0)
+    for G2v, h0v, hv in ((G2p, h0, h),                                   # all tables valid
+                         (G2p, off1[:96], h),                            # h0 outside G1: generic column
+                         (off2[:192], h0, off1[96:192] + h[96:]),        # g2 outside G2 and h_1 outside G1
+                         (G2p, h0, h)):                                  # back to the first parameters: tables rebuilt
+        assert ctx.bbs_plus_verify(G1p, G2v, h0v, hv, w, A, X, Rr, Mm) == oracle_eval(G2v, h0v, hv)
+    ctx.close()

@@ -246,3 +246,26 @@ def test_sim_hash_to_g1_and_zp(sim):
         out = ctypes.create_string_buffer(32 * m)
         assert sim.sim_zp_op_batch(op, sz(m), a, b if op <= 2 else None, out) == 0
         assert out.raw == cat(g["zp_" + name]), name
+
+
+def test_sim_fixed_base_tables(sim, oracle_port):
+    """fixed_base.hpp: table entries, table-driven evaluation and the subgroup tests, against the generic results"""
+    g = golden("g1")
+    gen = bytes.fromhex(g["generator"])
+    sc = cat(g["scalars"])[:32 * 10] + cat(g["offsubgroup_small_scalars"])
+    n = len(sc) // 32
+    base = oracle_port.g1_mul(gen, scalars(901, 1), 96)
+    out = ctypes.create_string_buffer(96 * n)
+    assert sim.sim_g1_fixed_mul_batch(sz(n), base, sc, out) == 0
+    assert out.raw == oracle_port.g1_mul(base * n, sc, 96)
+    assert sim.sim_g1_fixed_mul_batch(sz(1), cat(g["offsubgroup_points"])[:96], sc, out) == -2      # not a subgroup point
+    assert sim.sim_g1_fixed_mul_batch(sz(1), bytes(96), sc, out) == -2
+    g = golden("g2")
+    gen2 = bytes.fromhex(g["generator"])
+    sc2 = cat(g["scalars"])[:32 * 6] + cat(g["offsubgroup_small_scalars"])[:32 * 8]
+    n = len(sc2) // 32
+    base2 = oracle_port.g2_mul(gen2, scalars(902, 1), 192)
+    out = ctypes.create_string_buffer(192 * n)
+    assert sim.sim_g2_fixed_mul_batch(sz(n), base2, sc2, out) == 0
+    assert out.raw == oracle_port.g2_mul(base2 * n, sc2, 192)
+    assert sim.sim_g2_fixed_mul_batch(sz(1), cat(g["offsubgroup_points"])[:192], sc2, out) == -2
