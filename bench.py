@@ -234,6 +234,11 @@ def main():
         el = timed_steps(lambda: ctx.g1_from_hash_dev(nh, dg.data_ptr(), ho.data_ptr(), 96), 2)
         extras["hash_to_g1"] = {"metric": "hash-to-G1 points/s (2^20 SHA3-512 digests per GPU -> affine G1)", "value": world * nh * 2 / el,
                                 "unit": "points/s", "ms_per_batch": el / 2 * 1e3}
+        # g^x_i with ONE base for the batch (the reference's most common call shape): fixed-base tables
+        fo = torch.empty(96 * nh, dtype=torch.uint8, device=dev)
+        el = timed_steps(lambda: ctx.g1_mul_fixed_dev(nh, pts[96:192].data_ptr(), sc.data_ptr(), fo.data_ptr(), 96), 2)
+        extras["g1_fixed_base"] = {"metric": "G1 scalar-muls/s with one base for the batch (2^20 per GPU, table-driven)", "value": world * nh * 2 / el,
+                                   "unit": "scalar-muls/s", "ms_per_batch": el / 2 * 1e3}
         za = dg[: 32 * nh]
         zo = torch.empty(32 * nh, dtype=torch.uint8, device=dev)
         el = timed_steps(lambda: ctx.zp_op_dev("inv", nh, za.data_ptr(), None, zo.data_ptr()), 2)

@@ -62,6 +62,8 @@ def load_library() -> ctypes.CDLL:
         lib.c12381_gt_is_unity_batch.argtypes = [vp, sz, vp, vp]
         for name in ("c12381_g1_from_hash_batch", "c12381_g1_from_hash_batch_dev"):
             getattr(lib, name).argtypes = [vp, sz, vp, vp, ci]
+        for name in ("c12381_g1_mul_fixed_batch", "c12381_g1_mul_fixed_batch_dev", "c12381_g2_mul_fixed_batch", "c12381_g2_mul_fixed_batch_dev"):
+            getattr(lib, name).argtypes = [vp, sz, vp, vp, vp, ci]
         lib.c12381_g1_msm_multi.argtypes = [ctypes.POINTER(vp), ci, sz, vp, vp, vp, ci]
         lib.c12381_g1_map_to_point_batch.argtypes = [vp, sz, vp, vp]
         lib.c12381_g1_clear_cofactor_batch.argtypes = [vp, sz, vp, vp]
@@ -196,6 +198,21 @@ class Context:
         out = ctypes.create_string_buffer(max(fmt * n, 1))
         self._ck(self.lib.c12381_g1_from_hash_batch(self.h, n, _p(digests), _p(out), fmt))
         return out.raw[:fmt * n]
+
+    def g1_mul_fixed(self, base: bytes, scalars: bytes, fmt: int = 49, strict: bool = True) -> bytes:
+        n = len(scalars) // 32
+        out = ctypes.create_string_buffer(max(fmt * n, 1))
+        self._ck(self.lib.c12381_g1_mul_fixed_batch(self.h, n, _p(base), _p(scalars), _p(out), fmt), allow_point=not strict)
+        return out.raw[:fmt * n]
+
+    def g2_mul_fixed(self, base: bytes, scalars: bytes, fmt: int = 97, strict: bool = True) -> bytes:
+        n = len(scalars) // 32
+        out = ctypes.create_string_buffer(max(fmt * n, 1))
+        self._ck(self.lib.c12381_g2_mul_fixed_batch(self.h, n, _p(base), _p(scalars), _p(out), fmt), allow_point=not strict)
+        return out.raw[:fmt * n]
+
+    def g1_mul_fixed_dev(self, n, base_ptr, sc_ptr, out_ptr, fmt=49):
+        self._ck(self.lib.c12381_g1_mul_fixed_batch_dev(self.h, n, _p(base_ptr), _p(sc_ptr), _p(out_ptr), fmt))
 
     def g1_map_to_point(self, u48: bytes) -> bytes:
         n = len(u48) // 48

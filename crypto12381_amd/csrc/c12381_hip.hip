@@ -746,6 +746,58 @@ static bool fixed_base_enabled() {
     return on;
 }
 
+// ---------------------------------------------------------------- one base for the whole batch (g^x_i)
+int c12381_g1_mul_fixed_batch_dev(c12381_ctx* c, size_t n, const uint8_t* base96, const uint8_t* sc, uint8_t* out, int fmt) {
+    int rc = bind(c); if (rc) return rc;
+    if (!base96 || !sc || !out || (fmt != 49 && fmt != 96)) return C12381_E_ARG;
+    if (n == 0) return 0;
+    const size_t stride = round_up(n, 64);
+    if ((rc = ensure(c, c12381_ctx::WS_PROJ, (size_t)3 * NL * stride * 4))) return rc;
+    const int32_t* skip = nullptr;
+    if (fixed_base_enabled()) {
+        if ((rc = fixed_table(c, c12381_ctx::WS_FB_G1_0, base96, false))) return rc;
+        skip = (const int32_t*)c->ws[c12381_ctx::WS_FB_G1_0];
+        hipLaunchKernelGGL(g1_fixed_eval_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, skip, sc, (int32_t*)c->ws[c12381_ctx::WS_PROJ], stride,
+                           (size_t)0);
+        HIPCK(c, hipGetLastError());
+    }
+    if ((rc = g1_mul_to_proj(c, n, base96, sc, stride, 0, 0, skip))) return rc;
+    return g1_finish(c, n, (const int32_t*)c->ws[c12381_ctx::WS_PROJ], stride, out, fmt);
+}
+int c12381_g1_mul_fixed_batch(c12381_ctx* c, size_t n, const uint8_t* base96, const uint8_t* sc, uint8_t* out, int fmt) {
+    int rc = bind(c); if (rc) return rc;
+    if (!base96 || !sc || !out || (fmt != 49 && fmt != 96)) return C12381_E_ARG;
+    if (n == 0) return 0;
+    staged s;
+    if ((rc = stage_in(c, s, sc, 32 * n, base96, 96, (size_t)fmt * n))) return rc;
+    if ((rc = c12381_g1_mul_fixed_batch_dev(c, n, s.in1, s.in0, s.out, fmt))) return rc;
+    if ((rc = stage_out(c, s, out, (size_t)fmt * n))) return rc;
+    return read_flag(c);
+}
+int c12381_g2_mul_fixed_batch_dev(c12381_ctx* c, size_t n, const uint8_t* base192, const uint8_t* sc, uint8_t* out, int fmt) {
+    int rc = bind(c); if (rc) return rc;
+    if (!base192 || !sc || !out || (fmt != 97 && fmt != 192)) return C12381_E_ARG;
+    if (n == 0) return 0;
+    const int32_t* skip = nullptr;
+    if (fixed_base_enabled()) {
+        if ((rc = fixed_table(c, c12381_ctx::WS_FB_G2, base192, true))) return rc;
+        skip = (const int32_t*)c->ws[c12381_ctx::WS_FB_G2];
+        hipLaunchKernelGGL(g2_fixed_eval_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, skip, sc, (const uint8_t*)nullptr, out, fmt, c->d_flag);
+        HIPCK(c, hipGetLastError());
+    }
+    return g2_mul_dev_strided(c, n, base192, 0, sc, out, fmt, skip);
+}
+int c12381_g2_mul_fixed_batch(c12381_ctx* c, size_t n, const uint8_t* base192, const uint8_t* sc, uint8_t* out, int fmt) {
+    int rc = bind(c); if (rc) return rc;
+    if (!base192 || !sc || !out || (fmt != 97 && fmt != 192)) return C12381_E_ARG;
+    if (n == 0) return 0;
+    staged s;
+    if ((rc = stage_in(c, s, sc, 32 * n, base192, 192, (size_t)fmt * n))) return rc;
+    if ((rc = c12381_g2_mul_fixed_batch_dev(c, n, s.in1, s.in0, s.out, fmt))) return rc;
+    if ((rc = stage_out(c, s, out, (size_t)fmt * n))) return rc;
+    return read_flag(c);
+}
+
 // ---------------------------------------------------------------- BBS+ batch verification
 // ok[j] = [ e(A_j, w + x_j g2) == e(g1 + r_j h0 + sum_i m_{i,j} h_i, g2) ]   — the verification equation of the
 // reference's examples/bbs-plus/src/bbs+.cpp:57-73, evaluated as liner_pair.hpp:339-350 does (two Miller loops,
@@ -769,7 +821,7 @@ int c12381_bbs_plus_verify_batch_dev(c12381_ctx* c, size_t n, size_t nmsg, const
     if (fb) {
         if ((rc = fixed_table(c, c12381_ctx::WS_FB_G2, g2_192, true))) return rc;
         skip_g2 = (const int32_t*)c->ws[c12381_ctx::WS_FB_G2];
-        hipLaunchKernelGGL(g2_fixed_eval_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, skip_g2, x_32, w_192, d_q, c->d_flag);
+        hipLaunchKernelGGL(g2_fixed_eval_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, skip_g2, x_32, w_192, d_q, 192, c->d_flag);
         HIPCK(c, hipGetLastError());
     }
     if ((rc = g2_mul_dev_strided(c, n, g2_192, 0, x_32, d_b, 192, skip_g2))) return rc;

@@ -84,10 +84,10 @@ __global__ void __launch_bounds__(BLOCK, 2) g2_fixed_table_kernel(const uint8_t*
     fb_store_g2(buf + FB_HEADER_DWORDS + L * FB_G2_DWORDS, ax, ay);
 }
 
-// out[i] = addend + [k_i]Q (affine, canonical 192 B); addend = one broadcast 192-byte point (may be the zero bytes).
+// out[i] = addend + [k_i]Q (affine, canonical 192 B or 97 B); addend = one broadcast 192-byte point or nullptr.
 // Does nothing when the table is not valid.
 __global__ void __launch_bounds__(BLOCK, 2) g2_fixed_eval_kernel(size_t n, const int32_t* buf, const uint8_t* scalars, const uint8_t* addend192,
-                                                              uint8_t* out, int* bad_flag) {
+                                                              uint8_t* out, int fmt, int* bad_flag) {
     if (buf[48] == 0) return;
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -96,16 +96,19 @@ __global__ void __launch_bounds__(BLOCK, 2) g2_fixed_eval_kernel(size_t n, const
     scalar_from_raw32(k, raw);
     g2p acc;
     g2_fixed_eval(acc, buf + FB_HEADER_DWORDS, k);
-    g2p w, inf_pt;
-    bool winf, wok;
-    g2_parse192(w.x, w.y, winf, wok, addend192);
-    fp2_one(w.z);
-    g2_set_inf(inf_pt);
-    fp2_select(w.x, winf, inf_pt.x, w.x); fp2_select(w.y, winf, inf_pt.y, w.y); fp2_select(w.z, winf, inf_pt.z, w.z);
-    if (!wok) *bad_flag = 1;
-    g2_norm1(acc, acc);
-    g2_add(acc, w);
-    g2_store_affine(out + 192 * i, acc, 192, !wok);
+    bool wok = true;
+    if (addend192) {                                      // kernel-uniform
+        g2p w, inf_pt;
+        bool winf;
+        g2_parse192(w.x, w.y, winf, wok, addend192);
+        fp2_one(w.z);
+        g2_set_inf(inf_pt);
+        fp2_select(w.x, winf, inf_pt.x, w.x); fp2_select(w.y, winf, inf_pt.y, w.y); fp2_select(w.z, winf, inf_pt.z, w.z);
+        if (!wok) *bad_flag = 1;
+        g2_norm1(acc, acc);
+        g2_add(acc, w);
+    }
+    g2_store_affine(out + (size_t)fmt * i, acc, fmt, !wok);
 }
 
 }  // namespace c12381

@@ -135,6 +135,18 @@ int c12381_gt_op_batch(c12381_ctx* ctx, int op, size_t n, const uint8_t* a576, c
 /* is_unity(fp12&) (:197 -> 271-274 -> FP12_isunity): out[i] = 1 / 0. */
 int c12381_gt_is_unity_batch(c12381_ctx* ctx, size_t n, const uint8_t* a576, uint8_t* out);
 
+/* one base for the whole batch ------------------------------------------------------------------ */
+/* out[i] = scalars[i] * base: g^x with one g — the reference's most common call shape (the cached default generators,
+ * g1_point.hpp:257 / g2_point.hpp:246; setup / key_gen of examples/bbs-plus/src/bbs+.cpp:7-36), still `multiply`
+ * (:122 -> 174-177, :152 -> 202-205) per element there.  Here a subgroup base is served from a device-built table of
+ * its multiples (32 additions, no doubling; the table is kept in the context until the base changes); any other base
+ * goes through the generic kernels, so the result equals c12381_g1_mul_batch / c12381_g2_mul_batch on n copies of the
+ * base for every input. */
+int c12381_g1_mul_fixed_batch(c12381_ctx* ctx, size_t n, const uint8_t* base96, const uint8_t* scalars32, uint8_t* out, int out_fmt);
+int c12381_g1_mul_fixed_batch_dev(c12381_ctx* ctx, size_t n, const uint8_t* base96, const uint8_t* scalars32, uint8_t* out, int out_fmt);
+int c12381_g2_mul_fixed_batch(c12381_ctx* ctx, size_t n, const uint8_t* base192, const uint8_t* scalars32, uint8_t* out, int out_fmt);
+int c12381_g2_mul_fixed_batch_dev(c12381_ctx* ctx, size_t n, const uint8_t* base192, const uint8_t* scalars32, uint8_t* out, int out_fmt);
+
 /* caller pattern of BASELINE config 5 ------------------------------------------ */
 /* ok[j] = [ e(A_j, w + x_j*g2) == e(g1 + r_j*h0 + sum_i m[i*n + j]*h_i, g2) ]: the BBS+ verification equation of the
  * reference's examples/bbs-plus/src/bbs+.cpp:57-73 for n signatures of nmsg message blocks each, evaluated like

@@ -133,3 +133,26 @@ def test_msm_bucket_method_vs_naive_and_oracle(ctx, oracle_port):
     off, osc = cat(g["offsubgroup_points"]), cat(g["offsubgroup_scalars"])
     reps = 700
     assert ctx.g1_msm(off * reps, osc * reps, 96) == oracle_port.g1_msm(off * reps, osc * reps, 96, 16)
+
+
+def test_fixed_base_entry_points(ctx, oracle_port):
+    """g^x_i with one base: table path for subgroup bases, generic path otherwise — always equal to the generic batch."""
+    g = golden("g1")
+    gen = bytes.fromhex(g["generator"])
+    n = 700
+    sc = scalars(951, n - 14, 1 << 256) + cat(g["offsubgroup_small_scalars"])
+    base = oracle_port.g1_mul(gen, scalars(952, 1), 96)
+    assert ctx.g1_mul_fixed(base, sc, 49) == ctx.g1_mul(base * n, sc, 49)
+    assert ctx.g1_mul_fixed(base, sc[:32 * 40], 96) == oracle_port.g1_mul(base * 40, sc[:32 * 40], 96, 4)
+    off = cat(g["offsubgroup_points"])[:96]                 # not a subgroup point: generic path, still the reference's result
+    assert ctx.g1_mul_fixed(off, sc[-32 * 14:], 96) == oracle_port.g1_mul(off * 14, sc[-32 * 14:], 96)
+    assert ctx.g1_mul_fixed(gen, sc[:32 * 5], 96) == oracle_port.g1_mul(gen * 5, sc[:32 * 5], 96)     # base changed: table rebuilt
+    assert ctx.g1_mul_fixed(bytes(96), sc[:64], 96) == bytes(192)
+    g = golden("g2")
+    gen2 = bytes.fromhex(g["generator"])
+    sc2 = scalars(953, 90, 1 << 256) + cat(g["offsubgroup_small_scalars"])
+    m = len(sc2) // 32
+    assert ctx.g2_mul_fixed(gen2, sc2, 97) == ctx.g2_mul(gen2 * m, sc2, 97)
+    assert ctx.g2_mul_fixed(gen2, sc2[:32 * 12], 192) == oracle_port.g2_mul(gen2 * 12, sc2[:32 * 12], 192, 4)
+    off2 = cat(g["offsubgroup_points"])[:192]
+    assert ctx.g2_mul_fixed(off2, sc2[-32 * 14:], 192) == oracle_port.g2_mul(off2 * 14, sc2[-32 * 14:], 192)
