@@ -326,7 +326,8 @@ def main():
                 "ms_per_step": pair["elapsed"] / pair["steps"] * 1e3,
                 "parity": {"checked_lanes": len(pidx), "oracle": kind, "bit_exact": True},
                 "roofline": {"bound": "hbm", "achieved": BYTES_PER_PAIRING * npair / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": BYTES_PER_PAIRING * npair / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": pair_traffic, "kernel": "pair3_kernel" if os.environ.get("C12381_PAIR_LANES", "3") != "1" else "pair_kernel",
+                             "frac": BYTES_PER_PAIRING * npair / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": pair_traffic, "kernel": ("pair_kernel" if os.environ.get("C12381_PAIR_LANES", "3") == "1" else
+                                        ("pair3_queue_kernel" if (npair + 20) // 21 > 2048 and os.environ.get("C12381_PAIR_QUEUE", "") != "0" else "pair3_kernel")),
                              "avg_launch_ms": avg_s * 1e3},
                 "valu_roofline": {"bound": "int-valu", "achieved": MAC32_PER_PAIRING * npair / avg_s / 1e9, "peak": VALU_PEAK_MAC32 / 1e9,
                                   "unit": "GMAC32/s", "frac": MAC32_PER_PAIRING * npair / avg_s / VALU_PEAK_MAC32,

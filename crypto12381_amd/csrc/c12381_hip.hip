@@ -42,7 +42,7 @@ struct c12381_ctx {
     std::vector<hipEvent_t> ev_chunk;     // one per chunk of a scalar-mul batch (main -> side dependencies)
     char err[256] = {0};
     enum { WS_TAB, WS_PROJ, WS_PREF, WS_IN0, WS_IN1, WS_OUT, WS_RED0, WS_RED1, WS_BBS_Q, WS_BBS_B, WS_BBS_IN,
-           WS_FB_G2, WS_FB_G1_0, WS_FB_G1_1, WS_FB_G1_2, WS_FB_G1_3, WS_MSM_PTS, WS_MSM_K0, WS_MSM_K1, WS_MSM_V0, WS_MSM_V1, WS_MSM_TMP, WS_MSM_RNG, WS_MSM_BK, WS_COUNT };
+           WS_PAIR_ST, WS_FB_G2, WS_FB_G1_0, WS_FB_G1_1, WS_FB_G1_2, WS_FB_G1_3, WS_MSM_PTS, WS_MSM_K0, WS_MSM_K1, WS_MSM_V0, WS_MSM_V1, WS_MSM_TMP, WS_MSM_RNG, WS_MSM_BK, WS_COUNT };
     void* ws[WS_COUNT] = {nullptr};
     size_t ws_bytes[WS_COUNT] = {0};
     int* d_flag = nullptr;
@@ -493,15 +493,67 @@ static unsigned grid_tri(size_t n) {
     const size_t waves = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE;
     return (unsigned)((waves * 64 + BLOCK - 1) / BLOCK);
 }
+// Work-queue variant (k_pair3.hip): used when the batch is more than one machine-filling round of wavefronts, where the
+// plain grid would end in a mostly idle round.  C12381_PAIR_QUEUE=0 / 1 forces it off / on (A/B measurements, tests).
+constexpr size_t PAIR_QUEUE_WAVES = 2048;                  // resident wavefronts at 2 per SIMD
+static int pair_queue_mode() {
+    static const int v = [] { const char* e = std::getenv("C12381_PAIR_QUEUE"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    return v;
+}
+static bool pair_use_queue(size_t n) {
+    const int m = pair_queue_mode();
+    if (m >= 0) return m == 1;
+    return (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE > PAIR_QUEUE_WAVES;
+}
+// state slab: [flags: one word per group][counter][pad to 256 B][42 x 1 KiB per group]
+static int pair_queue_setup(c12381_ctx* c, size_t n, uint4*& state, unsigned int*& flags, unsigned int*& counter, unsigned& blocks) {
+    const size_t groups = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE;
+    const size_t head = round_up((groups + 1) * 4, 256);
+    int rc;
+    if ((rc = ensure(c, c12381_ctx::WS_PAIR_ST, head + groups * (size_t)PAIR_QUEUE_STATE_ROWS * 1024))) return rc;
+    uint8_t* base = (uint8_t*)c->ws[c12381_ctx::WS_PAIR_ST];
+    flags = (unsigned int*)base;
+    counter = flags + groups;
+    state = (uint4*)(base + head);
+    HIPCK(c, hipMemsetAsync(base, 0, (groups + 1) * 4, c->stream));
+    const size_t waves = groups < PAIR_QUEUE_WAVES ? groups : PAIR_QUEUE_WAVES;
+    blocks = (unsigned)((waves * 64 + BLOCK - 1) / BLOCK);
+    return 0;
+}
+static int launch_pair(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt) {
+    if (pair_lanes() == 1) hipLaunchKernelGGL(pair_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag);
+    else if (pair_use_queue(n)) {
+        uint4* st; unsigned int *fl, *ct; unsigned blocks; int rc;
+        if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
+        hipLaunchKernelGGL(pair3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag, st, fl, ct);
+    } else hipLaunchKernelGGL(pair3_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+static int launch_pair_eq(c12381_ctx* c, size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, size_t b2_stride, uint8_t* ok) {
+    if (pair_lanes() == 1) hipLaunchKernelGGL(pair_eq_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, a1, a2, b1, b2, b2_stride, ok, c->d_flag);
+    else if (pair_use_queue(n)) {
+        uint4* st; unsigned int *fl, *ct; unsigned blocks; int rc;
+        if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
+        hipLaunchKernelGGL(pair3_eq_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, a1, a2, b1, b2, b2_stride, ok, c->d_flag, st, fl, ct);
+    } else hipLaunchKernelGGL(pair3_eq_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, a1, a2, b1, b2, b2_stride, ok, c->d_flag);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
 int c12381_pair_batch_dev(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt) {
     int rc = bind(c); if (rc) return rc;
     if (!g1 || !g2 || !gt) return C12381_E_ARG;
     if (n == 0) return 0;
+    if (pair_lanes() != 1 && pair_use_queue(n)) {            // workspace and its reset stay outside the timed bracket
+        uint4* st; unsigned int *fl, *ct; unsigned blocks;
+        if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
+        timed tm(c, 3);
+        hipLaunchKernelGGL(pair3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag, st, fl, ct);
+        HIPCK(c, hipGetLastError());
+        return 0;
+    }
     timed tm(c, 3);
-    if (pair_lanes() == 1) hipLaunchKernelGGL(pair_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag);
-    else hipLaunchKernelGGL(pair3_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag);
-    HIPCK(c, hipGetLastError());
-    return 0;
+    return launch_pair(c, n, g1, g2, gt);
 }
 int c12381_pair_batch(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt) {
     int rc = bind(c); if (rc) return rc;
@@ -518,10 +570,7 @@ int c12381_pair_eq_batch_dev(c12381_ctx* c, size_t n, const uint8_t* a1, const u
     if (!a1 || !a2 || !b1 || !b2 || !ok) return C12381_E_ARG;
     if (n == 0) return 0;
     timed tm(c, 4);
-    if (pair_lanes() == 1) hipLaunchKernelGGL(pair_eq_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, a1, a2, b1, b2, (size_t)192, ok, c->d_flag);
-    else hipLaunchKernelGGL(pair3_eq_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, a1, a2, b1, b2, (size_t)192, ok, c->d_flag);
-    HIPCK(c, hipGetLastError());
-    return 0;
+    return launch_pair_eq(c, n, a1, a2, b1, b2, (size_t)192, ok);
 }
 int c12381_pair_eq_batch(c12381_ctx* c, size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, uint8_t* ok) {
     int rc = bind(c); if (rc) return rc;
@@ -853,10 +902,7 @@ int c12381_bbs_plus_verify_batch_dev(c12381_ctx* c, size_t n, size_t nmsg, const
     HIPCK(c, hipGetLastError());
     if ((rc = g1_finish(c, n, red, rstride, d_b, 96))) return rc;
     timed tm(c, 4);
-    if (pair_lanes() == 1) hipLaunchKernelGGL(pair_eq_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, A_96, d_q, d_b, g2_192, (size_t)0, ok, c->d_flag);
-    else hipLaunchKernelGGL(pair3_eq_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, A_96, d_q, d_b, g2_192, (size_t)0, ok, c->d_flag);
-    HIPCK(c, hipGetLastError());
-    return 0;
+    return launch_pair_eq(c, n, A_96, d_q, d_b, g2_192, (size_t)0, ok);
 }
 int c12381_bbs_plus_verify_batch(c12381_ctx* c, size_t n, size_t nmsg, const uint8_t* g1_96, const uint8_t* g2_192, const uint8_t* h0_96,
                                  const uint8_t* h_96, const uint8_t* w_192, const uint8_t* A_96, const uint8_t* x_32, const uint8_t* r_32,

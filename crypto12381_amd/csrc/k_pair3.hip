@@ -33,6 +33,25 @@ __device__ __forceinline__ void gt_store_coeff(uint8_t* o576, const fp4& x, int 
 // operand at LDS latency.  60 KB per workgroup, two workgroups per CU.
 struct alignas(16) fp4_slot { fp4 v; int32_t pad[4]; };
 
+// ---- work-queue variant: state of a group of 21 pairings between two phases, as rows of 64 x 16 bytes (one per lane)
+constexpr int ST_ROWS_F = 14, ST_ROWS_TC = 7;                 // Fp4 = 56 dwords, Fp2 = 28 dwords
+constexpr int ST_F = 0, ST_TC1 = ST_ROWS_F, ST_TC2 = ST_TC1 + ST_ROWS_TC, ST_Y1 = ST_TC2 + ST_ROWS_TC;
+
+template <class T, int ROWS>
+__device__ __forceinline__ void st_store(uint4* rows, unsigned lane, const T& x) {
+    static_assert(sizeof(T) == ROWS * 16, "state row count");
+    const int32_t* w = reinterpret_cast<const int32_t*>(&x);
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) rows[(size_t)r * 64 + lane] = make_uint4((uint32_t)w[4 * r], (uint32_t)w[4 * r + 1], (uint32_t)w[4 * r + 2], (uint32_t)w[4 * r + 3]);
+}
+template <class T, int ROWS>
+__device__ __forceinline__ void st_load(T& x, const uint4* rows, unsigned lane) {
+    static_assert(sizeof(T) == ROWS * 16, "state row count");
+    int32_t* w = reinterpret_cast<int32_t*>(&x);
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) { const uint4 v = rows[(size_t)r * 64 + lane]; w[4 * r] = (int32_t)v.x; w[4 * r + 1] = (int32_t)v.y; w[4 * r + 2] = (int32_t)v.z; w[4 * r + 3] = (int32_t)v.w; }
+}
+
 }  // namespace
 
 namespace c12381 {
@@ -86,6 +105,128 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_kernel(size_t n, const uint
         if (!valid) *bad_flag = 1;
         out[i] = valid ? (one ? 1 : 0) : 0xff;
     }
+}
+
+// ------------------------------------------------------------------ work-queue kernels
+// A pairing is ~3.4 M instructions per wavefront and every wavefront task is equally long, so a plain grid finishes in
+// whole "rounds": 3121 wavefronts (2^16 pairings) on 2048 resident slots take two full double rounds although they
+// are 1.52 rounds of work.  Here each group of 21 pairings is FOUR tasks — Miller iterations 64..33, 32..1, the two
+// halves of the final exponentiation — handed out through one atomic counter to a grid that just fills the machine;
+// a wavefront that finishes takes the next task, so the tail is a quarter as long.  Tasks are numbered phase-major
+// and a task of phase p waits (spins on the group's flag) only for a task of phase p-1, which never waits for anything
+// of phase >= p: no cycle, every wavefront reaches the end of the queue.  The spin is bounded as a last line of defence.
+template <bool EQ>
+__device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, size_t b2_stride,
+                                                 uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, fp4& H) {
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned trip = lane / 3u;
+    tri t;
+    t.role = lane == 63u ? 0 : (int)(lane - 3u * trip);
+    t.base = lane == 63u ? 63 : (int)(3u * trip);
+    const size_t ngroups = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE;
+    const size_t ntasks = ngroups * 4;
+    constexpr int ROWS = ST_Y1 + ST_ROWS_F;
+    for (;;) {
+        // lane 0 claims a task; readfirstlane makes the number a scalar, so phase / group and every branch on them are
+        // wave-uniform for the compiler too (a broadcast by shuffle leaves them "divergent": the loop was then
+        // restructured per lane set, lanes 1..63 re-entered it with task 0 and never left)
+        // (every lane issues the atomic, lanes 1..63 add zero: no divergent branch in front of the scalarisation)
+        const unsigned int claimed = atomicAdd(counter, lane == 0 ? 1u : 0u);
+        const unsigned int task = (unsigned int)__builtin_amdgcn_readfirstlane((int)claimed);
+        if ((size_t)task >= ntasks) break;
+        const unsigned int p = (unsigned int)(task / ngroups);
+        const size_t g = task % ngroups;
+        const size_t e = g * TRI_PER_WAVE + (lane == 63u ? TRI_PER_WAVE - 1 : trip);
+        const bool active = lane < 63u && e < n;
+        const size_t i = e < n ? e : n - 1;          // inactive lanes shadow the last element: same instruction stream
+        if (p > 0) {
+            int spins = 0;
+            while ((unsigned int)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&flags[g], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < p) {
+                __builtin_amdgcn_s_sleep(64);
+                if (++spins > (1 << 20)) { if (lane == 0) *bad_flag = 2; break; }
+            }
+        }
+        uint4* st = state + g * (size_t)ROWS * 64;
+        if (p <= 1) {
+            fp px, py, px2, py2; fp2 qx, qy, qx2, qy2; bool pinf, qinf, pinf2 = true, qinf2 = true, ok, okb = true;
+            pair_inputs(px, py, pinf, qx, qy, qinf, ok, a1 + 96 * i, a2 + 192 * i);
+            if (!ok) { pinf = true; qinf = true; }
+            g2p Q, Q2;
+            fp2 tc, tc2;
+            miller3_q(Q, qx, qy, qinf);
+            if (EQ) {
+                pair_inputs(px2, py2, pinf2, qx2, qy2, qinf2, okb, b1 + 96 * i, b2 + b2_stride * i);
+                if (!okb) { pinf2 = true; qinf2 = true; }
+                fp ny;
+                fp_neg(ny, py2);
+                fp_norm1(py2, ny);                       // e(a1, a2) * e(-b1, b2), see pair3_eq_kernel
+                miller3_q(Q2, qx2, qy2, qinf2);
+            }
+            if (p == 0) {
+                miller3_tc(tc, Q, t);
+                if (EQ) miller3_tc(tc2, Q2, t);
+                f12t_one(H, t);
+            } else {
+                st_load<fp4, ST_ROWS_F>(H, st + ST_F * 64, lane);
+                st_load<fp2, ST_ROWS_TC>(tc, st + ST_TC1 * 64, lane);
+                if (EQ) st_load<fp2, ST_ROWS_TC>(tc2, st + ST_TC2 * 64, lane);
+            }
+            const int hi = p == 0 ? 64 : 32, lo = p == 0 ? 33 : 1;
+            if (EQ) miller3_range2(H, tc, px, py, pinf, Q, tc2, px2, py2, pinf2, Q2, hi, lo, t);
+            else miller3_range(H, tc, px, py, pinf, Q, hi, lo, t);
+            if (p == 1) f12t_conj(H, H, t);
+            st_store<fp4, ST_ROWS_F>(st + ST_F * 64, lane, H);
+            if (p == 0) {
+                st_store<fp2, ST_ROWS_TC>(st + ST_TC1 * 64, lane, tc);
+                if (EQ) st_store<fp2, ST_ROWS_TC>(st + ST_TC2 * 64, lane, tc2);
+            }
+        } else if (p == 2) {
+            fp4 r, y1;
+            st_load<fp4, ST_ROWS_F>(r, st + ST_F * 64, lane);
+            f12t_final_exp_a(r, y1, H, t);
+            st_store<fp4, ST_ROWS_F>(st + ST_F * 64, lane, r);
+            st_store<fp4, ST_ROWS_F>(st + ST_Y1 * 64, lane, y1);
+        } else {
+            fp4 r, y1;
+            st_load<fp4, ST_ROWS_F>(r, st + ST_F * 64, lane);
+            st_load<fp4, ST_ROWS_F>(y1, st + ST_Y1 * 64, lane);
+            f12t_final_exp_b(r, y1, H, t);
+            // validity of this lane's inputs (cheap next to the arithmetic; keeps the state slab free of flags)
+            fp px, py; fp2 qx, qy; bool pinf, qinf, ok, okb = true;
+            pair_inputs(px, py, pinf, qx, qy, qinf, ok, a1 + 96 * i, a2 + 192 * i);
+            if (EQ) pair_inputs(px, py, pinf, qx, qy, qinf, okb, b1 + 96 * i, b2 + b2_stride * i);
+            const bool valid = ok && okb;
+            if (EQ) {
+                const bool one = f12t_is_one(r, t);
+                if (active && t.role == 0) {
+                    if (!valid) *bad_flag = 1;
+                    out[e] = valid ? (one ? 1 : 0) : 0xff;
+                }
+            } else if (active) {
+                if (!valid) {
+                    *bad_flag = 1;
+                    uint4* q = reinterpret_cast<uint4*>(out + 576 * e + (t.role == 0 ? 384 : (t.role == 1 ? 192 : 0)));
+                    for (int j = 0; j < 12; ++j) q[j] = make_uint4(~0u, ~0u, ~0u, ~0u);
+                } else {
+                    gt_store_coeff(out + 576 * e, r, t.role);
+                }
+            }
+        }
+        __threadfence();
+        if (lane == 0) __hip_atomic_store(&flags[g], p + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK, 2) pair3_queue_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag, uint4* state,
+                                                            unsigned int* flags, unsigned int* counter) {
+    __shared__ fp4_slot slots[BLOCK];
+    pair3_queue_body<false>(n, g1, g2, nullptr, nullptr, 0, gt, bad_flag, state, flags, counter, slots[threadIdx.x].v);
+}
+__global__ void __launch_bounds__(BLOCK, 2) pair3_eq_queue_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2,
+                                                               size_t b2_stride, uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags,
+                                                               unsigned int* counter) {
+    __shared__ fp4_slot slots[BLOCK];
+    pair3_queue_body<true>(n, a1, a2, b1, b2, b2_stride, out, bad_flag, state, flags, counter, slots[threadIdx.x].v);
 }
 
 }  // namespace c12381

@@ -207,9 +207,10 @@ C12381_HDN void f12t_pow_x(fp4& w, const fp4& a, const tri& t) {
     }
     f12t_conj(w, w, t);
 }
-// PAIR_fexp :629-755.  `h` is working storage for the exponentiations by x (kernels: an LDS slot).
-C12381_HDN void f12t_final_exp_ws(fp4& r, fp4& h, const tri& t) {
-    fp4 t0, y1;
+// PAIR_fexp :629-755 in two pieces (the work-queue kernels schedule them separately).  `h` is working storage for the
+// exponentiations by x (kernels: an LDS slot).  Part A: easy part, y1 = r^3, two of the five exponentiations.
+C12381_HDN void f12t_final_exp_a(fp4& r, fp4& y1, fp4& h, const tri& t) {
+    fp4 t0;
     f12t_inv(t0, r, t);
     f12t_conj(r, r, t);
     f12t_mul(r, r, t0, t);
@@ -218,6 +219,9 @@ C12381_HDN void f12t_final_exp_ws(fp4& r, fp4& h, const tri& t) {
     f12t_usqr(y1, r, false, t); f12t_mul(y1, y1, r, t);                       // r^3
     f12t_pow_x(h, r, t); f12t_conj(t0, r, t); f12t_mul(r, h, t0, t);          // r^(x-1)
     f12t_pow_x(h, r, t); f12t_conj(t0, r, t); f12t_mul(r, h, t0, t);          // r^(x-1)
+}
+C12381_HDN void f12t_final_exp_b(fp4& r, const fp4& y1, fp4& h, const tri& t) {
+    fp4 t0;
     f12t_pow_x(h, r, t); f12t_frob(t0, r, t); f12t_mul(r, h, t0, t);          // ^(x+p)
     f12t_pow_x(h, r, t); t0 = h; f12t_pow_x(h, t0, t);                        // r^(x^2)
     f12t_frob(t0, r, t); f12t_frob(t0, t0, t);                                // r^(p^2)
@@ -225,6 +229,11 @@ C12381_HDN void f12t_final_exp_ws(fp4& r, fp4& h, const tri& t) {
     f12t_conj(t0, r, t);
     f12t_mul(r, h, t0, t);                                                    // ^(x^2+p^2-1)
     f12t_mul(r, r, y1, t);
+}
+C12381_HD void f12t_final_exp_ws(fp4& r, fp4& h, const tri& t) {
+    fp4 y1;
+    f12t_final_exp_a(r, y1, h, t);
+    f12t_final_exp_b(r, y1, h, t);
 }
 C12381_HD void f12t_final_exp(fp4& r, const tri& t) {
     fp4 h;
@@ -305,93 +314,80 @@ C12381_HDN void miller3_dbl_line(fp4& F, fp2& tc, const fp& px, const fp& py, bo
     fp2_select(l0, skip, one2, l0); fp2_select(l1, skip, zero2, l1); fp2_select(l2, skip, zero2, l2);
     f12t_mul_line_core(F, l0, l1, l2, t);
 }
+// ------------------------------------------------------------------ Miller loop on a triple, in pieces
+// (the kernels run it either whole or as two half-ranges of a work queue, see k_pair3.hip)
+C12381_HD void miller3_q(g2p& Q, const fp2& qx, const fp2& qy, bool q_inf) {      // G2 infinity runs as (0:1:0), like PAIR_ate
+    g2p inf;
+    g2_set_inf(inf);
+    Q.x = qx; Q.y = qy; fp2_one(Q.z);
+    fp2_select(Q.x, q_inf, inf.x, Q.x); fp2_select(Q.y, q_inf, inf.y, Q.y); fp2_select(Q.z, q_inf, inf.z, Q.z);
+}
+C12381_HD void miller3_tc(fp2& tc, const g2p& Q, const tri& t) {                     // role 0/1/2 holds X/Y/Z of T
+    fp2_select(tc, t.role == 0, Q.x, Q.y); fp2_select(tc, t.role == 2, Q.z, tc);
+}
+C12381_HD void f12t_one(fp4& F, const tri& t) {
+    fp4 one4, zero4;
+    fp4_zero(zero4); one4 = zero4; fp_one(one4.a.a);
+    fp4_select(F, t.role == 0, one4, zero4);
+}
+// everything iteration i does for ONE (P, Q) pair after the squaring: doubling step + line, and the addition step of
+// the 5 iterations whose digit of 3|x| - |x| is non-zero.  skip: P is infinity, the pair contributes 1 (PAIR_ate :448-449).
+C12381_HD void miller3_pair_step(fp4& F, fp2& tc, const fp& px, const fp& py, bool skip, const g2p& Q, int i, const tri& t) {
+    constexpr unsigned __int128 N1 = (unsigned __int128)BLS_X;
+    constexpr unsigned __int128 N3 = N1 * 3;
+    miller3_dbl_line(F, tc, px, py, skip, t);
+    const int bt = (int)((N3 >> i) & 1) - (int)((N1 >> i) & 1);
+    if (bt != 0) {                                         // wave-uniform
+        fp2 l0, l1, l2, one2, zero2;
+        g2p T, S = Q;
+        tri_fetch_fp2(T.x, tc, 0, t); tri_fetch_fp2(T.y, tc, 1, t); tri_fetch_fp2(T.z, tc, 2, t);
+        if (bt < 0) g2_neg(S, Q);
+        miller_add_step(T, S, l0, l1, l2, px, py);         // replicated on the three lanes
+        fp2_select(tc, t.role == 0, T.x, T.y); fp2_select(tc, t.role == 2, T.z, tc);
+        fp2_one(one2); fp2_zero(zero2);
+        fp2_select(l0, skip, one2, l0); fp2_select(l1, skip, zero2, l1); fp2_select(l2, skip, zero2, l2);
+        f12t_mul_line(F, l0, l1, l2, t);
+    }
+}
+// iterations hi .. lo (inclusive, 64 >= hi >= lo >= 1) of the loop for one pair / for two pairs sharing the squarings
+C12381_HDN void miller3_range(fp4& F, fp2& tc, const fp& px, const fp& py, bool skip, const g2p& Q, int hi, int lo, const tri& t) {
+#pragma unroll 1
+    for (int i = hi; i >= lo; --i) {
+        f12t_sqr(F, F, t);
+        miller3_pair_step(F, tc, px, py, skip, Q, i, t);
+    }
+}
+C12381_HDN void miller3_range2(fp4& F, fp2& tc1, const fp& px1, const fp& py1, bool skip1, const g2p& Q1,
+                               fp2& tc2, const fp& px2, const fp& py2, bool skip2, const g2p& Q2, int hi, int lo, const tri& t) {
+#pragma unroll 1
+    for (int i = hi; i >= lo; --i) {
+        f12t_sqr(F, F, t);
+        miller3_pair_step(F, tc1, px1, py1, skip1, Q1, i, t);
+        miller3_pair_step(F, tc2, px2, py2, skip2, Q2, i, t);
+    }
+}
 // f = conj(Miller_{|x|}(Q, P)) on a triple.  Returns this lane's coefficient.
 C12381_HDN void miller3_loop(fp4& F, const fp& px, const fp& py, bool p_inf, const fp2& qx, const fp2& qy, bool q_inf, const tri& t) {
     g2p Q;
-    Q.x = qx; Q.y = qy; fp2_one(Q.z);
-    {
-        g2p inf;
-        g2_set_inf(inf);
-        fp2_select(Q.x, q_inf, inf.x, Q.x);
-        fp2_select(Q.y, q_inf, inf.y, Q.y);
-        fp2_select(Q.z, q_inf, inf.z, Q.z);
-    }
     fp2 tc;
-    fp2_select(tc, t.role == 0, Q.x, Q.y); fp2_select(tc, t.role == 2, Q.z, tc);
-    fp4 one4, zero4;
-    fp4_zero(zero4); one4 = zero4; fp_one(one4.a.a);
-    fp4_select(F, t.role == 0, one4, zero4);
-    constexpr unsigned __int128 N1 = (unsigned __int128)BLS_X;
-    constexpr unsigned __int128 N3 = N1 * 3;
-#pragma unroll 1
-    for (int i = 64; i >= 1; --i) {
-        f12t_sqr(F, F, t);
-        fp2 l0, l1, l2;
-        miller3_dbl_line(F, tc, px, py, false, t);
-        const int bt = (int)((N3 >> i) & 1) - (int)((N1 >> i) & 1);
-        if (bt != 0) {                                     // wave-uniform; 5 of 64 iterations
-            g2p T, S = Q;
-            tri_fetch_fp2(T.x, tc, 0, t); tri_fetch_fp2(T.y, tc, 1, t); tri_fetch_fp2(T.z, tc, 2, t);
-            if (bt < 0) g2_neg(S, Q);
-            miller_add_step(T, S, l0, l1, l2, px, py);     // replicated on the three lanes
-            fp2_select(tc, t.role == 0, T.x, T.y); fp2_select(tc, t.role == 2, T.z, tc);
-            f12t_mul_line(F, l0, l1, l2, t);
-        }
-    }
-    fp4 c;
-    f12t_conj(c, F, t);
-    fp4_select(F, p_inf, (t.role == 0 ? one4 : zero4), c);
+    miller3_q(Q, qx, qy, q_inf);
+    miller3_tc(tc, Q, t);
+    f12t_one(F, t);
+    miller3_range(F, tc, px, py, p_inf, Q, 64, 1, t);
+    f12t_conj(F, F, t);
 }
-
 // Two Miller loops with SHARED squarings: F = conj(M(Q1, P1) * M(Q2, P2)) — the product the reference forms from two
 // pair_ate results (liner_pair.hpp:339-350) costs one Fp12 squaring per iteration instead of two.  As a field element
 // the result is exactly the product of the two single-loop values (f <- f^2 * l distributes over the product).
-// A pair whose G1 argument is infinity contributes 1 (PAIR_ate :448-449): its lines are replaced by the identity.
 C12381_HDN void miller3_loop2(fp4& F, const fp& px1, const fp& py1, bool p_inf1, const fp2& qx1, const fp2& qy1, bool q_inf1,
                               const fp& px2, const fp& py2, bool p_inf2, const fp2& qx2, const fp2& qy2, bool q_inf2, const tri& t) {
-    g2p Q1, Q2, inf;
-    g2_set_inf(inf);
-    Q1.x = qx1; Q1.y = qy1; fp2_one(Q1.z);
-    Q2.x = qx2; Q2.y = qy2; fp2_one(Q2.z);
-    fp2_select(Q1.x, q_inf1, inf.x, Q1.x); fp2_select(Q1.y, q_inf1, inf.y, Q1.y); fp2_select(Q1.z, q_inf1, inf.z, Q1.z);
-    fp2_select(Q2.x, q_inf2, inf.x, Q2.x); fp2_select(Q2.y, q_inf2, inf.y, Q2.y); fp2_select(Q2.z, q_inf2, inf.z, Q2.z);
-    fp2 tc1, tc2, one2, zero2;
-    fp2_one(one2); fp2_zero(zero2);
-    fp2_select(tc1, t.role == 0, Q1.x, Q1.y); fp2_select(tc1, t.role == 2, Q1.z, tc1);
-    fp2_select(tc2, t.role == 0, Q2.x, Q2.y); fp2_select(tc2, t.role == 2, Q2.z, tc2);
-    fp4 one4, zero4;
-    fp4_zero(zero4); one4 = zero4; fp_one(one4.a.a);
-    fp4_select(F, t.role == 0, one4, zero4);
-    constexpr unsigned __int128 N1 = (unsigned __int128)BLS_X;
-    constexpr unsigned __int128 N3 = N1 * 3;
-#pragma unroll 1
-    for (int i = 64; i >= 1; --i) {
-        f12t_sqr(F, F, t);
-        fp2 l0, l1, l2;
-        miller3_dbl_line(F, tc1, px1, py1, p_inf1, t);
-        miller3_dbl_line(F, tc2, px2, py2, p_inf2, t);
-        const int bt = (int)((N3 >> i) & 1) - (int)((N1 >> i) & 1);
-        if (bt != 0) {                                     // wave-uniform; 5 of 64 iterations
-            g2p T, S;
-            S = Q1;
-            tri_fetch_fp2(T.x, tc1, 0, t); tri_fetch_fp2(T.y, tc1, 1, t); tri_fetch_fp2(T.z, tc1, 2, t);
-            if (bt < 0) g2_neg(S, Q1);
-            miller_add_step(T, S, l0, l1, l2, px1, py1);
-            fp2_select(tc1, t.role == 0, T.x, T.y); fp2_select(tc1, t.role == 2, T.z, tc1);
-            fp2_select(l0, p_inf1, one2, l0); fp2_select(l1, p_inf1, zero2, l1); fp2_select(l2, p_inf1, zero2, l2);
-            f12t_mul_line(F, l0, l1, l2, t);
-            S = Q2;
-            tri_fetch_fp2(T.x, tc2, 0, t); tri_fetch_fp2(T.y, tc2, 1, t); tri_fetch_fp2(T.z, tc2, 2, t);
-            if (bt < 0) g2_neg(S, Q2);
-            miller_add_step(T, S, l0, l1, l2, px2, py2);
-            fp2_select(tc2, t.role == 0, T.x, T.y); fp2_select(tc2, t.role == 2, T.z, tc2);
-            fp2_select(l0, p_inf2, one2, l0); fp2_select(l1, p_inf2, zero2, l1); fp2_select(l2, p_inf2, zero2, l2);
-            f12t_mul_line(F, l0, l1, l2, t);
-        }
-    }
-    fp4 c;
-    f12t_conj(c, F, t);
-    F = c;
+    g2p Q1, Q2;
+    fp2 tc1, tc2;
+    miller3_q(Q1, qx1, qy1, q_inf1); miller3_q(Q2, qx2, qy2, q_inf2);
+    miller3_tc(tc1, Q1, t); miller3_tc(tc2, Q2, t);
+    f12t_one(F, t);
+    miller3_range2(F, tc1, px1, py1, p_inf1, Q1, tc2, px2, py2, p_inf2, Q2, 64, 1, t);
+    f12t_conj(F, F, t);
 }
 
 }  // namespace c12381

@@ -37,8 +37,9 @@ print('variant ok')
 """
 
 
-@pytest.mark.parametrize("env", [{"C12381_PAIR_LANES": "1"}, {"C12381_MSM": "naive"}, {"C12381_MSM": "bucket"}, {"C12381_FIXED_BASE": "0"}],
-                         ids=["one-lane-pairing", "msm-naive", "msm-bucket", "fixed-base-off"])
+@pytest.mark.parametrize("env", [{"C12381_PAIR_LANES": "1"}, {"C12381_MSM": "naive"}, {"C12381_MSM": "bucket"}, {"C12381_FIXED_BASE": "0"},
+                                 {"C12381_PAIR_QUEUE": "1"}, {"C12381_PAIR_QUEUE": "0"}],
+                         ids=["one-lane-pairing", "msm-naive", "msm-bucket", "fixed-base-off", "pair-queue-on", "pair-queue-off"])
 def test_environment_selected_paths(env):
     e = dict(os.environ)
     e.update(env)
