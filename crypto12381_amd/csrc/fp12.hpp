@@ -182,7 +182,9 @@ C12381_HDN void fp12_sqr(fp12& w, const fp12& x) {
 //   wa = 3 xa^2 - 2 conj(xa)                       needs xa only
 //   wb = 3 s xc^2 + 2 conj(xb),  wc = 3 xb^2 - 2 conj(xc)   need xb and xc
 // `reduce` re-bounds the results (fp_weak_reduce) in the same pass.  Outputs may alias inputs.
-C12381_HD void fp4_sqr_core(fp4& w, const fp4& x) {            // fp4_sqr body, inlined into the callers below
+// fp4_sqr body without the final carry round: limbs up to 2^30 (w.a) / 2^29 (w.b) — for callers that add or select
+// before they normalise anyway (the unitary squaring)
+C12381_HD void fp4_sqr_core_raw(fp4& w, const fp4& x) {
     fp2 t1, t2, t3, wa;
     fp2_mul(t3, x.a, x.b);
     fp2_add(t1, x.a, x.b);
@@ -192,10 +194,14 @@ C12381_HD void fp4_sqr_core(fp4& w, const fp4& x) {            // fp4_sqr body, 
     fp2_mul(wa, t1, t2);
     fp2_mul_ip(t2, t3);
     fp2_add(t2, t2, t3);
-    fp2_sub(wa, wa, t2);
-    fp2_dbl(t3, t3);
-    fp2_norm1(w.a, wa);
-    fp2_norm1(w.b, t3);
+    fp2_sub(w.a, wa, t2);
+    fp2_dbl(w.b, t3);
+}
+C12381_HD void fp4_sqr_core(fp4& w, const fp4& x) {            // fp4_sqr body, inlined into the callers below
+    fp4 r;
+    fp4_sqr_core_raw(r, x);
+    fp2_norm1(w.a, r.a);
+    fp2_norm1(w.b, r.b);
 }
 C12381_HDN void fp12_usqr_a(fp4& wa, const fp4& xa, bool reduce) {
     fp4 A, t, u;

@@ -110,11 +110,12 @@ C12381_HDN void f12t_sqr(fp4& w, const fp4& x, const tri& t) {
 //   w_a = 3 xa^2 - 2 conj(xa),  w_b = 3 s xc^2 + 2 conj(xb),  w_c = 3 xb^2 - 2 conj(xc)
 C12381_HDN void f12t_usqr(fp4& w, const fp4& x, bool reduce, const tri& t) {
     fp4 q, qq, sq, three, lin, c1, c2, r;
-    fp4_sqr_core(q, x);
+    fp4_sqr_core_raw(q, x);                                // un-normalised: one carry round after the select below
     const int src = t.role == 0 ? t.role : (t.role == 1 ? tri_next(t) : tri_prev(t));
     tri_fetch_fp4(qq, q, src, t);
-    fp4_times_i(sq, qq); fp4_norm1(sq, sq);
-    fp4_select(qq, t.role == 1, sq, qq);
+    fp4_times_i(sq, qq);
+    fp4_select(sq, t.role == 1, sq, qq);
+    fp4_norm1(qq, sq);
     fp4_add(three, qq, qq); fp4_add(three, three, qq);
     fp4_conj(c1, x); fp4_nconj(c2, x);
     fp4_select(lin, t.role == 1, c1, c2);
