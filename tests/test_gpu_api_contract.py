@@ -1,0 +1,117 @@
+"""GPU test of the C ABI's contract (include/c12381_hip.h): argument errors, empty batches, invalid points reported as
+C12381_E_POINT with an all-0xff output lane while the other lanes stay valid, status collection through c12381_sync
+for the device-pointer entry points, and independence of contexts."""
+import ctypes
+
+import pytest
+
+from util import cat, golden, scalars
+
+pytestmark = pytest.mark.gpu
+
+E_ARG, E_POINT = -1, -3
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    torch.cuda.init()             # torch brings its own HIP runtime: let it load first when both live in one process
+    from crypto12381_amd import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def test_argument_errors(ctx):
+    lib, h = ctx.lib, ctx.h
+    buf = ctypes.create_string_buffer(4096)
+    n = ctypes.c_size_t(1)
+    assert lib.c12381_g1_mul_batch(h, n, None, buf, buf, 49) == E_ARG
+    assert lib.c12381_g1_mul_batch(h, n, buf, buf, buf, 50) == E_ARG              # unknown output format
+    assert lib.c12381_g2_mul_batch(h, n, buf, buf, buf, 96) == E_ARG
+    assert lib.c12381_fp_op_batch(h, 9, n, buf, buf, buf) == E_ARG                # unknown op
+    assert lib.c12381_zp_op_batch(h, 0, n, buf, None, buf) == E_ARG               # binary op without b
+    assert lib.c12381_pair_batch(h, n, buf, None, buf) == E_ARG
+    assert lib.c12381_g1_msm(h, n, None, buf, buf, 49) == E_ARG
+    assert lib.c12381_gt_op_batch(h, 7, n, buf, buf, buf) == E_ARG
+    assert lib.c12381_g1_mul_batch(None, n, buf, buf, buf, 49) == E_ARG           # no context
+    assert lib.c12381_create(0, None) == E_ARG
+    assert lib.c12381_create(99, ctypes.byref(ctypes.c_void_p())) < 0            # no such device: fails, never a CPU fallback
+
+
+def test_empty_batches(ctx):
+    assert ctx.g1_mul(b"", b"", 49) == b""
+    assert ctx.g2_mul(b"", b"", 97) == b""
+    assert ctx.pair(b"", b"") == b""
+    assert ctx.pair_eq(b"", b"", b"", b"") == b""
+    assert ctx.g1_msm(b"", b"", 49) == bytes(49)                                  # the empty product is the identity
+    assert ctx.g1_msm(b"", b"", 96) == bytes(96)
+    assert ctx.fp_op("mul", b"", b"") == b""
+    assert ctx.zp_op("inv", b"") == b""
+    dec, st = ctx.g1_decompress(b"")
+    assert dec == b"" and st == b""
+    assert ctx.g1_mul_fixed(bytes.fromhex(golden("g1")["generator"]), b"", 49) == b""
+
+
+def test_invalid_points_poison_only_their_lane(ctx):
+    from crypto12381_amd import C12381Error
+    g1, g2, gp = golden("g1"), golden("g2"), golden("pairing")
+    p_good = bytes.fromhex(g1["points"][0])
+    p_bad = p_good[:95] + bytes([p_good[95] ^ 1])
+    q_good = bytes.fromhex(g2["points"][0])
+    q_bad = q_good[:191] + bytes([q_good[191] ^ 1])
+    sc = scalars(961, 2)
+    with pytest.raises(C12381Error) as ei:
+        ctx.g2_mul(q_good + q_bad, sc, 97)
+    assert ei.value.code == E_POINT
+    out = ctx.g2_mul(q_good + q_bad, sc, 97, strict=False)
+    assert out[97:] == b"\xff" * 97 and out[:97] == ctx.g2_mul(q_good, sc[:32], 97)
+    out = ctx.g1_add(p_good + p_bad, p_good + p_good, 96, strict=False)
+    assert out[96:] == b"\xff" * 96 and out[:96] == ctx.g1_add(p_good, p_good, 96)
+    gt = ctx.pair(p_good + p_bad + p_good, q_good + q_good + q_bad, strict=False)
+    assert gt[576:] == b"\xff" * 1152 and gt[:576] == ctx.pair(p_good, q_good)
+    ok = ctx.pair_eq(p_good + p_bad, q_good + q_good, p_good + p_good, q_good + q_good, strict=False)
+    assert ok == b"\x01\xff"
+    with pytest.raises(C12381Error):
+        ctx.g1_msm(p_good + p_bad, sc, 49)
+    # a valid call after an error starts clean
+    assert ctx.g1_mul(p_good, sc[:32], 49) == ctx.g1_mul(p_good, sc[:32], 49)
+    # large enough for the work-queue pairing kernels: one bad lane in the middle
+    n = 21 * 2100
+    P = (p_good * n)[: 96 * 1000] + p_bad + (p_good * n)[96 * 1001:]
+    gt = ctx.pair(P, q_good * n, strict=False)
+    one = ctx.pair(p_good, q_good)
+    assert gt[576 * 1000:576 * 1001] == b"\xff" * 576 and gt[:576] == one and gt[-576:] == one and gt[576 * 999:576 * 1000] == one
+
+
+def test_device_pointer_entry_points_report_through_sync(ctx):
+    import torch
+    dev = torch.device("cuda", 0)
+    g = golden("g1")
+    pts, sc = cat(g["points"]), cat(g["scalars"])
+    n = len(sc) // 32
+    bad = bytearray(pts); bad[95] ^= 1
+    dp = torch.frombuffer(bytearray(pts), dtype=torch.uint8).to(dev)
+    db = torch.frombuffer(bad, dtype=torch.uint8).to(dev)
+    ds = torch.frombuffer(bytearray(sc), dtype=torch.uint8).to(dev)
+    out = torch.empty(49 * n, dtype=torch.uint8, device=dev)
+    ctx.g1_mul_dev(n, dp.data_ptr(), ds.data_ptr(), out.data_ptr(), 49)
+    assert ctx.sync() == 0
+    assert bytes(out.cpu().numpy()) == cat(g["mul49"])
+    ctx.g1_mul_dev(n, db.data_ptr(), ds.data_ptr(), out.data_ptr(), 49)
+    assert ctx.sync() == E_POINT                                                   # collected by the sync, then cleared
+    assert ctx.sync() == 0
+    res = bytes(out.cpu().numpy())
+    assert res[:49] == b"\xff" * 49 and res[49:] == cat(g["mul49"])[49:]
+
+
+def test_contexts_are_independent(ctx):
+    from crypto12381_amd import Context
+    g = golden("g1")
+    pts, sc = cat(g["points"]), cat(g["scalars"])
+    other = Context(0)
+    a = ctx.g1_mul(pts, sc, 49)
+    b = other.g1_mul(pts, sc, 96)
+    assert a == cat(g["mul49"]) and b == cat(g["mul96"])
+    other.close()
+    assert ctx.g1_mul(pts, sc, 49) == a                                            # closing one does not disturb the other
