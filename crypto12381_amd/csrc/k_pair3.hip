@@ -110,9 +110,9 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_kernel(size_t n, const uint
 // ------------------------------------------------------------------ work-queue kernels
 // A pairing is ~3.4 M instructions per wavefront and every wavefront task is equally long, so a plain grid finishes in
 // whole "rounds": 3121 wavefronts (2^16 pairings) on 2048 resident slots take two full double rounds although they
-// are 1.52 rounds of work.  Here each group of 21 pairings is FOUR tasks — Miller iterations 64..33, 32..1, the two
-// halves of the final exponentiation — handed out through one atomic counter to a grid that just fills the machine;
-// a wavefront that finishes takes the next task, so the tail is a quarter as long.  Tasks are numbered phase-major
+// are 1.52 rounds of work.  Here each group of 21 pairings is TEN tasks — four quarters of the Miller loop and the six
+// steps of the final exponentiation (f12t_final_exp_step) — handed out through one atomic counter to a grid that just
+// fills the machine; a wavefront that finishes takes the next task, so the tail is a tenth as long.  Tasks are numbered phase-major
 // and a task of phase p waits (spins on the group's flag) only for a task of phase p-1, which never waits for anything
 // of phase >= p: no cycle, every wavefront reaches the end of the queue.  The spin is bounded as a last line of defence.
 template <bool EQ>
@@ -124,7 +124,8 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
     t.role = lane == 63u ? 0 : (int)(lane - 3u * trip);
     t.base = lane == 63u ? 63 : (int)(3u * trip);
     const size_t ngroups = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE;
-    const size_t ntasks = ngroups * 4;
+    constexpr unsigned int MILLER_TASKS = 4, TASKS = MILLER_TASKS + 6;
+    const size_t ntasks = ngroups * TASKS;
     constexpr int ROWS = ST_Y1 + ST_ROWS_F;
     for (;;) {
         // lane 0 claims a task; readfirstlane makes the number a scalar, so phase / group and every branch on them are
@@ -147,7 +148,7 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
             }
         }
         uint4* st = state + g * (size_t)ROWS * 64;
-        if (p <= 1) {
+        if (p < MILLER_TASKS) {
             fp px, py, px2, py2; fp2 qx, qy, qx2, qy2; bool pinf, qinf, pinf2 = true, qinf2 = true, ok, okb = true;
             pair_inputs(px, py, pinf, qx, qy, qinf, ok, a1 + 96 * i, a2 + 192 * i);
             if (!ok) { pinf = true; qinf = true; }
@@ -171,44 +172,46 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
                 st_load<fp2, ST_ROWS_TC>(tc, st + ST_TC1 * 64, lane);
                 if (EQ) st_load<fp2, ST_ROWS_TC>(tc2, st + ST_TC2 * 64, lane);
             }
-            const int hi = p == 0 ? 64 : 32, lo = p == 0 ? 33 : 1;
+            const int hi = 64 - 16 * (int)p, lo = hi - 15;
             if (EQ) miller3_range2(H, tc, px, py, pinf, Q, tc2, px2, py2, pinf2, Q2, hi, lo, t);
             else miller3_range(H, tc, px, py, pinf, Q, hi, lo, t);
-            if (p == 1) f12t_conj(H, H, t);
+            if (p == MILLER_TASKS - 1) f12t_conj(H, H, t);
             st_store<fp4, ST_ROWS_F>(st + ST_F * 64, lane, H);
-            if (p == 0) {
+            if (p < MILLER_TASKS - 1) {
                 st_store<fp2, ST_ROWS_TC>(st + ST_TC1 * 64, lane, tc);
                 if (EQ) st_store<fp2, ST_ROWS_TC>(st + ST_TC2 * 64, lane, tc2);
             }
-        } else if (p == 2) {
-            fp4 r, y1;
-            st_load<fp4, ST_ROWS_F>(r, st + ST_F * 64, lane);
-            f12t_final_exp_a(r, y1, H, t);
-            st_store<fp4, ST_ROWS_F>(st + ST_F * 64, lane, r);
-            st_store<fp4, ST_ROWS_F>(st + ST_Y1 * 64, lane, y1);
         } else {
-            fp4 r, y1;
+            const int step = (int)(p - MILLER_TASKS);
+            fp4 r, y1, aux;                              // aux shares the rows of the (finished) running points
             st_load<fp4, ST_ROWS_F>(r, st + ST_F * 64, lane);
-            st_load<fp4, ST_ROWS_F>(y1, st + ST_Y1 * 64, lane);
-            f12t_final_exp_b(r, y1, H, t);
-            // validity of this lane's inputs (cheap next to the arithmetic; keeps the state slab free of flags)
-            fp px, py; fp2 qx, qy; bool pinf, qinf, ok, okb = true;
-            pair_inputs(px, py, pinf, qx, qy, qinf, ok, a1 + 96 * i, a2 + 192 * i);
-            if (EQ) pair_inputs(px, py, pinf, qx, qy, qinf, okb, b1 + 96 * i, b2 + b2_stride * i);
-            const bool valid = ok && okb;
-            if (EQ) {
-                const bool one = f12t_is_one(r, t);
-                if (active && t.role == 0) {
-                    if (!valid) *bad_flag = 1;
-                    out[e] = valid ? (one ? 1 : 0) : 0xff;
-                }
-            } else if (active) {
-                if (!valid) {
-                    *bad_flag = 1;
-                    uint4* q = reinterpret_cast<uint4*>(out + 576 * e + (t.role == 0 ? 384 : (t.role == 1 ? 192 : 0)));
-                    for (int j = 0; j < 12; ++j) q[j] = make_uint4(~0u, ~0u, ~0u, ~0u);
-                } else {
-                    gt_store_coeff(out + 576 * e, r, t.role);
+            if (step >= 1) st_load<fp4, ST_ROWS_F>(y1, st + ST_Y1 * 64, lane);
+            if (step == 5) st_load<fp4, ST_ROWS_F>(aux, st + ST_TC1 * 64, lane);
+            f12t_final_exp_step(step, r, y1, aux, H, t);
+            if (step < 5) {
+                st_store<fp4, ST_ROWS_F>(st + ST_F * 64, lane, r);
+                if (step == 0) st_store<fp4, ST_ROWS_F>(st + ST_Y1 * 64, lane, y1);
+                if (step == 4) st_store<fp4, ST_ROWS_F>(st + ST_TC1 * 64, lane, aux);
+            } else {
+                // validity of this lane's inputs (cheap next to the arithmetic; keeps the state slab free of flags)
+                fp px, py; fp2 qx, qy; bool pinf, qinf, ok, okb = true;
+                pair_inputs(px, py, pinf, qx, qy, qinf, ok, a1 + 96 * i, a2 + 192 * i);
+                if (EQ) pair_inputs(px, py, pinf, qx, qy, qinf, okb, b1 + 96 * i, b2 + b2_stride * i);
+                const bool valid = ok && okb;
+                if (EQ) {
+                    const bool one = f12t_is_one(r, t);
+                    if (active && t.role == 0) {
+                        if (!valid) *bad_flag = 1;
+                        out[e] = valid ? (one ? 1 : 0) : 0xff;
+                    }
+                } else if (active) {
+                    if (!valid) {
+                        *bad_flag = 1;
+                        uint4* q = reinterpret_cast<uint4*>(out + 576 * e + (t.role == 0 ? 384 : (t.role == 1 ? 192 : 0)));
+                        for (int j = 0; j < 12; ++j) q[j] = make_uint4(~0u, ~0u, ~0u, ~0u);
+                    } else {
+                        gt_store_coeff(out + 576 * e, r, t.role);
+                    }
                 }
             }
         }

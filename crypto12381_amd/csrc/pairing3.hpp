@@ -208,33 +208,38 @@ C12381_HDN void f12t_pow_x(fp4& w, const fp4& a, const tri& t) {
     }
     f12t_conj(w, w, t);
 }
-// PAIR_fexp :629-755 in two pieces (the work-queue kernels schedule them separately).  `h` is working storage for the
-// exponentiations by x (kernels: an LDS slot).  Part A: easy part, y1 = r^3, two of the five exponentiations.
-C12381_HDN void f12t_final_exp_a(fp4& r, fp4& y1, fp4& h, const tri& t) {
+// PAIR_fexp :629-755 as six steps (the work-queue kernels schedule them as separate tasks; state between steps: r, y1
+// and — after step 4 — aux).  `h` is working storage for the exponentiation by x (kernels: an LDS slot).
+//   0: easy part, y1 = r^3      1, 2: r <- r^(x-1)      3: r <- r^(x+p)      4: aux = r^x      5: r <- aux^x r^(p^2-1) y1
+C12381_HDN void f12t_final_exp_step(int step, fp4& r, fp4& y1, fp4& aux, fp4& h, const tri& t) {
     fp4 t0;
-    f12t_inv(t0, r, t);
-    f12t_conj(r, r, t);
-    f12t_mul(r, r, t0, t);
-    f12t_frob(t0, r, t); f12t_frob(t0, t0, t);
-    f12t_mul(r, t0, r, t);
-    f12t_usqr(y1, r, false, t); f12t_mul(y1, y1, r, t);                       // r^3
-    f12t_pow_x(h, r, t); f12t_conj(t0, r, t); f12t_mul(r, h, t0, t);          // r^(x-1)
-    f12t_pow_x(h, r, t); f12t_conj(t0, r, t); f12t_mul(r, h, t0, t);          // r^(x-1)
-}
-C12381_HDN void f12t_final_exp_b(fp4& r, const fp4& y1, fp4& h, const tri& t) {
-    fp4 t0;
-    f12t_pow_x(h, r, t); f12t_frob(t0, r, t); f12t_mul(r, h, t0, t);          // ^(x+p)
-    f12t_pow_x(h, r, t); t0 = h; f12t_pow_x(h, t0, t);                        // r^(x^2)
-    f12t_frob(t0, r, t); f12t_frob(t0, t0, t);                                // r^(p^2)
-    f12t_mul(h, h, t0, t);
-    f12t_conj(t0, r, t);
-    f12t_mul(r, h, t0, t);                                                    // ^(x^2+p^2-1)
-    f12t_mul(r, r, y1, t);
+    if (step == 0) {
+        f12t_inv(t0, r, t);
+        f12t_conj(r, r, t);
+        f12t_mul(r, r, t0, t);
+        f12t_frob(t0, r, t); f12t_frob(t0, t0, t);
+        f12t_mul(r, t0, r, t);
+        f12t_usqr(y1, r, false, t); f12t_mul(y1, y1, r, t);                   // r^3
+    } else if (step <= 3) {
+        f12t_pow_x(h, r, t);
+        if (step == 3) f12t_frob(t0, r, t); else f12t_conj(t0, r, t);
+        f12t_mul(r, h, t0, t);                                                // r^(x-1) twice, then r^(x+p)
+    } else if (step == 4) {
+        f12t_pow_x(h, r, t);
+        aux = h;                                                              // r^x
+    } else {
+        f12t_pow_x(h, aux, t);                                                // r^(x^2)
+        f12t_frob(t0, r, t); f12t_frob(t0, t0, t);                            // r^(p^2)
+        f12t_mul(h, h, t0, t);
+        f12t_conj(t0, r, t);
+        f12t_mul(r, h, t0, t);                                                // ^(x^2+p^2-1)
+        f12t_mul(r, r, y1, t);
+    }
 }
 C12381_HD void f12t_final_exp_ws(fp4& r, fp4& h, const tri& t) {
-    fp4 y1;
-    f12t_final_exp_a(r, y1, h, t);
-    f12t_final_exp_b(r, y1, h, t);
+    fp4 y1, aux;
+#pragma unroll 1
+    for (int step = 0; step < 6; ++step) f12t_final_exp_step(step, r, y1, aux, h, t);
 }
 C12381_HD void f12t_final_exp(fp4& r, const tri& t) {
     fp4 h;
