@@ -43,7 +43,15 @@ def _compile(unit: str, force: bool, verbose: bool) -> str:
         cmd = [HIPCC, *CFLAGS, "-c", "-o", obj, src]
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True)
+        r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+        if r.stderr:
+            print(r.stderr, end="", flush=True)
+        if r.returncode != 0:
+            raise subprocess.CalledProcessError(r.returncode, cmd)
+        # every kernel is built for 2 waves per SIMD; a kernel in the same file with laxer launch bounds silently hands the
+        # shared out-of-line routines a 512-register budget and drags all of them to occupancy 1 — treat that as an error
+        if "failed to meet occupancy target" in r.stderr:
+            raise RuntimeError("%s: a kernel missed its occupancy target (see the compiler warning above)" % unit)
     return obj
 
 

@@ -16,6 +16,7 @@
 #include "g2.hpp"
 #include "msm.hpp"
 #include "fixed_base.hpp"
+#include "pairing3.hpp"
 #include "kernels.hpp"
 
 using namespace c12381;
@@ -42,7 +43,7 @@ struct c12381_ctx {
     std::vector<hipEvent_t> ev_chunk;     // one per chunk of a scalar-mul batch (main -> side dependencies)
     char err[256] = {0};
     enum { WS_TAB, WS_PROJ, WS_PREF, WS_IN0, WS_IN1, WS_OUT, WS_RED0, WS_RED1, WS_BBS_Q, WS_BBS_B, WS_BBS_IN,
-           WS_PAIR_ST, WS_FB_G2, WS_FB_G1_0, WS_FB_G1_1, WS_FB_G1_2, WS_FB_G1_3, WS_MSM_PTS, WS_MSM_K0, WS_MSM_K1, WS_MSM_V0, WS_MSM_V1, WS_MSM_TMP, WS_MSM_RNG, WS_MSM_BK, WS_COUNT };
+           WS_PAIR_ST, WS_FQ_W, WS_FQ_G, WS_FQ_GATE, WS_FB_G2, WS_FB_G1_0, WS_FB_G1_1, WS_FB_G1_2, WS_FB_G1_3, WS_MSM_PTS, WS_MSM_K0, WS_MSM_K1, WS_MSM_V0, WS_MSM_V1, WS_MSM_TMP, WS_MSM_RNG, WS_MSM_BK, WS_COUNT };
     void* ws[WS_COUNT] = {nullptr};
     size_t ws_bytes[WS_COUNT] = {0};
     int* d_flag = nullptr;
@@ -530,13 +531,14 @@ static int launch_pair(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8_t
     HIPCK(c, hipGetLastError());
     return 0;
 }
-static int launch_pair_eq(c12381_ctx* c, size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, size_t b2_stride, uint8_t* ok) {
+static int launch_pair_eq(c12381_ctx* c, size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, size_t b2_stride, uint8_t* ok,
+                          const int32_t* skip_if = nullptr) {
     if (pair_lanes() == 1) hipLaunchKernelGGL(pair_eq_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, a1, a2, b1, b2, b2_stride, ok, c->d_flag);
     else if (pair_use_queue(n)) {
         uint4* st; unsigned int *fl, *ct; unsigned blocks; int rc;
         if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
-        hipLaunchKernelGGL(pair3_eq_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, a1, a2, b1, b2, b2_stride, ok, c->d_flag, st, fl, ct);
-    } else hipLaunchKernelGGL(pair3_eq_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, a1, a2, b1, b2, b2_stride, ok, c->d_flag);
+        hipLaunchKernelGGL(pair3_eq_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, a1, a2, b1, b2, b2_stride, ok, c->d_flag, st, fl, ct, skip_if);
+    } else hipLaunchKernelGGL(pair3_eq_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, a1, a2, b1, b2, b2_stride, ok, c->d_flag, skip_if);
     HIPCK(c, hipGetLastError());
     return 0;
 }
@@ -790,6 +792,21 @@ static int fixed_table(c12381_ctx* c, int slot, const uint8_t* d_base, bool is_g
     HIPCK(c, hipGetLastError());
     return 0;
 }
+// Coefficient table of a fixed G2 argument of the Miller loop (pairing3.hpp): same header / cache protocol as above.
+static int lines_table(c12381_ctx* c, int slot, const uint8_t* d_q192) {
+    const size_t dwords = FB_HEADER_DWORDS + (size_t)FQ_LINES * FQ_LINE_DWORDS;
+    int rc;
+    if (c->ws_bytes[slot] < dwords * 4) {
+        if ((rc = ensure(c, slot, dwords * 4))) return rc;
+        HIPCK(c, hipMemsetAsync(c->ws[slot], 0, FB_HEADER_DWORDS * 4, c->stream));
+    }
+    int32_t* buf = (int32_t*)c->ws[slot];
+    hipLaunchKernelGGL(fixed_cache_check_kernel, dim3(1), dim3(64), 0, c->stream, d_q192, 192, buf);
+    HIPCK(c, hipGetLastError());
+    hipLaunchKernelGGL(g2_lines_table_kernel, dim3(1), dim3(BLOCK), 0, c->stream, d_q192, buf);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
 static bool fixed_base_enabled() {
     static const bool on = [] { const char* e = std::getenv("C12381_FIXED_BASE"); return !(e && e[0] == '0'); }();
     return on;
@@ -863,18 +880,36 @@ int c12381_bbs_plus_verify_batch_dev(c12381_ctx* c, size_t n, size_t nmsg, const
     if ((rc = ensure(c, c12381_ctx::WS_BBS_B, 192 * n))) return rc;
     uint8_t* d_q = (uint8_t*)c->ws[c12381_ctx::WS_BBS_Q];
     uint8_t* d_b = (uint8_t*)c->ws[c12381_ctx::WS_BBS_B];
-    // g2 is one public point: its multiples come from a table when it is a subgroup point (32 additions, no doubling);
-    // otherwise the table stays invalid and the generic kernels below do the work — exactly one of the two paths runs
+    // Both G2 arguments of the equation are public points.  When g2 and w are elements of G2 the equation is evaluated
+    // as e(A, w) * e(x A - B, g2) == 1 (bilinearity in the G2 argument holds for every point A of the curve, and the
+    // cofactor part of the GLV multiple x A pairs to 1), so BOTH Miller loops run against fixed G2 points: their line
+    // coefficients come from two 69-entry tables, no G2 arithmetic per signature at all.  Otherwise — the reference
+    // checks nothing — the generic path below evaluates e(A, w + x g2) == e(B, g2) exactly as written.  `gate` selects:
+    // every kernel of either path reads it and returns at once if it belongs to the other path.
     const bool fb = fixed_base_enabled();
+    const bool fq = fb && pair_lanes() != 1;
+    const int32_t *gate_fast = nullptr, *gate_generic = nullptr;      // skip_if pointers: skip when [48] != 0
+    if (fq) {
+        if ((rc = lines_table(c, c12381_ctx::WS_FQ_W, w_192))) return rc;
+        if ((rc = lines_table(c, c12381_ctx::WS_FQ_G, g2_192))) return rc;
+        if ((rc = ensure(c, c12381_ctx::WS_FQ_GATE, 128 * 4))) return rc;
+        int32_t* gate = (int32_t*)c->ws[c12381_ctx::WS_FQ_GATE];
+        hipLaunchKernelGGL(gate_and_kernel, dim3(1), dim3(BLOCK), 0, c->stream, gate, (const int32_t*)c->ws[c12381_ctx::WS_FQ_W],
+                           (const int32_t*)c->ws[c12381_ctx::WS_FQ_G]);
+        HIPCK(c, hipGetLastError());
+        gate_generic = gate;          // generic kernels: skip when the fixed-G2 path is valid
+        gate_fast = gate + 49;        // kernels that exist only for the fixed-G2 path and take a skip pointer: skip when it is not
+    }
+    // generic path: Q_j = w + x_j g2 (g2's multiples from its fixed-base table when it is a subgroup point)
     const int32_t* skip_g2 = nullptr;
-    if (fb) {
+    if (fb && !fq) {
         if ((rc = fixed_table(c, c12381_ctx::WS_FB_G2, g2_192, true))) return rc;
         skip_g2 = (const int32_t*)c->ws[c12381_ctx::WS_FB_G2];
         hipLaunchKernelGGL(g2_fixed_eval_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, skip_g2, x_32, w_192, d_q, 192, c->d_flag);
         HIPCK(c, hipGetLastError());
     }
-    if ((rc = g2_mul_dev_strided(c, n, g2_192, 0, x_32, d_b, 192, skip_g2))) return rc;
-    hipLaunchKernelGGL(g2_add_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, w_192, (size_t)0, d_b, d_q, 192, c->d_flag, skip_g2);
+    if ((rc = g2_mul_dev_strided(c, n, g2_192, 0, x_32, d_b, 192, fq ? gate_generic : skip_g2))) return rc;
+    hipLaunchKernelGGL(g2_add_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, w_192, (size_t)0, d_b, d_q, 192, c->d_flag, fq ? gate_generic : skip_g2);
     HIPCK(c, hipGetLastError());
     // B_j = g1 + r_j h0 + sum_i m_ij h_i : (nmsg + 1) fixed-base columns of n scalar multiplications, summed per lane
     const size_t cols = nmsg + 1, total = cols * n, stride = round_up(total, 64);
@@ -900,9 +935,24 @@ int c12381_bbs_plus_verify_batch_dev(c12381_ctx* c, size_t n, size_t nmsg, const
     HIPCK(c, hipGetLastError());
     hipLaunchKernelGGL(g1_add_const_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, red, rstride, g1_96, c->d_flag);
     HIPCK(c, hipGetLastError());
+    if (fq) {
+        // fixed-G2 path: red <- x A - B  (x A by the generic scalar multiplication: A differs per signature)
+        if ((rc = g1_mul_to_proj(c, n, A_96, x_32, stride, 96, 0, gate_fast))) return rc;
+        hipLaunchKernelGGL(g1_rsub_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, red, rstride, (const int32_t*)c->ws[c12381_ctx::WS_PROJ], stride,
+                           (size_t)0, gate_generic);
+        HIPCK(c, hipGetLastError());
+    }
     if ((rc = g1_finish(c, n, red, rstride, d_b, 96))) return rc;
     timed tm(c, 4);
-    return launch_pair_eq(c, n, A_96, d_q, d_b, g2_192, (size_t)0, ok);
+    if (fq) {
+        uint4* st; unsigned int *fl, *ct; unsigned blocks;
+        if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
+        hipLaunchKernelGGL(pair3_prod_fixed_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, A_96, d_b,
+                           (const int32_t*)c->ws[c12381_ctx::WS_FQ_W] + FB_HEADER_DWORDS, (const int32_t*)c->ws[c12381_ctx::WS_FQ_G] + FB_HEADER_DWORDS, ok,
+                           c->d_flag, st, fl, ct, gate_generic);
+        HIPCK(c, hipGetLastError());
+    }
+    return launch_pair_eq(c, n, A_96, d_q, d_b, g2_192, (size_t)0, ok, gate_generic);
 }
 int c12381_bbs_plus_verify_batch(c12381_ctx* c, size_t n, size_t nmsg, const uint8_t* g1_96, const uint8_t* g2_192, const uint8_t* h0_96,
                                  const uint8_t* h_96, const uint8_t* w_192, const uint8_t* A_96, const uint8_t* x_32, const uint8_t* r_32,

@@ -218,6 +218,24 @@ __global__ void __launch_bounds__(BLOCK, 2) g1_add_const_kernel(size_t n, int32_
     soa_store_g1(proj, stride, i, o);
 }
 
+// acc[i] <- other[off + i] - acc[i] on projective SoA arrays (BBS+ with fixed G2 arguments: x A - B); runs only when
+// run_if[48] != 0
+__global__ void __launch_bounds__(BLOCK, 2) g1_rsub_kernel(size_t n, int32_t* acc, size_t acc_stride, const int32_t* other, size_t other_stride,
+                                                        size_t other_off, const int32_t* run_if) {
+    if (run_if[48] == 0) return;
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    g1p a, b, o;
+    soa_load_g1(a, acc, acc_stride, i);
+    soa_load_g1(b, other, other_stride, other_off + i);
+    fp ny;
+    fp_neg(ny, a.y);
+    fp_norm1(a.y, ny);
+    g1_add(b, a);
+    g1_norm1(o, b);
+    soa_store_g1(acc, acc_stride, i, o);
+}
+
 __global__ void __launch_bounds__(BLOCK, 2) msm_prep_kernel(size_t n, const uint8_t* pts, const uint8_t* scalars, int c, int W, int32_t* pts2,
                                                          uint32_t* keys, uint32_t* vals, int* bad_flag) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;

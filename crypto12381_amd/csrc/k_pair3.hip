@@ -4,6 +4,7 @@
 //   pair3_eq_kernel    e(a1,a2) == e(b1,b2)
 #include "kernels_common.hpp"
 #include "pairing3.hpp"
+#include "fixed_base.hpp"
 
 using namespace c12381;
 
@@ -75,7 +76,8 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_kernel(size_t n, const uint8_t
 }
 
 __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2,
-                                                         size_t b2_stride, uint8_t* out, int* bad_flag) {
+                                                         size_t b2_stride, uint8_t* out, int* bad_flag, const int32_t* skip_if) {
+    if (skip_if && skip_if[48] != 0) return;          // the fixed-G2 path serves this batch (pair3_prod_fixed_queue_kernel)
     if ((((size_t)blockIdx.x * BLOCK + threadIdx.x) >> 6) * TRI_PER_WAVE >= n) return;
     tri t; size_t i; bool active;
     tri_setup(t, i, active, n);
@@ -227,9 +229,105 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_queue_kernel(size_t n, const u
 }
 __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_queue_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2,
                                                                size_t b2_stride, uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags,
-                                                               unsigned int* counter) {
+                                                               unsigned int* counter, const int32_t* skip_if) {
+    if (skip_if && skip_if[48] != 0) return;
     __shared__ fp4_slot slots[BLOCK];
     pair3_queue_body<true>(n, a1, a2, b1, b2, b2_stride, out, bad_flag, state, flags, counter, slots[threadIdx.x].v);
+}
+
+// ------------------------------------------------------------------ both G2 arguments fixed for the batch
+// Coefficient table of one G2 point (pairing3.hpp, 69 lines) with the header of the fixed-base tables (k_fixed.hip):
+// header[48] = valid (on the twist, not infinity, in G2), header[49] = rebuild requested by fixed_cache_check_kernel.
+// (One working lane, but the launch bounds of every kernel in this file: the out-of-line field routines are compiled
+// once for all their callers, and a kernel that allowed one wave per SIMD would hand them a 512-register budget.)
+__global__ void __launch_bounds__(BLOCK, 2) g2_lines_table_kernel(const uint8_t* q192, int32_t* buf) {
+    if (buf[49] == 0) return;                              // cached table is current
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    g2p Q;
+    bool inf, ok;
+    g2_parse192(Q.x, Q.y, inf, ok, q192);
+    fp2_one(Q.z);
+    const bool valid = ok && !inf && g2_in_subgroup(Q);
+    buf[48] = valid ? 1 : 0;
+    if (valid) miller_lines_precompute(buf + 64, Q.x, Q.y);
+}
+// gate[48] = a valid and b valid (the table-driven kernels run), gate[49] = the opposite (the generic kernels run)
+__global__ void __launch_bounds__(BLOCK, 2) gate_and_kernel(int32_t* gate, const int32_t* a, const int32_t* b) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int both = (a[48] != 0 && b[48] != 0) ? 1 : 0;
+    gate[48] = both;
+    gate[49 + 48] = both ? 0 : 1;                          // read through (gate + 49)[48] by kernels that skip on "generic"
+}
+// ok[i] = [ e(a_i, W) * e(c_i, G) == 1 ] with W, G given by their coefficient tables.  Work queue as above (ten tasks
+// per group); the Miller tasks carry only F.  Runs only when run_if[48] != 0.
+__global__ void __launch_bounds__(BLOCK, 2) pair3_prod_fixed_queue_kernel(size_t n, const uint8_t* a96, const uint8_t* c96, const int32_t* tabw,
+                                                                       const int32_t* tabg, uint8_t* out, int* bad_flag, uint4* state,
+                                                                       unsigned int* flags, unsigned int* counter, const int32_t* run_if) {
+    if (run_if[48] == 0) return;
+    __shared__ fp4_slot slots[BLOCK];
+    fp4& H = slots[threadIdx.x].v;
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned trip = lane / 3u;
+    tri t;
+    t.role = lane == 63u ? 0 : (int)(lane - 3u * trip);
+    t.base = lane == 63u ? 63 : (int)(3u * trip);
+    const size_t ngroups = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE;
+    constexpr unsigned int MILLER_TASKS = 4, TASKS = MILLER_TASKS + 6;
+    const size_t ntasks = ngroups * TASKS;
+    constexpr int ROWS = ST_Y1 + ST_ROWS_F;
+    for (;;) {
+        const unsigned int claimed = atomicAdd(counter, lane == 0 ? 1u : 0u);
+        const unsigned int task = (unsigned int)__builtin_amdgcn_readfirstlane((int)claimed);
+        if ((size_t)task >= ntasks) break;
+        const unsigned int p = (unsigned int)(task / ngroups);
+        const size_t g = task % ngroups;
+        const size_t e = g * TRI_PER_WAVE + (lane == 63u ? TRI_PER_WAVE - 1 : trip);
+        const bool active = lane < 63u && e < n;
+        const size_t i = e < n ? e : n - 1;
+        if (p > 0) {
+            int spins = 0;
+            while ((unsigned int)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&flags[g], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < p) {
+                __builtin_amdgcn_s_sleep(64);
+                if (++spins > (1 << 20)) { if (lane == 0) *bad_flag = 2; break; }
+            }
+        }
+        uint4* st = state + g * (size_t)ROWS * 64;
+        fp ax, ay, cx, cy; bool ainf, cinf, oka, okc;
+        if (p < MILLER_TASKS || p == TASKS - 1) {
+            g1_parse96(ax, ay, ainf, oka, a96 + 96 * i);
+            g1_parse96(cx, cy, cinf, okc, c96 + 96 * i);
+            if (!oka) ainf = true;
+            if (!okc) cinf = true;
+        }
+        if (p < MILLER_TASKS) {
+            if (p == 0) f12t_one(H, t); else st_load<fp4, ST_ROWS_F>(H, st + ST_F * 64, lane);
+            const int hi = 64 - 16 * (int)p, lo = hi - 15;
+            miller3_range2_fixed(H, ax, ay, ainf, tabw, cx, cy, cinf, tabg, hi, lo, t);
+            if (p == MILLER_TASKS - 1) f12t_conj(H, H, t);
+            st_store<fp4, ST_ROWS_F>(st + ST_F * 64, lane, H);
+        } else {
+            const int step = (int)(p - MILLER_TASKS);
+            fp4 r, y1, aux;
+            st_load<fp4, ST_ROWS_F>(r, st + ST_F * 64, lane);
+            if (step >= 1) st_load<fp4, ST_ROWS_F>(y1, st + ST_Y1 * 64, lane);
+            if (step == 5) st_load<fp4, ST_ROWS_F>(aux, st + ST_TC1 * 64, lane);
+            f12t_final_exp_step(step, r, y1, aux, H, t);
+            if (step < 5) {
+                st_store<fp4, ST_ROWS_F>(st + ST_F * 64, lane, r);
+                if (step == 0) st_store<fp4, ST_ROWS_F>(st + ST_Y1 * 64, lane, y1);
+                if (step == 4) st_store<fp4, ST_ROWS_F>(st + ST_TC1 * 64, lane, aux);
+            } else {
+                const bool one = f12t_is_one(r, t);
+                const bool valid = oka && okc;
+                if (active && t.role == 0) {
+                    if (!valid) *bad_flag = 1;
+                    out[e] = valid ? (one ? 1 : 0) : 0xff;
+                }
+            }
+        }
+        __threadfence();
+        if (lane == 0) __hip_atomic_store(&flags[g], p + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 }  // namespace c12381

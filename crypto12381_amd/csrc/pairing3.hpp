@@ -15,6 +15,7 @@
 #include "fp12.hpp"
 #include "g2.hpp"
 #include "pairing.hpp"
+#include "msm.hpp"
 
 namespace c12381 {
 
@@ -372,6 +373,88 @@ C12381_HDN void miller3_range2(fp4& F, fp2& tc1, const fp& px1, const fp& py1, b
         miller3_pair_step(F, tc2, px2, py2, skip2, Q2, i, t);
     }
 }
+// ------------------------------------------------------------------ fixed G2 argument: precomputed lines
+// The running point T and the coefficients of every line depend on Q only:  l0 = c0 * py,  l1 = c1,  l2 = c2 * px
+// (miller_dbl_step / miller_add_step, pairing.hpp).  When a whole batch pairs against ONE Q (the public w and g2 of
+// BBS+ verification) the 69 coefficient triples are computed once — by running the one-lane steps with P = (1, 1) —
+// and an iteration costs four Fp multiplications per line instead of the G2 doubling.
+constexpr int FQ_LINES = 69;                         // 64 doubling steps + 5 addition steps, in loop order
+constexpr int FQ_LINE_DWORDS = 6 * NL;               // c0, c1, c2: 336 B = 21 16-byte words
+constexpr int fq_line_index(int i) {                 // index of iteration i's doubling line (its addition line follows)
+    constexpr unsigned __int128 N1 = (unsigned __int128)BLS_X;
+    constexpr unsigned __int128 N3 = N1 * 3;
+    int k = 0;
+    for (int j = 64; j > i; --j) k += 1 + ((((N3 >> j) & 1) != ((N1 >> j) & 1)) ? 1 : 0);
+    return k;
+}
+C12381_HD void fq_store_line(int32_t* dst, const fp2& c0, const fp2& c1, const fp2& c2) {
+    msm_store_pt(dst, c0.a, c0.b);
+    msm_store_pt(dst + 2 * NL, c1.a, c1.b);
+    msm_store_pt(dst + 4 * NL, c2.a, c2.b);
+}
+C12381_HD void fq_load_line(fp2& c0, fp2& c1, fp2& c2, const int32_t* src) {
+    msm_load_pt(c0.a, c0.b, src);
+    msm_load_pt(c1.a, c1.b, src + 2 * NL);
+    msm_load_pt(c2.a, c2.b, src + 4 * NL);
+}
+// one lane: the whole coefficient table of Q (affine, a valid point of G2 that is not infinity)
+C12381_HDN void miller_lines_precompute(int32_t* tab, const fp2& qx, const fp2& qy) {
+    g2p Q, T;
+    Q.x = qx; Q.y = qy; fp2_one(Q.z);
+    T = Q;
+    fp one;
+    fp_one(one);
+    constexpr unsigned __int128 N1 = (unsigned __int128)BLS_X;
+    constexpr unsigned __int128 N3 = N1 * 3;
+    int k = 0;
+#pragma unroll 1
+    for (int i = 64; i >= 1; --i) {
+        fp2 l0, l1, l2, n0, n1, n2;
+        miller_dbl_step(T, l0, l1, l2, one, one);
+        fp2_norm1(n0, l0); fp2_norm1(n1, l1); fp2_norm1(n2, l2);
+        fq_store_line(tab + (size_t)(k++) * FQ_LINE_DWORDS, n0, n1, n2);
+        const int bt = (int)((N3 >> i) & 1) - (int)((N1 >> i) & 1);
+        if (bt != 0) {
+            g2p S = Q;
+            if (bt < 0) g2_neg(S, Q);
+            miller_add_step(T, S, l0, l1, l2, one, one);
+            fp2_norm1(n0, l0); fp2_norm1(n1, l1); fp2_norm1(n2, l2);
+            fq_store_line(tab + (size_t)(k++) * FQ_LINE_DWORDS, n0, n1, n2);
+        }
+    }
+}
+// f *= line(tab[k]) evaluated at P = (px, py); every lane of the triple forms the three coefficients itself
+C12381_HDN void miller3_fixed_line(fp4& F, const int32_t* tab, int k, const fp& px, const fp& py, bool skip, const tri& t) {
+    fp2 c0, c1, c2, l0, l2, one2, zero2;
+    fq_load_line(c0, c1, c2, tab + (size_t)k * FQ_LINE_DWORDS);
+    fp2_mul_fp(l0, c0, py);
+    fp2_mul_fp(l2, c2, px);
+    fp2_one(one2); fp2_zero(zero2);
+    fp2_select(l0, skip, one2, l0); fp2_select(c1, skip, zero2, c1); fp2_select(l2, skip, zero2, l2);
+    f12t_mul_line_core(F, l0, c1, l2, t);
+}
+// iterations hi .. lo of the joint loop of two pairs whose G2 arguments are both fixed (tables tab1, tab2)
+C12381_HDN void miller3_range2_fixed(fp4& F, const fp& px1, const fp& py1, bool skip1, const int32_t* tab1,
+                                     const fp& px2, const fp& py2, bool skip2, const int32_t* tab2, int hi, int lo, const tri& t) {
+    constexpr unsigned __int128 N1 = (unsigned __int128)BLS_X;
+    constexpr unsigned __int128 N3 = N1 * 3;
+    int k = 0;
+#pragma unroll 1
+    for (int j = 64; j > hi; --j) k += 1 + ((((N3 >> j) & 1) != ((N1 >> j) & 1)) ? 1 : 0);
+#pragma unroll 1
+    for (int i = hi; i >= lo; --i) {
+        f12t_sqr(F, F, t);
+        miller3_fixed_line(F, tab1, k, px1, py1, skip1, t);
+        miller3_fixed_line(F, tab2, k, px2, py2, skip2, t);
+        ++k;
+        if (((N3 >> i) & 1) != ((N1 >> i) & 1)) {           // wave-uniform: addition step of this iteration
+            miller3_fixed_line(F, tab1, k, px1, py1, skip1, t);
+            miller3_fixed_line(F, tab2, k, px2, py2, skip2, t);
+            ++k;
+        }
+    }
+}
+
 // f = conj(Miller_{|x|}(Q, P)) on a triple.  Returns this lane's coefficient.
 C12381_HDN void miller3_loop(fp4& F, const fp& px, const fp& py, bool p_inf, const fp2& qx, const fp2& qy, bool q_inf, const tri& t) {
     g2p Q;

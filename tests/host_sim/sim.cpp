@@ -271,7 +271,7 @@ void c12381_tri_exchange(void* out, const void* in, size_t bytes, int src_role, 
 }
 }
 namespace {
-struct Tri3Job { TriBox* box; int role; size_t n; const uint8_t *a1, *a2, *b1, *b2; uint8_t* out; int mode; };
+struct Tri3Job { TriBox* box; int role; size_t n; const uint8_t *a1, *a2, *b1, *b2; uint8_t* out; int mode; const int32_t *tab1, *tab2; };
 void gt_store_coeff(uint8_t* o576, const fp4& x, int role) {
     // FP12_toOctet order c | b | a, each Fp4 as b.b, b.a, a.b, a.a
     uint8_t* o = o576 + (role == 0 ? 384 : (role == 1 ? 192 : 0));
@@ -286,7 +286,16 @@ void* tri3_worker(void* arg) {
         fp px, py; fp2 qx, qy; bool pinf, qinf;
         fp4 F;
         pair_load(px, py, pinf, qx, qy, qinf, jb->a1 + 96 * i, jb->a2 + 192 * i);
-        if (jb->mode == 1) {          // equality as pair3_eq_kernel evaluates it: joint loop on (a1, a2), (-b1, b2)
+        if (jb->mode == 2) {          // product of two pairings whose G2 arguments are fixed: lines from the tables
+            fp px2, py2; fp2 qx2, qy2; bool pinf2, qinf2;
+            pair_load(px2, py2, pinf2, qx2, qy2, qinf2, jb->b1 + 96 * i, jb->b2);
+            f12t_one(F, t);
+            miller3_range2_fixed(F, px, py, pinf, jb->tab1, px2, py2, pinf2, jb->tab2, 64, 33, t);
+            miller3_range2_fixed(F, px, py, pinf, jb->tab1, px2, py2, pinf2, jb->tab2, 32, 1, t);
+            f12t_conj(F, F, t);
+            f12t_final_exp(F, t);
+            gt_store_coeff(jb->out + 576 * i, F, jb->role);
+        } else if (jb->mode == 1) {          // equality as pair3_eq_kernel evaluates it: joint loop on (a1, a2), (-b1, b2)
             fp px2, py2, ny; fp2 qx2, qy2; bool pinf2, qinf2;
             pair_load(px2, py2, pinf2, qx2, qy2, qinf2, jb->b1 + 96 * i, jb->b2 + 192 * i);
             fp_neg(ny, py2); fp_norm1(py2, ny);
@@ -302,11 +311,12 @@ void* tri3_worker(void* arg) {
     }
     return nullptr;
 }
-int run_tri3(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, uint8_t* out, int mode) {
+int run_tri3(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, uint8_t* out, int mode,
+             const int32_t* tab1 = nullptr, const int32_t* tab2 = nullptr) {
     TriBox box;
     pthread_barrier_init(&box.bar, nullptr, 3);
     pthread_t th[3]; Tri3Job jb[3];
-    for (int r = 0; r < 3; ++r) { jb[r] = Tri3Job{&box, r, n, a1, a2, b1, b2, out, mode}; pthread_create(&th[r], nullptr, tri3_worker, &jb[r]); }
+    for (int r = 0; r < 3; ++r) { jb[r] = Tri3Job{&box, r, n, a1, a2, b1, b2, out, mode, tab1, tab2}; pthread_create(&th[r], nullptr, tri3_worker, &jb[r]); }
     for (int r = 0; r < 3; ++r) pthread_join(th[r], nullptr);
     pthread_barrier_destroy(&box.bar);
     return 0;
@@ -550,3 +560,19 @@ int sim_g2_fixed_mul_batch(size_t n, const uint8_t* base192, const uint8_t* scal
 }
 
 }  // extern "C"
+
+// e(a_i, W) * e(c_i, G) with the two G2 arguments fixed for the batch: coefficient tables + table-driven joint loop
+extern "C" int sim_pair2_fixed_batch(size_t n, const uint8_t* a96, const uint8_t* w192, const uint8_t* c96, const uint8_t* g192, uint8_t* gt576) {
+    std::vector<int32_t> t1v(FQ_LINES * FQ_LINE_DWORDS + 4), t2v(FQ_LINES * FQ_LINE_DWORDS + 4);
+    int32_t* t1 = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(t1v.data()) + 15) & ~(uintptr_t)15);
+    int32_t* t2 = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(t2v.data()) + 15) & ~(uintptr_t)15);
+    fp2 qx, qy;
+    fp2_from_bytes96(qx, w192); fp2_from_bytes96(qy, w192 + 96);
+    miller_lines_precompute(t1, qx, qy);
+    fp2_from_bytes96(qx, g192); fp2_from_bytes96(qy, g192 + 96);
+    miller_lines_precompute(t2, qx, qy);
+    // a2 is only parsed for its infinity flag by pair_load: give every lane the fixed point
+    std::vector<uint8_t> wrep(192 * n);
+    for (size_t i = 0; i < n; ++i) std::memcpy(&wrep[192 * i], w192, 192);
+    return run_tri3(n, a96, wrep.data(), c96, g192, gt576, 2, t1, t2);
+}

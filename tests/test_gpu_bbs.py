@@ -88,8 +88,9 @@ def test_bbs_plus_fixed_base_fallbacks(oracle_port):
     Mm = b"".join(scalars(740 + i, n) for i in range(nmsg))
     A = orc.g1_mul(G1p * n, scalars(733, n), 96)
 
-    def oracle_eval(G2v, h0v, hv):
-        Q = orc.g2_add(w * n, orc.g2_mul(G2v * n, X, 192, 8), 192)
+    def oracle_eval(G2v, h0v, hv, wv=None):
+        wv = wv or w
+        Q = orc.g2_add(wv * n, orc.g2_mul(G2v * n, X, 192, 8), 192)
         Bv = b""
         for j in range(n):
             acc = orc.g1_add(G1p, orc.g1_mul(h0v, Rr[32 * j:32 * j + 32], 96), 96)
@@ -104,4 +105,13 @@ def test_bbs_plus_fixed_base_fallbacks(oracle_port):
                          (off2[:192], h0, off1[96:192] + h[96:]),        # g2 outside G2 and h_1 outside G1
                          (G2p, h0, h)):                                  # back to the first parameters: tables rebuilt
         assert ctx.bbs_plus_verify(G1p, G2v, h0v, hv, w, A, X, Rr, Mm) == oracle_eval(G2v, h0v, hv)
+    # a public key outside G2: the fixed-G2 evaluation e(A, w) e(x A - B, g2) is not used, the equation is evaluated as written
+    w_off = off2[192:384]
+    assert ctx.bbs_plus_verify(G1p, G2p, h0, h, w_off, A, X, Rr, Mm) == oracle_eval(G2p, h0, h, w_off)
+    # signatures (A) outside G1 with valid public parameters: the fixed-G2 path stays exact (the cofactor part pairs to 1)
+    A_off = (off1 * n)[:96 * n]
+    assert ctx.bbs_plus_verify(G1p, G2p, h0, h, w, A_off, X, Rr, Mm) == orc.pair_eq(
+        A_off, orc.g2_add(w * n, orc.g2_mul(G2p * n, X, 192, 8), 192),
+        b"".join(orc.g1_msm(G1p + h0 + h, (1).to_bytes(32, "big") + Rr[32 * j:32 * j + 32] + b"".join(Mm[32 * (n * i + j):32 * (n * i + j) + 32] for i in range(nmsg)), 96, 1)
+                 for j in range(n)), G2p * n, 8)
     ctx.close()

@@ -269,3 +269,16 @@ def test_sim_fixed_base_tables(sim, oracle_port):
     assert sim.sim_g2_fixed_mul_batch(sz(n), base2, sc2, out) == 0
     assert out.raw == oracle_port.g2_mul(base2 * n, sc2, 192)
     assert sim.sim_g2_fixed_mul_batch(sz(1), cat(g["offsubgroup_points"])[:192], sc2, out) == -2
+
+
+def test_sim_fixed_g2_lines(sim, oracle_port):
+    """precomputed line coefficients of a fixed G2 argument + the table-driven joint Miller loop (pairing3.hpp): the
+    product of two pairings must be the reference's pair_double_ate value after the final exponentiation"""
+    g = golden("pairing")
+    g1s = cat(g["g1"])
+    a, c = g1s[:96 * 3] + bytes(96), g1s[96 * 3:96 * 6] + g1s[:96]          # one G1 argument at infinity
+    w, q = cat(g["g2"])[:192], cat(g["g2"])[192:384]
+    n = 4
+    out = ctypes.create_string_buffer(576 * n)
+    assert sim.sim_pair2_fixed_batch(sz(n), a, w, c, q, out) == 0
+    assert out.raw == oracle_port.pair2(a, w * n, c, q * n)
