@@ -64,6 +64,8 @@ def load_library() -> ctypes.CDLL:
             getattr(lib, name).argtypes = [vp, sz, vp, vp, ci]
         for name in ("c12381_g1_mul_fixed_batch", "c12381_g1_mul_fixed_batch_dev", "c12381_g2_mul_fixed_batch", "c12381_g2_mul_fixed_batch_dev"):
             getattr(lib, name).argtypes = [vp, sz, vp, vp, vp, ci]
+        for name in ("c12381_pair_fixed_g2_batch", "c12381_pair_fixed_g2_batch_dev"):
+            getattr(lib, name).argtypes = [vp, sz, vp, vp, vp]
         lib.c12381_g1_msm_multi.argtypes = [ctypes.POINTER(vp), ci, sz, vp, vp, vp, ci]
         lib.c12381_g1_map_to_point_batch.argtypes = [vp, sz, vp, vp]
         lib.c12381_g1_clear_cofactor_batch.argtypes = [vp, sz, vp, vp]
@@ -174,6 +176,15 @@ class Context:
         out = ctypes.create_string_buffer(max(576 * n, 1))
         self._ck(self.lib.c12381_pair_batch(self.h, n, _p(g1), _p(g2), _p(out)), allow_point=not strict)
         return out.raw[:576 * n]
+
+    def pair_fixed_g2(self, g1: bytes, g2_one: bytes, strict: bool = True) -> bytes:
+        n = len(g1) // 96
+        out = ctypes.create_string_buffer(max(576 * n, 1))
+        self._ck(self.lib.c12381_pair_fixed_g2_batch(self.h, n, _p(g1), _p(g2_one), _p(out)), allow_point=not strict)
+        return out.raw[:576 * n]
+
+    def pair_fixed_g2_dev(self, n, g1_ptr, g2_ptr, gt_ptr):
+        self._ck(self.lib.c12381_pair_fixed_g2_batch_dev(self.h, n, _p(g1_ptr), _p(g2_ptr), _p(gt_ptr)))
 
     def pair_eq(self, a1: bytes, a2: bytes, b1: bytes, b2: bytes, strict: bool = True) -> bytes:
         n = len(a1) // 96

@@ -43,7 +43,7 @@ struct c12381_ctx {
     std::vector<hipEvent_t> ev_chunk;     // one per chunk of a scalar-mul batch (main -> side dependencies)
     char err[256] = {0};
     enum { WS_TAB, WS_PROJ, WS_PREF, WS_IN0, WS_IN1, WS_OUT, WS_RED0, WS_RED1, WS_BBS_Q, WS_BBS_B, WS_BBS_IN,
-           WS_PAIR_ST, WS_FQ_W, WS_FQ_G, WS_FQ_GATE, WS_FB_G2, WS_FB_G1_0, WS_FB_G1_1, WS_FB_G1_2, WS_FB_G1_3, WS_MSM_PTS, WS_MSM_K0, WS_MSM_K1, WS_MSM_V0, WS_MSM_V1, WS_MSM_TMP, WS_MSM_RNG, WS_MSM_BK, WS_COUNT };
+           WS_PAIR_ST, WS_FQ_W, WS_FQ_G, WS_FQ_GATE, WS_FQ_P, WS_FB_G2, WS_FB_G1_0, WS_FB_G1_1, WS_FB_G1_2, WS_FB_G1_3, WS_MSM_PTS, WS_MSM_K0, WS_MSM_K1, WS_MSM_V0, WS_MSM_V1, WS_MSM_TMP, WS_MSM_RNG, WS_MSM_BK, WS_COUNT };
     void* ws[WS_COUNT] = {nullptr};
     size_t ws_bytes[WS_COUNT] = {0};
     int* d_flag = nullptr;
@@ -567,6 +567,33 @@ int c12381_pair_batch(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8_t*
     if ((rc = stage_out(c, s, gt, 576 * n))) return rc;
     return read_flag(c);
 }
+static int lines_table(c12381_ctx* c, int slot, const uint8_t* d_q192, int need_g2);
+// gt[i] = e(P_i, Q) with ONE G2 argument for the batch: the 69 line-coefficient triples of Q are computed once (and kept
+// until Q changes), every element then runs the table-driven Miller loop.  Same field elements as the running-point loop,
+// so the GT bytes equal c12381_pair_batch on n copies of Q for every Q, infinity included.
+int c12381_pair_fixed_g2_batch_dev(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2_192, uint8_t* gt) {
+    int rc = bind(c); if (rc) return rc;
+    if (!g1 || !g2_192 || !gt) return C12381_E_ARG;
+    if (n == 0) return 0;
+    if ((rc = lines_table(c, c12381_ctx::WS_FQ_P, g2_192, 0))) return rc;
+    uint4* st; unsigned int *fl, *ct; unsigned blocks;
+    if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
+    timed tm(c, 3);
+    hipLaunchKernelGGL(pair3_fixed_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, g1, (const int32_t*)c->ws[c12381_ctx::WS_FQ_P], gt, c->d_flag,
+                       st, fl, ct);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+int c12381_pair_fixed_g2_batch(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2_192, uint8_t* gt) {
+    int rc = bind(c); if (rc) return rc;
+    if (!g1 || !g2_192 || !gt) return C12381_E_ARG;
+    if (n == 0) return 0;
+    staged s;
+    if ((rc = stage_in(c, s, g1, 96 * n, g2_192, 192, 576 * n))) return rc;
+    if ((rc = c12381_pair_fixed_g2_batch_dev(c, n, s.in0, s.in1, s.out))) return rc;
+    if ((rc = stage_out(c, s, gt, 576 * n))) return rc;
+    return read_flag(c);
+}
 int c12381_pair_eq_batch_dev(c12381_ctx* c, size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, uint8_t* ok) {
     int rc = bind(c); if (rc) return rc;
     if (!a1 || !a2 || !b1 || !b2 || !ok) return C12381_E_ARG;
@@ -793,7 +820,7 @@ static int fixed_table(c12381_ctx* c, int slot, const uint8_t* d_base, bool is_g
     return 0;
 }
 // Coefficient table of a fixed G2 argument of the Miller loop (pairing3.hpp): same header / cache protocol as above.
-static int lines_table(c12381_ctx* c, int slot, const uint8_t* d_q192) {
+static int lines_table(c12381_ctx* c, int slot, const uint8_t* d_q192, int need_g2) {
     const size_t dwords = FB_HEADER_DWORDS + (size_t)FQ_LINES * FQ_LINE_DWORDS;
     int rc;
     if (c->ws_bytes[slot] < dwords * 4) {
@@ -803,7 +830,7 @@ static int lines_table(c12381_ctx* c, int slot, const uint8_t* d_q192) {
     int32_t* buf = (int32_t*)c->ws[slot];
     hipLaunchKernelGGL(fixed_cache_check_kernel, dim3(1), dim3(64), 0, c->stream, d_q192, 192, buf);
     HIPCK(c, hipGetLastError());
-    hipLaunchKernelGGL(g2_lines_table_kernel, dim3(1), dim3(BLOCK), 0, c->stream, d_q192, buf);
+    hipLaunchKernelGGL(g2_lines_table_kernel, dim3(1), dim3(BLOCK), 0, c->stream, d_q192, buf, need_g2);
     HIPCK(c, hipGetLastError());
     return 0;
 }
@@ -890,8 +917,8 @@ int c12381_bbs_plus_verify_batch_dev(c12381_ctx* c, size_t n, size_t nmsg, const
     const bool fq = fb && pair_lanes() != 1;
     const int32_t *gate_fast = nullptr, *gate_generic = nullptr;      // skip_if pointers: skip when [48] != 0
     if (fq) {
-        if ((rc = lines_table(c, c12381_ctx::WS_FQ_W, w_192))) return rc;
-        if ((rc = lines_table(c, c12381_ctx::WS_FQ_G, g2_192))) return rc;
+        if ((rc = lines_table(c, c12381_ctx::WS_FQ_W, w_192, 1))) return rc;
+        if ((rc = lines_table(c, c12381_ctx::WS_FQ_G, g2_192, 1))) return rc;
         if ((rc = ensure(c, c12381_ctx::WS_FQ_GATE, 128 * 4))) return rc;
         int32_t* gate = (int32_t*)c->ws[c12381_ctx::WS_FQ_GATE];
         hipLaunchKernelGGL(gate_and_kernel, dim3(1), dim3(BLOCK), 0, c->stream, gate, (const int32_t*)c->ws[c12381_ctx::WS_FQ_W],

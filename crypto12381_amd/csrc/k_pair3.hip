@@ -240,16 +240,20 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_queue_kernel(size_t n, cons
 // header[48] = valid (on the twist, not infinity, in G2), header[49] = rebuild requested by fixed_cache_check_kernel.
 // (One working lane, but the launch bounds of every kernel in this file: the out-of-line field routines are compiled
 // once for all their callers, and a kernel that allowed one wave per SIMD would hand them a 512-register budget.)
-__global__ void __launch_bounds__(BLOCK, 2) g2_lines_table_kernel(const uint8_t* q192, int32_t* buf) {
-    if (buf[49] == 0) return;                              // cached table is current
+// need_g2 != 0: valid only for elements of G2 other than infinity (BBS+ rewrite); need_g2 == 0: any point of the twist
+// and infinity (plain pairing against one Q: the table holds exactly the lines the running-point loop would compute).
+// header[51] remembers which rule the cached flag was computed under.
+__global__ void __launch_bounds__(BLOCK, 2) g2_lines_table_kernel(const uint8_t* q192, int32_t* buf, int need_g2) {
+    if (buf[49] == 0 && buf[51] == need_g2 + 1) return;    // cached table is current
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     g2p Q;
     bool inf, ok;
     g2_parse192(Q.x, Q.y, inf, ok, q192);
     fp2_one(Q.z);
-    const bool valid = ok && !inf && g2_in_subgroup(Q);
+    const bool valid = need_g2 ? (ok && !inf && g2_in_subgroup(Q)) : ok;
     buf[48] = valid ? 1 : 0;
-    if (valid) miller_lines_precompute(buf + 64, Q.x, Q.y);
+    buf[51] = need_g2 + 1;
+    if (valid) miller_lines_precompute(buf + 64, Q.x, Q.y, inf);
 }
 // gate[48] = a valid and b valid (the table-driven kernels run), gate[49] = the opposite (the generic kernels run)
 __global__ void __launch_bounds__(BLOCK, 2) gate_and_kernel(int32_t* gate, const int32_t* a, const int32_t* b) {
@@ -260,12 +264,12 @@ __global__ void __launch_bounds__(BLOCK, 2) gate_and_kernel(int32_t* gate, const
 }
 // ok[i] = [ e(a_i, W) * e(c_i, G) == 1 ] with W, G given by their coefficient tables.  Work queue as above (ten tasks
 // per group); the Miller tasks carry only F.  Runs only when run_if[48] != 0.
-__global__ void __launch_bounds__(BLOCK, 2) pair3_prod_fixed_queue_kernel(size_t n, const uint8_t* a96, const uint8_t* c96, const int32_t* tabw,
-                                                                       const int32_t* tabg, uint8_t* out, int* bad_flag, uint4* state,
-                                                                       unsigned int* flags, unsigned int* counter, const int32_t* run_if) {
-    if (run_if[48] == 0) return;
-    __shared__ fp4_slot slots[BLOCK];
-    fp4& H = slots[threadIdx.x].v;
+// TWO: product of two pairings, boolean output; otherwise one pairing per element against the table tabw, GT output
+// (an invalid table — Q not on the twist — poisons every output and raises the flag).
+template <bool TWO>
+__device__ __forceinline__ void pair3_fixed_queue_body(size_t n, const uint8_t* a96, const uint8_t* c96, const int32_t* tabw, const int32_t* tabg,
+                                                       uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter,
+                                                       bool table_ok, fp4& H) {
     const unsigned lane = threadIdx.x & 63u;
     const unsigned trip = lane / 3u;
     tri t;
@@ -292,17 +296,20 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_prod_fixed_queue_kernel(size_t
             }
         }
         uint4* st = state + g * (size_t)ROWS * 64;
-        fp ax, ay, cx, cy; bool ainf, cinf, oka, okc;
+        fp ax, ay, cx, cy; bool ainf, cinf = true, oka, okc = true;
         if (p < MILLER_TASKS || p == TASKS - 1) {
             g1_parse96(ax, ay, ainf, oka, a96 + 96 * i);
-            g1_parse96(cx, cy, cinf, okc, c96 + 96 * i);
-            if (!oka) ainf = true;
-            if (!okc) cinf = true;
+            if (!oka || !table_ok) ainf = true;
+            if (TWO) {
+                g1_parse96(cx, cy, cinf, okc, c96 + 96 * i);
+                if (!okc) cinf = true;
+            }
         }
         if (p < MILLER_TASKS) {
             if (p == 0) f12t_one(H, t); else st_load<fp4, ST_ROWS_F>(H, st + ST_F * 64, lane);
             const int hi = 64 - 16 * (int)p, lo = hi - 15;
-            miller3_range2_fixed(H, ax, ay, ainf, tabw, cx, cy, cinf, tabg, hi, lo, t);
+            if (TWO) miller3_range2_fixed(H, ax, ay, ainf, tabw, cx, cy, cinf, tabg, hi, lo, t);
+            else miller3_range_fixed(H, ax, ay, ainf, tabw, hi, lo, t);
             if (p == MILLER_TASKS - 1) f12t_conj(H, H, t);
             st_store<fp4, ST_ROWS_F>(st + ST_F * 64, lane, H);
         } else {
@@ -316,18 +323,39 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_prod_fixed_queue_kernel(size_t
                 st_store<fp4, ST_ROWS_F>(st + ST_F * 64, lane, r);
                 if (step == 0) st_store<fp4, ST_ROWS_F>(st + ST_Y1 * 64, lane, y1);
                 if (step == 4) st_store<fp4, ST_ROWS_F>(st + ST_TC1 * 64, lane, aux);
-            } else {
+            } else if (TWO) {
                 const bool one = f12t_is_one(r, t);
                 const bool valid = oka && okc;
                 if (active && t.role == 0) {
                     if (!valid) *bad_flag = 1;
                     out[e] = valid ? (one ? 1 : 0) : 0xff;
                 }
+            } else if (active) {
+                if (!(oka && table_ok)) {
+                    *bad_flag = 1;
+                    uint4* q = reinterpret_cast<uint4*>(out + 576 * e + (t.role == 0 ? 384 : (t.role == 1 ? 192 : 0)));
+                    for (int j = 0; j < 12; ++j) q[j] = make_uint4(~0u, ~0u, ~0u, ~0u);
+                } else {
+                    gt_store_coeff(out + 576 * e, r, t.role);
+                }
             }
         }
         __threadfence();
         if (lane == 0) __hip_atomic_store(&flags[g], p + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+__global__ void __launch_bounds__(BLOCK, 2) pair3_prod_fixed_queue_kernel(size_t n, const uint8_t* a96, const uint8_t* c96, const int32_t* tabw,
+                                                                       const int32_t* tabg, uint8_t* out, int* bad_flag, uint4* state,
+                                                                       unsigned int* flags, unsigned int* counter, const int32_t* run_if) {
+    if (run_if[48] == 0) return;
+    __shared__ fp4_slot slots[BLOCK];
+    pair3_fixed_queue_body<true>(n, a96, c96, tabw, tabg, out, bad_flag, state, flags, counter, true, slots[threadIdx.x].v);
+}
+// gt[i] = e(P_i, Q) for ONE Q given by its coefficient table (header at `buf`, lines behind it)
+__global__ void __launch_bounds__(BLOCK, 2) pair3_fixed_queue_kernel(size_t n, const uint8_t* g1_96, const int32_t* buf, uint8_t* gt, int* bad_flag,
+                                                                  uint4* state, unsigned int* flags, unsigned int* counter) {
+    __shared__ fp4_slot slots[BLOCK];
+    pair3_fixed_queue_body<false>(n, g1_96, nullptr, buf + 64, nullptr, gt, bad_flag, state, flags, counter, buf[48] != 0, slots[threadIdx.x].v);
 }
 
 }  // namespace c12381

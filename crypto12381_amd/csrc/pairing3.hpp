@@ -373,6 +373,8 @@ C12381_HDN void miller3_range2(fp4& F, fp2& tc1, const fp& px1, const fp& py1, b
         miller3_pair_step(F, tc2, px2, py2, skip2, Q2, i, t);
     }
 }
+C12381_HD void miller3_q(g2p& Q, const fp2& qx, const fp2& qy, bool q_inf);
+
 // ------------------------------------------------------------------ fixed G2 argument: precomputed lines
 // The running point T and the coefficients of every line depend on Q only:  l0 = c0 * py,  l1 = c1,  l2 = c2 * px
 // (miller_dbl_step / miller_add_step, pairing.hpp).  When a whole batch pairs against ONE Q (the public w and g2 of
@@ -397,10 +399,11 @@ C12381_HD void fq_load_line(fp2& c0, fp2& c1, fp2& c2, const int32_t* src) {
     msm_load_pt(c1.a, c1.b, src + 2 * NL);
     msm_load_pt(c2.a, c2.b, src + 4 * NL);
 }
-// one lane: the whole coefficient table of Q (affine, a valid point of G2 that is not infinity)
-C12381_HDN void miller_lines_precompute(int32_t* tab, const fp2& qx, const fp2& qy) {
+// one lane: the whole coefficient table of Q (affine point of the twist; "infinity" runs as (0:1:0) with the affine
+// view (0, 1), exactly as the running-point loop does — the coefficients are the same field elements either way)
+C12381_HDN void miller_lines_precompute(int32_t* tab, const fp2& qx, const fp2& qy, bool q_inf = false) {
     g2p Q, T;
-    Q.x = qx; Q.y = qy; fp2_one(Q.z);
+    miller3_q(Q, qx, qy, q_inf);
     T = Q;
     fp one;
     fp_one(one);
@@ -432,6 +435,20 @@ C12381_HDN void miller3_fixed_line(fp4& F, const int32_t* tab, int k, const fp& 
     fp2_one(one2); fp2_zero(zero2);
     fp2_select(l0, skip, one2, l0); fp2_select(c1, skip, zero2, c1); fp2_select(l2, skip, zero2, l2);
     f12t_mul_line_core(F, l0, c1, l2, t);
+}
+// iterations hi .. lo of the loop of one pair whose G2 argument is fixed (table tab)
+C12381_HDN void miller3_range_fixed(fp4& F, const fp& px, const fp& py, bool skip, const int32_t* tab, int hi, int lo, const tri& t) {
+    constexpr unsigned __int128 N1 = (unsigned __int128)BLS_X;
+    constexpr unsigned __int128 N3 = N1 * 3;
+    int k = 0;
+#pragma unroll 1
+    for (int j = 64; j > hi; --j) k += 1 + ((((N3 >> j) & 1) != ((N1 >> j) & 1)) ? 1 : 0);
+#pragma unroll 1
+    for (int i = hi; i >= lo; --i) {
+        f12t_sqr(F, F, t);
+        miller3_fixed_line(F, tab, k++, px, py, skip, t);
+        if (((N3 >> i) & 1) != ((N1 >> i) & 1)) miller3_fixed_line(F, tab, k++, px, py, skip, t);
+    }
 }
 // iterations hi .. lo of the joint loop of two pairs whose G2 arguments are both fixed (tables tab1, tab2)
 C12381_HDN void miller3_range2_fixed(fp4& F, const fp& px1, const fp& py1, bool skip1, const int32_t* tab1,

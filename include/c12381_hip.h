@@ -135,6 +135,13 @@ int c12381_gt_op_batch(c12381_ctx* ctx, int op, size_t n, const uint8_t* a576, c
 /* is_unity(fp12&) (:197 -> 271-274 -> FP12_isunity): out[i] = 1 / 0. */
 int c12381_gt_is_unity_batch(c12381_ctx* ctx, size_t n, const uint8_t* a576, uint8_t* out);
 
+/* gt[i] = e(g1[i], Q) with ONE G2 argument for the batch (pair(P_i, g2) against a generator or public key — the
+ * shape of every verification equation in the reference's examples): pair_ate + pair_final_exponentiation + to_bytes as
+ * c12381_pair_batch, but the line coefficients of Q are computed once and kept until Q changes.  Identical bytes to
+ * c12381_pair_batch on n copies of Q for every Q (infinity included); Q not on the twist poisons all outputs. */
+int c12381_pair_fixed_g2_batch(c12381_ctx* ctx, size_t n, const uint8_t* g1_96, const uint8_t* g2_192, uint8_t* gt576);
+int c12381_pair_fixed_g2_batch_dev(c12381_ctx* ctx, size_t n, const uint8_t* g1_96, const uint8_t* g2_192, uint8_t* gt576);
+
 /* one base for the whole batch ------------------------------------------------------------------ */
 /* out[i] = scalars[i] * base: g^x with one g — the reference's most common call shape (the cached default generators,
  * g1_point.hpp:257 / g2_point.hpp:246; setup / key_gen of examples/bbs-plus/src/bbs+.cpp:7-36), still `multiply`

@@ -139,3 +139,23 @@ def test_gt_ops_and_split_pairing(ctx, oracle_port):
     assert ctx.fexp(m) == gt
     one = ctx.gt_op("mul", gta, ctx.gt_op("conj", gta))     # unitary: a * conj(a) = 1
     assert ctx.gt_is_unity(one) == b"\x01" * 4 and ctx.gt_is_unity(gta)[:3] == b"\x00" * 3
+
+
+def test_pair_fixed_g2(ctx, oracle_port):
+    """One G2 argument for the batch: table-driven Miller loop, identical GT bytes to the general entry point."""
+    g = golden("pairing")
+    g1s, g2s = cat(g["g1"]), cat(g["g2"])
+    n = len(g1s) // 96
+    for k in (0, 5, 7):                                     # an ordinary point, the generator, infinity (row 7 of the golden set)
+        q = g2s[192 * k:192 * k + 192]
+        assert ctx.pair_fixed_g2(g1s, q) == ctx.pair(g1s, q * n)
+    assert ctx.pair_fixed_g2(g1s, g2s[:192]) == oracle_port.pair(g1s, g2s[:192] * n, 4)
+    off = cat(golden("g2")["offsubgroup_points"])[:192]     # on the twist, outside G2: still the same lines
+    assert ctx.pair_fixed_g2(g1s, off) == ctx.pair(g1s, off * n)
+    m = 5000                                                # ragged size, several work-queue groups
+    p = (g1s * (m // n + 1))[:96 * m]
+    got = ctx.pair_fixed_g2(p, g2s[192:384])
+    assert got[:576 * n] == ctx.pair(g1s, g2s[192:384] * n) and got[-576:] == ctx.pair(p[-96:], g2s[192:384])
+    bad = g2s[:191] + bytes([g2s[191] ^ 1])
+    assert ctx.pair_fixed_g2(g1s, bad, strict=False) == b"\xff" * (576 * n)
+    assert ctx.pair_fixed_g2(b"", g2s[:192]) == b""
