@@ -915,7 +915,7 @@ int c12381_bbs_plus_verify_batch_dev(c12381_ctx* c, size_t n, size_t nmsg, const
     // every kernel of either path reads it and returns at once if it belongs to the other path.
     const bool fb = fixed_base_enabled();
     const bool fq = fb && pair_lanes() != 1;
-    const int32_t *gate_fast = nullptr, *gate_generic = nullptr;      // skip_if pointers: skip when [48] != 0
+    const int32_t *gate_fast = nullptr, *gate_generic = nullptr;      // skip_if pointers: skip when [HDR_VALID] != 0
     if (fq) {
         if ((rc = lines_table(c, c12381_ctx::WS_FQ_W, w_192, 1))) return rc;
         if ((rc = lines_table(c, c12381_ctx::WS_FQ_G, g2_192, 1))) return rc;
@@ -925,7 +925,7 @@ int c12381_bbs_plus_verify_batch_dev(c12381_ctx* c, size_t n, size_t nmsg, const
                            (const int32_t*)c->ws[c12381_ctx::WS_FQ_G]);
         HIPCK(c, hipGetLastError());
         gate_generic = gate;          // generic kernels: skip when the fixed-G2 path is valid
-        gate_fast = gate + 49;        // kernels that exist only for the fixed-G2 path and take a skip pointer: skip when it is not
+        gate_fast = gate + GATE_OTHER;        // kernels that exist only for the fixed-G2 path and take a skip pointer: skip when it is not
     }
     // generic path: Q_j = w + x_j g2 (g2's multiples from its fixed-base table when it is a subgroup point)
     const int32_t* skip_g2 = nullptr;

@@ -20,7 +20,7 @@ constexpr int FB_ENTRIES = 255;                       // digits 1..255 of an 8-b
 constexpr int FB_G1_WINDOWS = 16, FB_G2_WINDOWS = 8;
 constexpr int FB_G1_DWORDS = MSM_PT_DWORDS;           // affine (x, y) Montgomery, 112 B
 constexpr int FB_G2_DWORDS = 4 * NL;                  // affine (x.a, x.b, y.a, y.b), 224 B
-constexpr int FB_HEADER_DWORDS = 64;                  // cached base bytes (up to 192) + state words, in front of the table
+constexpr int FB_HEADER_DWORDS = 64;                  // cached base bytes (up to 192) + state words (kernels.hpp: HDR_*), in front of the table
 
 // P in G1  <=>  phi(P) = [-x^2]P  <=>  [x^2]P + (beta X : Y : Z) = infinity   (kernel of phi - lambda has order r)
 C12381_HDN bool g1_in_subgroup(const g1p& p) {

@@ -1,8 +1,8 @@
 // Fixed-base columns (fixed_base.hpp): table construction with a device-side "same base as last time?" check, and
 // the table-driven evaluation kernels.  Table buffer = FB_HEADER_DWORDS header (cached base bytes, state) + entries.
 //   header[0..47]  the base's canonical bytes as dwords (96 B for G1, 192 B for G2)
-//   header[48]     ok: 1 = table valid (base on the curve, not infinity, in the order-r subgroup)
-//   header[49]     build: 1 = the table kernel must (re)build, 0 = cached table matches the base
+//   header[HDR_VALID]    ok: 1 = table valid (base on the curve, not infinity, in the order-r subgroup)
+//   header[HDR_REBUILD]  build: 1 = the table kernel must (re)build, 0 = cached table matches the base
 #include "kernels_common.hpp"
 #include "fixed_base.hpp"
 
@@ -17,21 +17,21 @@ __global__ void __launch_bounds__(64, 1) fixed_cache_check_kernel(const uint8_t*
     const uint32_t* b = reinterpret_cast<const uint32_t*>(base);
     uint32_t mine = 0, cached = 0;
     if (lane < nd) { mine = b[lane]; cached = (uint32_t)header[lane]; }
-    const bool same = __all(mine == cached) && header[50] == 0x46423031;      // magic: the header has been written before
+    const bool same = __all(mine == cached) && header[HDR_MAGIC] == 0x46423031;      // magic: the header has been written before
     if (lane < nd) header[lane] = (int32_t)mine;
-    if (lane == 0) { header[49] = same ? 0 : 1; header[50] = 0x46423031; if (!same) header[48] = 0; }
+    if (lane == 0) { header[HDR_REBUILD] = same ? 0 : 1; header[HDR_MAGIC] = 0x46423031; if (!same) header[HDR_VALID] = 0; }
 }
 
 __global__ void __launch_bounds__(BLOCK, 2) g1_fixed_table_kernel(const uint8_t* base96, int32_t* buf) {
     int32_t* header = buf;
-    if (header[49] == 0) return;                                   // cached table is current
+    if (header[HDR_REBUILD] == 0) return;                                   // cached table is current
     const size_t L = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (L >= (size_t)FB_G1_WINDOWS * FB_ENTRIES) return;
     g1p base;
     bool inf, ok;
     g1_parse96(base.x, base.y, inf, ok, base96);
     fp_one(base.z);
-    if (L == 0) header[48] = (ok && !inf && g1_in_subgroup(base)) ? 1 : 0;
+    if (L == 0) header[HDR_VALID] = (ok && !inf && g1_in_subgroup(base)) ? 1 : 0;
     if (!ok || inf) return;
     const int j = (int)(L / FB_ENTRIES);
     const uint32_t d = (uint32_t)(L % FB_ENTRIES) + 1u;
@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(BLOCK, 2) g1_fixed_table_kernel(const uint8_t*
 // proj[off + i] = [k_i]B from the table; does nothing when the table is not valid (the generic kernel runs then)
 __global__ void __launch_bounds__(BLOCK, 2) g1_fixed_eval_kernel(size_t n, const int32_t* buf, const uint8_t* scalars, int32_t* proj, size_t proj_stride,
                                                               size_t proj_off) {
-    if (buf[48] == 0) return;
+    if (buf[HDR_VALID] == 0) return;
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     uint32_t raw[8], k[8];
@@ -63,14 +63,14 @@ __global__ void __launch_bounds__(BLOCK, 2) g1_fixed_eval_kernel(size_t n, const
 
 __global__ void __launch_bounds__(BLOCK, 2) g2_fixed_table_kernel(const uint8_t* base192, int32_t* buf) {
     int32_t* header = buf;
-    if (header[49] == 0) return;
+    if (header[HDR_REBUILD] == 0) return;
     const size_t L = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (L >= (size_t)FB_G2_WINDOWS * FB_ENTRIES) return;
     g2p base;
     bool inf, ok;
     g2_parse192(base.x, base.y, inf, ok, base192);
     fp2_one(base.z);
-    if (L == 0) header[48] = (ok && !inf && g2_in_subgroup(base)) ? 1 : 0;
+    if (L == 0) header[HDR_VALID] = (ok && !inf && g2_in_subgroup(base)) ? 1 : 0;
     if (!ok || inf) return;
     const int j = (int)(L / FB_ENTRIES);
     const uint32_t d = (uint32_t)(L % FB_ENTRIES) + 1u;
@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(BLOCK, 2) g2_fixed_table_kernel(const uint8_t*
 // Does nothing when the table is not valid.
 __global__ void __launch_bounds__(BLOCK, 2) g2_fixed_eval_kernel(size_t n, const int32_t* buf, const uint8_t* scalars, const uint8_t* addend192,
                                                               uint8_t* out, int fmt, int* bad_flag) {
-    if (buf[48] == 0) return;
+    if (buf[HDR_VALID] == 0) return;
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     uint32_t raw[8], k[8];

@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(BLOCK, 2) fp_mulchain_kernel(size_t n, int ite
 // pt_stride = 96 for per-lane points, 0 to broadcast one point to every lane (fixed-base columns of BBS+)
 __global__ void __launch_bounds__(BLOCK, 2) g1_mul_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab,
                                                        int32_t* proj, size_t proj_stride, size_t proj_off, int* bad_flag, const int32_t* skip_if) {
-    if (skip_if && skip_if[48] != 0) return;          // this column is served by a valid fixed-base table (k_fixed.hip)
+    if (skip_if && skip_if[HDR_VALID] != 0) return;          // this column is served by a valid fixed-base table (k_fixed.hip)
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     fp px, py;
@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(BLOCK, 2) g1_mul_kernel(size_t n, const uint8_
 // other lane — with random scalars: all of them — leaves after reading its scalar.
 __global__ void __launch_bounds__(BLOCK, 2) g1_small_scalar_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars,
                                                                 int32_t* proj, size_t proj_stride, size_t proj_off, const int32_t* skip_if) {
-    if (skip_if && skip_if[48] != 0) return;
+    if (skip_if && skip_if[HDR_VALID] != 0) return;
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     uint32_t raw[8], k[8];
@@ -219,10 +219,10 @@ __global__ void __launch_bounds__(BLOCK, 2) g1_add_const_kernel(size_t n, int32_
 }
 
 // acc[i] <- other[off + i] - acc[i] on projective SoA arrays (BBS+ with fixed G2 arguments: x A - B); runs only when
-// run_if[48] != 0
+// run_if[HDR_VALID] != 0
 __global__ void __launch_bounds__(BLOCK, 2) g1_rsub_kernel(size_t n, int32_t* acc, size_t acc_stride, const int32_t* other, size_t other_stride,
                                                         size_t other_off, const int32_t* run_if) {
-    if (run_if[48] == 0) return;
+    if (run_if[HDR_VALID] == 0) return;
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     g1p a, b, o;

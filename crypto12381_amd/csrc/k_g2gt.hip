@@ -13,7 +13,7 @@ namespace c12381 {
 
 __global__ void __launch_bounds__(BLOCK, 2) g2_mul_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab,
                                                        size_t tab_stride, uint8_t* out, int fmt, int* bad_flag, const int32_t* skip_if) {
-    if (skip_if && skip_if[48] != 0) return;          // served by a valid fixed-base table (k_fixed.hip)
+    if (skip_if && skip_if[HDR_VALID] != 0) return;          // served by a valid fixed-base table (k_fixed.hip)
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     fp2 qx, qy;
@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(BLOCK, 2) g2_mul_kernel(size_t n, const uint8_
 
 __global__ void __launch_bounds__(BLOCK, 2) g2_add_kernel(size_t n, const uint8_t* a, size_t a_stride, const uint8_t* b, uint8_t* out, int fmt,
                                                        int* bad_flag, const int32_t* skip_if) {
-    if (skip_if && skip_if[48] != 0) return;
+    if (skip_if && skip_if[HDR_VALID] != 0) return;
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     g2p p, q, inf_pt;

@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_kernel(size_t n, const uint8_t
 
 __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2,
                                                          size_t b2_stride, uint8_t* out, int* bad_flag, const int32_t* skip_if) {
-    if (skip_if && skip_if[48] != 0) return;          // the fixed-G2 path serves this batch (pair3_prod_fixed_queue_kernel)
+    if (skip_if && skip_if[HDR_VALID] != 0) return;          // the fixed-G2 path serves this batch (pair3_prod_fixed_queue_kernel)
     if ((((size_t)blockIdx.x * BLOCK + threadIdx.x) >> 6) * TRI_PER_WAVE >= n) return;
     tri t; size_t i; bool active;
     tri_setup(t, i, active, n);
@@ -230,40 +230,40 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_queue_kernel(size_t n, const u
 __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_queue_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2,
                                                                size_t b2_stride, uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags,
                                                                unsigned int* counter, const int32_t* skip_if) {
-    if (skip_if && skip_if[48] != 0) return;
+    if (skip_if && skip_if[HDR_VALID] != 0) return;
     __shared__ fp4_slot slots[BLOCK];
     pair3_queue_body<true>(n, a1, a2, b1, b2, b2_stride, out, bad_flag, state, flags, counter, slots[threadIdx.x].v);
 }
 
 // ------------------------------------------------------------------ both G2 arguments fixed for the batch
 // Coefficient table of one G2 point (pairing3.hpp, 69 lines) with the header of the fixed-base tables (k_fixed.hip):
-// header[48] = valid (on the twist, not infinity, in G2), header[49] = rebuild requested by fixed_cache_check_kernel.
+// header[HDR_VALID] = valid (on the twist, not infinity, in G2), header[HDR_REBUILD] = rebuild requested by fixed_cache_check_kernel.
 // (One working lane, but the launch bounds of every kernel in this file: the out-of-line field routines are compiled
 // once for all their callers, and a kernel that allowed one wave per SIMD would hand them a 512-register budget.)
 // need_g2 != 0: valid only for elements of G2 other than infinity (BBS+ rewrite); need_g2 == 0: any point of the twist
 // and infinity (plain pairing against one Q: the table holds exactly the lines the running-point loop would compute).
-// header[51] remembers which rule the cached flag was computed under.
+// header[HDR_RULE] remembers which rule the cached flag was computed under.
 __global__ void __launch_bounds__(BLOCK, 2) g2_lines_table_kernel(const uint8_t* q192, int32_t* buf, int need_g2) {
-    if (buf[49] == 0 && buf[51] == need_g2 + 1) return;    // cached table is current
+    if (buf[HDR_REBUILD] == 0 && buf[HDR_RULE] == need_g2 + 1) return;    // cached table is current
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     g2p Q;
     bool inf, ok;
     g2_parse192(Q.x, Q.y, inf, ok, q192);
     fp2_one(Q.z);
     const bool valid = need_g2 ? (ok && !inf && g2_in_subgroup(Q)) : ok;
-    buf[48] = valid ? 1 : 0;
-    buf[51] = need_g2 + 1;
-    if (valid) miller_lines_precompute(buf + 64, Q.x, Q.y, inf);
+    buf[HDR_VALID] = valid ? 1 : 0;
+    buf[HDR_RULE] = need_g2 + 1;
+    if (valid) miller_lines_precompute(buf + HDR_DWORDS, Q.x, Q.y, inf);
 }
-// gate[48] = a valid and b valid (the table-driven kernels run), gate[49] = the opposite (the generic kernels run)
+// gate[HDR_VALID] = a valid and b valid (the table-driven kernels run), (gate + GATE_OTHER)[HDR_VALID] = the opposite (the generic kernels run)
 __global__ void __launch_bounds__(BLOCK, 2) gate_and_kernel(int32_t* gate, const int32_t* a, const int32_t* b) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const int both = (a[48] != 0 && b[48] != 0) ? 1 : 0;
-    gate[48] = both;
-    gate[49 + 48] = both ? 0 : 1;                          // read through (gate + 49)[48] by kernels that skip on "generic"
+    const int both = (a[HDR_VALID] != 0 && b[HDR_VALID] != 0) ? 1 : 0;
+    gate[HDR_VALID] = both;
+    gate[GATE_OTHER + HDR_VALID] = both ? 0 : 1;          // read as (gate + GATE_OTHER)[HDR_VALID] by kernels that skip on "generic"
 }
 // ok[i] = [ e(a_i, W) * e(c_i, G) == 1 ] with W, G given by their coefficient tables.  Work queue as above (ten tasks
-// per group); the Miller tasks carry only F.  Runs only when run_if[48] != 0.
+// per group); the Miller tasks carry only F.  Runs only when run_if[HDR_VALID] != 0.
 // TWO: product of two pairings, boolean output; otherwise one pairing per element against the table tabw, GT output
 // (an invalid table — Q not on the twist — poisons every output and raises the flag).
 template <bool TWO>
@@ -347,7 +347,7 @@ __device__ __forceinline__ void pair3_fixed_queue_body(size_t n, const uint8_t* 
 __global__ void __launch_bounds__(BLOCK, 2) pair3_prod_fixed_queue_kernel(size_t n, const uint8_t* a96, const uint8_t* c96, const int32_t* tabw,
                                                                        const int32_t* tabg, uint8_t* out, int* bad_flag, uint4* state,
                                                                        unsigned int* flags, unsigned int* counter, const int32_t* run_if) {
-    if (run_if[48] == 0) return;
+    if (run_if[HDR_VALID] == 0) return;
     __shared__ fp4_slot slots[BLOCK];
     pair3_fixed_queue_body<true>(n, a96, c96, tabw, tabg, out, bad_flag, state, flags, counter, true, slots[threadIdx.x].v);
 }
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_prod_fixed_queue_kernel(size_t
 __global__ void __launch_bounds__(BLOCK, 2) pair3_fixed_queue_kernel(size_t n, const uint8_t* g1_96, const int32_t* buf, uint8_t* gt, int* bad_flag,
                                                                   uint4* state, unsigned int* flags, unsigned int* counter) {
     __shared__ fp4_slot slots[BLOCK];
-    pair3_fixed_queue_body<false>(n, g1_96, nullptr, buf + 64, nullptr, gt, bad_flag, state, flags, counter, buf[48] != 0, slots[threadIdx.x].v);
+    pair3_fixed_queue_body<false>(n, g1_96, nullptr, buf + HDR_DWORDS, nullptr, gt, bad_flag, state, flags, counter, buf[HDR_VALID] != 0, slots[threadIdx.x].v);
 }
 
 }  // namespace c12381

@@ -15,7 +15,14 @@ namespace c12381 {
 
 constexpr int BLOCK = 256;
 constexpr int FINISH_M = 16;                     // elements per lane in the simultaneous inversion
-constexpr int TRI_PER_WAVE = 21;                 // pairings per 64-lane wave in the three-lane kernels (lane 63 idles)
+constexpr int TRI_PER_WAVE = 21;
+// Header words in front of a device-built table (fixed-base multiples, line coefficients) and of a gate buffer
+constexpr int HDR_VALID = 48;                    // 1 = table usable / this path runs; kernels of the other path return at once
+constexpr int HDR_REBUILD = 49;                  // set by fixed_cache_check_kernel when the cached point differs
+constexpr int HDR_MAGIC = 50;                    // the header has been written before
+constexpr int HDR_RULE = 51;                     // validity rule the flag was computed under (line tables)
+constexpr int HDR_DWORDS = 64;                   // table data starts here
+constexpr int GATE_OTHER = 49;                   // (gate + GATE_OTHER)[HDR_VALID] = the complement of gate[HDR_VALID]                 // pairings per 64-lane wave in the three-lane kernels (lane 63 idles)
 
 __global__ void __launch_bounds__(BLOCK, 2) fp_op_kernel(int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out);
 __global__ void __launch_bounds__(BLOCK, 2) fp_mulchain_kernel(size_t n, int iters, const uint8_t* a, const uint8_t* b, uint8_t* out);
