@@ -66,6 +66,8 @@ def load_library() -> ctypes.CDLL:
             getattr(lib, name).argtypes = [vp, sz, vp, vp, vp, ci]
         for name in ("c12381_pair_fixed_g2_batch", "c12381_pair_fixed_g2_batch_dev"):
             getattr(lib, name).argtypes = [vp, sz, vp, vp, vp]
+        for name in ("c12381_bbs_plus_sign_batch", "c12381_bbs_plus_sign_batch_dev"):
+            getattr(lib, name).argtypes = [vp, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.c12381_g1_msm_multi.argtypes = [ctypes.POINTER(vp), ci, sz, vp, vp, vp, ci]
         lib.c12381_g1_map_to_point_batch.argtypes = [vp, sz, vp, vp]
         lib.c12381_g1_clear_cofactor_batch.argtypes = [vp, sz, vp, vp]
@@ -298,6 +300,13 @@ class Context:
                                                            _p(m), _p(ok)))
 
     # ---- device-pointer entry points (ints = device addresses, e.g. torch tensor.data_ptr())
+    def bbs_plus_sign(self, g1, h0, h, gamma32, x, r, m) -> bytes:
+        n = len(x) // 32
+        nmsg = len(h) // 96
+        out = ctypes.create_string_buffer(max(96 * n, 1))
+        self._ck(self.lib.c12381_bbs_plus_sign_batch(self.h, n, nmsg, _p(g1), _p(h0), _p(h), _p(gamma32), _p(x), _p(r), _p(m), _p(out)))
+        return out.raw[:96 * n]
+
     def g1_from_hash_dev(self, n, digests_ptr, out_ptr, fmt=96):
         self._ck(self.lib.c12381_g1_from_hash_batch_dev(self.h, n, _p(digests_ptr), _p(out_ptr), fmt))
 

@@ -891,6 +891,39 @@ int c12381_g2_mul_fixed_batch(c12381_ctx* c, size_t n, const uint8_t* base192, c
     return read_flag(c);
 }
 
+// B_j = g1 + r_j h0 + sum_i m_ij h_i for a batch of BBS+ signatures (bbs+.cpp:51, :72): (nmsg + 1) columns of n scalar
+// multiplications with ONE base each — table-driven for subgroup bases, generic otherwise — summed per lane.  Result:
+// projective SoA in WS_RED0 (`red`, stride `rstride`); `stride` is the stride of the column workspace WS_PROJ.
+static int bbs_message_points(c12381_ctx* c, size_t n, size_t nmsg, const uint8_t* g1_96, const uint8_t* h0_96, const uint8_t* h_96, const uint8_t* r_32,
+                              const uint8_t* m_32, bool fb, int32_t*& red, size_t& rstride, size_t& stride) {
+    int rc;
+    const size_t cols = nmsg + 1, total = cols * n;
+    stride = round_up(total, 64);
+    if ((rc = ensure(c, c12381_ctx::WS_PROJ, (size_t)3 * NL * stride * 4))) return rc;
+    for (size_t col = 0; col < cols; ++col) {
+        const uint8_t* base = col == 0 ? h0_96 : h_96 + 96 * (col - 1);
+        const uint8_t* sc = col == 0 ? r_32 : m_32 + 32 * n * (col - 1);
+        const int32_t* skip = nullptr;
+        if (fb && col < 4) {                                   // table slots for h0 and the first three h_i
+            const int slot = c12381_ctx::WS_FB_G1_0 + (int)col;
+            if ((rc = fixed_table(c, slot, base, false))) return rc;
+            skip = (const int32_t*)c->ws[slot];
+            hipLaunchKernelGGL(g1_fixed_eval_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, skip, sc, (int32_t*)c->ws[c12381_ctx::WS_PROJ],
+                               stride, col * n);
+            HIPCK(c, hipGetLastError());
+        }
+        if ((rc = g1_mul_to_proj(c, n, base, sc, stride, 0, col * n, skip))) return rc;
+    }
+    rstride = round_up(n, 64);
+    if ((rc = ensure(c, c12381_ctx::WS_RED0, (size_t)3 * NL * rstride * 4))) return rc;
+    red = (int32_t*)c->ws[c12381_ctx::WS_RED0];
+    hipLaunchKernelGGL(g1_reduce_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, total, (const int32_t*)c->ws[c12381_ctx::WS_PROJ], stride, n, red, rstride);
+    HIPCK(c, hipGetLastError());
+    hipLaunchKernelGGL(g1_add_const_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, red, rstride, g1_96, c->d_flag);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+
 // ---------------------------------------------------------------- BBS+ batch verification
 // ok[j] = [ e(A_j, w + x_j g2) == e(g1 + r_j h0 + sum_i m_{i,j} h_i, g2) ]   — the verification equation of the
 // reference's examples/bbs-plus/src/bbs+.cpp:57-73, evaluated as liner_pair.hpp:339-350 does (two Miller loops,
@@ -938,30 +971,8 @@ int c12381_bbs_plus_verify_batch_dev(c12381_ctx* c, size_t n, size_t nmsg, const
     if ((rc = g2_mul_dev_strided(c, n, g2_192, 0, x_32, d_b, 192, fq ? gate_generic : skip_g2))) return rc;
     hipLaunchKernelGGL(g2_add_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, w_192, (size_t)0, d_b, d_q, 192, c->d_flag, fq ? gate_generic : skip_g2);
     HIPCK(c, hipGetLastError());
-    // B_j = g1 + r_j h0 + sum_i m_ij h_i : (nmsg + 1) fixed-base columns of n scalar multiplications, summed per lane
-    const size_t cols = nmsg + 1, total = cols * n, stride = round_up(total, 64);
-    if ((rc = ensure(c, c12381_ctx::WS_PROJ, (size_t)3 * NL * stride * 4))) return rc;
-    for (size_t col = 0; col < cols; ++col) {
-        const uint8_t* base = col == 0 ? h0_96 : h_96 + 96 * (col - 1);
-        const uint8_t* sc = col == 0 ? r_32 : m_32 + 32 * n * (col - 1);
-        const int32_t* skip = nullptr;
-        if (fb && col < 4) {                                   // table slots for h0 and the first three h_i
-            const int slot = c12381_ctx::WS_FB_G1_0 + (int)col;
-            if ((rc = fixed_table(c, slot, base, false))) return rc;
-            skip = (const int32_t*)c->ws[slot];
-            hipLaunchKernelGGL(g1_fixed_eval_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, skip, sc, (int32_t*)c->ws[c12381_ctx::WS_PROJ],
-                               stride, col * n);
-            HIPCK(c, hipGetLastError());
-        }
-        if ((rc = g1_mul_to_proj(c, n, base, sc, stride, 0, col * n, skip))) return rc;
-    }
-    const size_t rstride = round_up(n, 64);
-    if ((rc = ensure(c, c12381_ctx::WS_RED0, (size_t)3 * NL * rstride * 4))) return rc;
-    int32_t* red = (int32_t*)c->ws[c12381_ctx::WS_RED0];
-    hipLaunchKernelGGL(g1_reduce_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, total, (const int32_t*)c->ws[c12381_ctx::WS_PROJ], stride, n, red, rstride);
-    HIPCK(c, hipGetLastError());
-    hipLaunchKernelGGL(g1_add_const_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, red, rstride, g1_96, c->d_flag);
-    HIPCK(c, hipGetLastError());
+    int32_t* red; size_t rstride, stride;
+    if ((rc = bbs_message_points(c, n, nmsg, g1_96, h0_96, h_96, r_32, m_32, fb, red, rstride, stride))) return rc;
     if (fq) {
         // fixed-G2 path: red <- x A - B  (x A by the generic scalar multiplication: A differs per signature)
         if ((rc = g1_mul_to_proj(c, n, A_96, x_32, stride, 96, 0, gate_fast))) return rc;
@@ -1003,6 +1014,45 @@ int c12381_bbs_plus_verify_batch(c12381_ctx* c, size_t n, size_t nmsg, const uin
     if (nmsg) HIPCK(c, hipMemcpyAsync(d + o_m, m_32, 32 * n * nmsg, hipMemcpyHostToDevice, c->stream));
     if ((rc = c12381_bbs_plus_verify_batch_dev(c, n, nmsg, d + o_g1, d + o_g2, d + o_h0, d + o_h, d + o_w, d + o_A, d + o_x, d + o_r, d + o_m, d + o_ok))) return rc;
     HIPCK(c, hipMemcpyAsync(ok, d + o_ok, n, hipMemcpyDeviceToHost, c->stream));
+    return read_flag(c);
+}
+
+// BBS+ signing for a batch (bbs+.cpp:38-55): A_j = (g1 * h0^r_j * prod_i h_i^m_ij)^(1/(gamma + x_j)).  x_j, r_j are the
+// caller's random scalars (the reference draws them inside sign()); inverse(0) = 0 gives the point at infinity, as there.
+int c12381_bbs_plus_sign_batch_dev(c12381_ctx* c, size_t n, size_t nmsg, const uint8_t* g1_96, const uint8_t* h0_96, const uint8_t* h_96,
+                                   const uint8_t* gamma_32, const uint8_t* x_32, const uint8_t* r_32, const uint8_t* m_32, uint8_t* A_out96) {
+    int rc = bind(c); if (rc) return rc;
+    if (!g1_96 || !h0_96 || !gamma_32 || !x_32 || !r_32 || !A_out96 || (nmsg && (!h_96 || !m_32))) return C12381_E_ARG;
+    if (n == 0) return 0;
+    if ((rc = ensure(c, c12381_ctx::WS_BBS_B, 192 * n))) return rc;
+    if ((rc = ensure(c, c12381_ctx::WS_BBS_Q, 192 * n))) return rc;
+    uint8_t* d_b = (uint8_t*)c->ws[c12381_ctx::WS_BBS_B];         // B_j affine
+    uint8_t* d_e = (uint8_t*)c->ws[c12381_ctx::WS_BBS_Q];         // 1 / (gamma + x_j)
+    int32_t* red; size_t rstride, stride;
+    if ((rc = bbs_message_points(c, n, nmsg, g1_96, h0_96, h_96, r_32, m_32, fixed_base_enabled(), red, rstride, stride))) return rc;
+    if ((rc = g1_finish(c, n, red, rstride, d_b, 96))) return rc;
+    hipLaunchKernelGGL(zp_inv_sum_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, x_32, gamma_32, d_e);
+    HIPCK(c, hipGetLastError());
+    return c12381_g1_mul_batch_dev(c, n, d_b, d_e, A_out96, 96);
+}
+int c12381_bbs_plus_sign_batch(c12381_ctx* c, size_t n, size_t nmsg, const uint8_t* g1_96, const uint8_t* h0_96, const uint8_t* h_96,
+                               const uint8_t* gamma_32, const uint8_t* x_32, const uint8_t* r_32, const uint8_t* m_32, uint8_t* A_out96) {
+    int rc = bind(c); if (rc) return rc;
+    if (!g1_96 || !h0_96 || !gamma_32 || !x_32 || !r_32 || !A_out96 || (nmsg && (!h_96 || !m_32))) return C12381_E_ARG;
+    if (n == 0) return 0;
+    const size_t o_g1 = 0, o_h0 = 96, o_gm = 192, o_h = 256, o_x = round_up(o_h + 96 * nmsg, 256), o_r = o_x + 32 * n, o_m = o_r + 32 * n,
+                 o_A = round_up(o_m + 32 * n * nmsg, 256), bytes = o_A + 96 * n;
+    if ((rc = ensure(c, c12381_ctx::WS_BBS_IN, bytes))) return rc;
+    uint8_t* d = (uint8_t*)c->ws[c12381_ctx::WS_BBS_IN];
+    HIPCK(c, hipMemcpyAsync(d + o_g1, g1_96, 96, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d + o_h0, h0_96, 96, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d + o_gm, gamma_32, 32, hipMemcpyHostToDevice, c->stream));
+    if (nmsg) HIPCK(c, hipMemcpyAsync(d + o_h, h_96, 96 * nmsg, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d + o_x, x_32, 32 * n, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d + o_r, r_32, 32 * n, hipMemcpyHostToDevice, c->stream));
+    if (nmsg) HIPCK(c, hipMemcpyAsync(d + o_m, m_32, 32 * n * nmsg, hipMemcpyHostToDevice, c->stream));
+    if ((rc = c12381_bbs_plus_sign_batch_dev(c, n, nmsg, d + o_g1, d + o_h0, d + o_h, d + o_gm, d + o_x, d + o_r, d + o_m, d + o_A))) return rc;
+    HIPCK(c, hipMemcpyAsync(A_out96, d + o_A, 96 * n, hipMemcpyDeviceToHost, c->stream));
     return read_flag(c);
 }
 

@@ -82,6 +82,18 @@ __global__ void __launch_bounds__(BLOCK, 2) zp_op_kernel(int op, size_t n, const
     fr_store32(out + 32 * i, r);
 }
 
+// out[i] = 1 / (x[i] + gamma) mod r for ONE gamma (BBS+ sign: inverse(gamma + x), bbs+.cpp:53); inverse(0) = 0
+__global__ void __launch_bounds__(BLOCK, 2) zp_inv_sum_kernel(size_t n, const uint8_t* x, const uint8_t* gamma, uint8_t* out) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    fr a, g, s, r;
+    fr_load32(a, x + 32 * i);
+    fr_load32(g, gamma);
+    fr_add(s, a, g);
+    fr_inv(r, s);
+    fr_store32(out + 32 * i, r);
+}
+
 __global__ void __launch_bounds__(BLOCK, 2) zp_from_hash_kernel(size_t n, const uint8_t* digests, uint8_t* out) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;

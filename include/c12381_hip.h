@@ -197,6 +197,15 @@ int c12381_zp_from_hash_batch(c12381_ctx* ctx, size_t n, const uint8_t* digests6
 int c12381_zp_inner_product(c12381_ctx* ctx, size_t n, const uint8_t* a32, const uint8_t* b32, uint8_t out32[32]);
 int c12381_zp_inner_product_dev(c12381_ctx* ctx, size_t n, const uint8_t* a32, const uint8_t* b32, uint8_t* out32);
 
+/* BBS+ signing for a batch (examples/bbs-plus/src/bbs+.cpp:38-55): A[j] = (g1 * h0^r[j] * prod_i h_i^m[i*n + j])^(1/(gamma + x[j]))
+ * — `^` is multiply (:122), `inverse` is mod_inverse (:59; inverse(0) = 0, so A is then the point at infinity), Π the
+ * sum of the columns.  x and r are the caller's random scalars (the reference draws them inside sign()); gamma is the
+ * secret key (32 B).  Output 96-byte affine points, message-major m as in the verification entry. */
+int c12381_bbs_plus_sign_batch(c12381_ctx* ctx, size_t n, size_t nmsg, const uint8_t* g1_96, const uint8_t* h0_96, const uint8_t* h_96,
+                               const uint8_t* gamma_32, const uint8_t* x_32, const uint8_t* r_32, const uint8_t* m_32, uint8_t* A_out96);
+int c12381_bbs_plus_sign_batch_dev(c12381_ctx* ctx, size_t n, size_t nmsg, const uint8_t* g1_96, const uint8_t* h0_96, const uint8_t* h_96,
+                                   const uint8_t* gamma_32, const uint8_t* x_32, const uint8_t* r_32, const uint8_t* m_32, uint8_t* A_out96);
+
 #ifdef __cplusplus
 }
 #endif

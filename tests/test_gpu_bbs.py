@@ -115,3 +115,28 @@ def test_bbs_plus_fixed_base_fallbacks(oracle_port):
         b"".join(orc.g1_msm(G1p + h0 + h, (1).to_bytes(32, "big") + Rr[32 * j:32 * j + 32] + b"".join(Mm[32 * (n * i + j):32 * (n * i + j) + 32] for i in range(nmsg)), 96, 1)
                  for j in range(n)), G2p * n, 8)
     ctx.close()
+
+
+def test_bbs_plus_sign_batch(oracle_port):
+    """sign() for a batch (bbs+.cpp:38-55) against the oracle's evaluation, and the round trip through verify."""
+    from crypto12381_amd import Context
+    orc = oracle_port
+    nmsg, n = 2, 50
+    G1p, G2p, h0, h, gamma, w = _setup(orc, nmsg)
+    X = scalars(751, n)
+    X = ((R - gamma) % R).to_bytes(32, "big") + X[32:]          # lane 0: gamma + x = 0, inverse(0) = 0, A = infinity
+    Rr = scalars(752, n)
+    Mm = scalars(753, n) + scalars(754, n)
+    ctx = Context(0)
+    A = ctx.bbs_plus_sign(G1p, h0, h, gamma.to_bytes(32, "big"), X, Rr, Mm)
+    exp = b""
+    for j in range(n):
+        x = int.from_bytes(X[32 * j:32 * j + 32], "big")
+        e = pow((gamma + x) % R, R - 2, R)
+        B = orc.g1_msm(G1p + h0 + h, (1).to_bytes(32, "big") + Rr[32 * j:32 * j + 32] + Mm[32 * j:32 * j + 32] + Mm[32 * (n + j):32 * (n + j) + 32], 96, 1)
+        exp += orc.g1_mul(B, e.to_bytes(32, "big"), 96)
+    assert A == exp
+    assert A[:96] == bytes(96)
+    ok = ctx.bbs_plus_verify(G1p, G2p, h0, h, w, A, X, Rr, Mm)
+    assert ok[1:] == b"\x01" * (n - 1)
+    ctx.close()
