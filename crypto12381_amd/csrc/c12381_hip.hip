@@ -769,7 +769,8 @@ int c12381_miller_batch(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8_
     if (n == 0) return 0;
     staged s;
     if ((rc = stage_in(c, s, g1, 96 * n, g2, 192 * n, 576 * n))) return rc;
-    hipLaunchKernelGGL(miller_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, s.in0, s.in1, s.out, c->d_flag);
+    if (pair_lanes() == 1) hipLaunchKernelGGL(miller_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, s.in0, s.in1, s.out, c->d_flag);
+    else hipLaunchKernelGGL(miller3_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, s.in0, s.in1, s.out, c->d_flag);
     HIPCK(c, hipGetLastError());
     if ((rc = stage_out(c, s, out576, 576 * n))) return rc;
     return read_flag(c);
@@ -781,7 +782,8 @@ int c12381_gt_op_batch(c12381_ctx* c, int op, size_t n, const uint8_t* a576, con
     staged s;
     const size_t bb = op == 0 ? 576 * n : (op == 2 ? 32 * n : 0);
     if ((rc = stage_in(c, s, a576, 576 * n, bb ? b : nullptr, bb, 576 * n))) return rc;
-    hipLaunchKernelGGL(gt_op_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, op, n, s.in0, s.in1, s.out);
+    if (pair_lanes() == 1) hipLaunchKernelGGL(gt_op_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, op, n, s.in0, s.in1, s.out);
+    else hipLaunchKernelGGL(gt3_op_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, op, n, s.in0, s.in1, s.out);
     HIPCK(c, hipGetLastError());
     if ((rc = stage_out(c, s, out576, 576 * n))) return rc;
     HIPCK(c, hipStreamSynchronize(c->stream));
@@ -794,7 +796,8 @@ int c12381_gt_is_unity_batch(c12381_ctx* c, size_t n, const uint8_t* a576, uint8
     if (n == 0) return 0;
     staged s;
     if ((rc = stage_in(c, s, a576, 576 * n, nullptr, 0, n))) return rc;
-    hipLaunchKernelGGL(gt_is_unity_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, s.in0, s.out);
+    if (pair_lanes() == 1) hipLaunchKernelGGL(gt_is_unity_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, s.in0, s.out);
+    else hipLaunchKernelGGL(gt3_is_unity_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, s.in0, s.out);
     HIPCK(c, hipGetLastError());
     if ((rc = stage_out(c, s, out, n))) return rc;
     HIPCK(c, hipStreamSynchronize(c->stream));

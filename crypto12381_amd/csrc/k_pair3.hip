@@ -34,6 +34,15 @@ __device__ __forceinline__ void gt_store_coeff(uint8_t* o576, const fp4& x, int 
 // operand at LDS latency.  60 KB per workgroup, two workgroups per CU.
 struct alignas(16) fp4_slot { fp4 v; int32_t pad[4]; };
 
+__device__ __forceinline__ void gt_load_coeff(fp4& x, const uint8_t* p576, int role) {
+    const uint8_t* p = p576 + (role == 0 ? 384 : (role == 1 ? 192 : 0));
+    uint32_t raw[12];
+    load_raw48(raw, p); fp_from_raw48(x.b.b, raw);
+    load_raw48(raw, p + 48); fp_from_raw48(x.b.a, raw);
+    load_raw48(raw, p + 96); fp_from_raw48(x.a.b, raw);
+    load_raw48(raw, p + 144); fp_from_raw48(x.a.a, raw);
+}
+
 // ---- work-queue variant: state of a group of 21 pairings between two phases, as rows of 64 x 16 bytes (one per lane)
 constexpr int ST_ROWS_F = 14, ST_ROWS_TC = 7;                 // Fp4 = 56 dwords, Fp2 = 28 dwords
 constexpr int ST_F = 0, ST_TC1 = ST_ROWS_F, ST_TC2 = ST_TC1 + ST_ROWS_TC, ST_Y1 = ST_TC2 + ST_ROWS_TC;
@@ -356,6 +365,48 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_fixed_queue_kernel(size_t n, c
                                                                   uint4* state, unsigned int* flags, unsigned int* counter) {
     __shared__ fp4_slot slots[BLOCK];
     pair3_fixed_queue_body<false>(n, g1_96, nullptr, buf + HDR_DWORDS, nullptr, gt, bad_flag, state, flags, counter, buf[HDR_VALID] != 0, slots[threadIdx.x].v);
+}
+
+// ------------------------------------------------------------------ split pairing and GT arithmetic on triples
+// pair_ate alone: the Miller value (not canonical as a pairing value, but the same field element as the reference's)
+__global__ void __launch_bounds__(BLOCK, 2) miller3_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* out, int* bad_flag) {
+    if ((((size_t)blockIdx.x * BLOCK + threadIdx.x) >> 6) * TRI_PER_WAVE >= n) return;
+    tri t; size_t i; bool active;
+    tri_setup(t, i, active, n);
+    fp px, py; fp2 qx, qy; bool pinf, qinf, ok;
+    pair_inputs(px, py, pinf, qx, qy, qinf, ok, g1 + 96 * i, g2 + 192 * i);
+    if (!ok) { if (active) *bad_flag = 1; pinf = true; qinf = true; }
+    __shared__ fp4_slot slots[BLOCK];
+    fp4& H = slots[threadIdx.x].v;
+    miller3_loop(H, px, py, pinf, qx, qy, qinf, t);
+    if (active) {
+        if (!ok) { uint4* q = reinterpret_cast<uint4*>(out + 576 * i + (t.role == 0 ? 384 : (t.role == 1 ? 192 : 0))); for (int j = 0; j < 12; ++j) q[j] = make_uint4(~0u, ~0u, ~0u, ~0u); }
+        else { fp4 F = H; gt_store_coeff(out + 576 * i, F, t.role); }
+    }
+}
+// op 0: a*b (FP12_mul), 1: conj(a), 2: a^e (FP12_pow, e = 32-byte exponent used as given), 3: final exponentiation
+__global__ void __launch_bounds__(BLOCK, 2) gt3_op_kernel(int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    if ((((size_t)blockIdx.x * BLOCK + threadIdx.x) >> 6) * TRI_PER_WAVE >= n) return;
+    tri t; size_t i; bool active;
+    tri_setup(t, i, active, n);
+    __shared__ fp4_slot slots[BLOCK];
+    fp4& H = slots[threadIdx.x].v;
+    fp4 x, r;
+    gt_load_coeff(x, a + 576 * i, t.role);
+    if (op == 0) { fp4 y; gt_load_coeff(y, b + 576 * i, t.role); f12t_mul(r, x, y, t); }
+    else if (op == 1) { f12t_conj(r, x, t); }
+    else if (op == 2) { uint32_t raw[8], e[8]; load_raw32(raw, b + 32 * i); scalar_from_raw32(e, raw); f12t_pow_generic(r, x, e, t); }
+    else { r = x; f12t_final_exp_ws(r, H, t); }
+    if (active) gt_store_coeff(out + 576 * i, r, t.role);
+}
+__global__ void __launch_bounds__(BLOCK, 2) gt3_is_unity_kernel(size_t n, const uint8_t* a, uint8_t* out) {
+    if ((((size_t)blockIdx.x * BLOCK + threadIdx.x) >> 6) * TRI_PER_WAVE >= n) return;
+    tri t; size_t i; bool active;
+    tri_setup(t, i, active, n);
+    fp4 x;
+    gt_load_coeff(x, a + 576 * i, t.role);
+    const bool one = f12t_is_one(x, t);
+    if (active && t.role == 0) out[i] = one ? 1 : 0;
 }
 
 }  // namespace c12381

@@ -246,6 +246,40 @@ C12381_HD void f12t_final_exp(fp4& r, const tri& t) {
     fp4 h;
     f12t_final_exp_ws(r, h, t);
 }
+C12381_HD void f12t_one(fp4& F, const tri& t);
+// FP12_pow :736-774 on a triple, exponent e < 2^256 used AS GIVEN (the three lanes of a triple hold the same e): the
+// reference's signed-digit ladder over (3e, e) with Granger-Scott squarings — a power only for unitary inputs, like
+// there.  Triples hold different exponents, so both candidates are always formed and selected (fp12_pow_generic).
+C12381_HDN void f12t_pow_generic(fp4& r, const fp4& a, const uint32_t (&e)[8], const tri& t) {
+    uint32_t e3[9];
+    {
+        uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { c += (uint64_t)e[i] * 3u; e3[i] = (uint32_t)c; c >>= 32; }
+        e3[8] = (uint32_t)c;
+    }
+    int nb = 0;
+#pragma unroll 1
+    for (int i = 0; i < 9 * 32; ++i) if ((e3[i >> 5] >> (i & 31)) & 1u) nb = i + 1;
+    fp4 w = a, ac;
+    f12t_conj(ac, a, t);
+#pragma unroll 1
+    for (int i = 257; i >= 1; --i) {
+        const bool active = i <= nb - 2;
+        fp4 sq, m, prod, nxt;
+        f12t_usqr(sq, w, true, t);
+        const int b3 = (int)((e3[i >> 5] >> (i & 31)) & 1u);
+        const int b1 = i < 256 ? (int)((e[i >> 5] >> (i & 31)) & 1u) : 0;
+        const int bt = b3 - b1;
+        fp4_select(m, bt < 0, ac, a);
+        f12t_mul(prod, sq, m, t);
+        fp4_select(nxt, bt != 0, prod, sq);
+        fp4_select(w, active, nxt, w);
+    }
+    fp4 one;
+    f12t_one(one, t);
+    fp4_select(r, nb == 0, one, w);
+}
 // FP12_isunity: every lane tests its own coefficient, the verdict is combined over the triple
 C12381_HD bool f12t_is_one(const fp4& x, const tri& t) {
     fp d, one;

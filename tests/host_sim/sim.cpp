@@ -278,15 +278,37 @@ void gt_store_coeff(uint8_t* o576, const fp4& x, int role) {
     const fp* order[4] = {&x.b.b, &x.b.a, &x.a.b, &x.a.a};
     for (int j = 0; j < 4; ++j) { uint32_t raw[12]; fp_to_raw48(raw, *order[j]); std::memcpy(o + 48 * j, raw, 48); }
 }
+void gt_load_coeff(fp4& x, const uint8_t* p576, int role) {
+    const uint8_t* p = p576 + (role == 0 ? 384 : (role == 1 ? 192 : 0));
+    fp* order[4] = {&x.b.b, &x.b.a, &x.a.b, &x.a.a};
+    for (int j = 0; j < 4; ++j) { uint32_t raw[12]; load_raw(raw, p + 48 * j, 12); fp_from_raw48(*order[j], raw); }
+}
 void* tri3_worker(void* arg) {
     Tri3Job* jb = (Tri3Job*)arg;
     tl_box = jb->box;
     tri t{jb->role, 0};
+    if (jb->mode >= 10) {                 // GT operators on triples: a1 = 576-byte elements, b1 = second operand
+        const int op = jb->mode - 10;
+        for (size_t i = 0; i < jb->n; ++i) {
+            fp4 x, r, h;
+            gt_load_coeff(x, jb->a1 + 576 * i, jb->role);
+            if (op == 0) { fp4 y; gt_load_coeff(y, jb->b1 + 576 * i, jb->role); f12t_mul(r, x, y, t); }
+            else if (op == 1) f12t_conj(r, x, t);
+            else if (op == 2) { uint32_t raw[8], e[8]; load_raw(raw, jb->b1 + 32 * i, 8); scalar_from_raw32(e, raw); f12t_pow_generic(r, x, e, t); }
+            else if (op == 3) { r = x; f12t_final_exp_ws(r, h, t); }
+            else { const bool one = f12t_is_one(x, t); if (jb->role == 0) jb->out[i] = one ? 1 : 0; continue; }
+            gt_store_coeff(jb->out + 576 * i, r, jb->role);
+        }
+        return nullptr;
+    }
     for (size_t i = 0; i < jb->n; ++i) {
         fp px, py; fp2 qx, qy; bool pinf, qinf;
         fp4 F;
         pair_load(px, py, pinf, qx, qy, qinf, jb->a1 + 96 * i, jb->a2 + 192 * i);
-        if (jb->mode == 2) {          // product of two pairings whose G2 arguments are fixed: lines from the tables
+        if (jb->mode == 3) {          // Miller value alone
+            miller3_loop(F, px, py, pinf, qx, qy, qinf, t);
+            gt_store_coeff(jb->out + 576 * i, F, jb->role);
+        } else if (jb->mode == 2) {          // product of two pairings whose G2 arguments are fixed: lines from the tables
             fp px2, py2; fp2 qx2, qy2; bool pinf2, qinf2;
             pair_load(px2, py2, pinf2, qx2, qy2, qinf2, jb->b1 + 96 * i, jb->b2);
             f12t_one(F, t);
@@ -576,3 +598,7 @@ extern "C" int sim_pair2_fixed_batch(size_t n, const uint8_t* a96, const uint8_t
     for (size_t i = 0; i < n; ++i) std::memcpy(&wrep[192 * i], w192, 192);
     return run_tri3(n, a96, wrep.data(), c96, g192, gt576, 2, t1, t2);
 }
+
+extern "C" int sim_miller3_batch(size_t n, const uint8_t* g1_96, const uint8_t* g2_192, uint8_t* out576) { return run_tri3(n, g1_96, g2_192, nullptr, nullptr, out576, 3); }
+// op: 0 mul, 1 conj, 2 pow, 3 final exponentiation, 4 is-unity (out = n bytes)
+extern "C" int sim_gt3_op_batch(int op, size_t n, const uint8_t* a576, const uint8_t* b, uint8_t* out) { return run_tri3(n, a576, nullptr, b, nullptr, out, 10 + op); }

@@ -282,3 +282,25 @@ def test_sim_fixed_g2_lines(sim, oracle_port):
     out = ctypes.create_string_buffer(576 * n)
     assert sim.sim_pair2_fixed_batch(sz(n), a, w, c, q, out) == 0
     assert out.raw == oracle_port.pair2(a, w * n, c, q * n)
+
+
+def test_sim_three_lane_miller_and_gt_ops(sim, oracle_port):
+    """miller3_kernel / gt3_op_kernel bodies: the Miller VALUE (not only the pairing) and the GT operators on triples"""
+    g = golden("pairing")
+    g1, g2 = cat(g["g1"]), cat(g["g2"])
+    n = len(g1) // 96
+    out = ctypes.create_string_buffer(576 * n)
+    assert sim.sim_miller3_batch(sz(n), g1, g2, out) == 0
+    mil = oracle_port.miller(g1, g2)
+    assert out.raw == mil
+    gt = cat(g["gt"])
+    a, b = gt[:576 * 4], gt[576 * 4:]
+    o4 = ctypes.create_string_buffer(576 * 4)
+    assert sim.sim_gt3_op_batch(0, sz(4), a, b, o4) == 0 and o4.raw == cat(g["gt_mul"])
+    assert sim.sim_gt3_op_batch(1, sz(4), a, None, o4) == 0 and o4.raw == cat(g["gt_conj"])
+    assert sim.sim_gt3_op_batch(2, sz(4), a, cat(g["gt_pow_exp"]), o4) == 0 and o4.raw == cat(g["gt_pow"])
+    o3 = ctypes.create_string_buffer(576 * 3)
+    assert sim.sim_gt3_op_batch(3, sz(3), mil[:576 * 3], None, o3) == 0 and o3.raw == gt[:576 * 3]
+    one = oracle_port.gt_op("mul", a[:576], oracle_port.gt_op("conj", a[:576]))
+    u = ctypes.create_string_buffer(2)
+    assert sim.sim_gt3_op_batch(4, sz(2), one + a[:576], None, u) == 0 and u.raw == b"\x01\x00"
