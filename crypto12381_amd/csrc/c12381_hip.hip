@@ -43,7 +43,7 @@ struct c12381_ctx {
     std::vector<hipEvent_t> ev_chunk;     // one per chunk of a scalar-mul batch (main -> side dependencies)
     char err[256] = {0};
     enum { WS_TAB, WS_PROJ, WS_PREF, WS_IN0, WS_IN1, WS_OUT, WS_RED0, WS_RED1, WS_BBS_Q, WS_BBS_B, WS_BBS_IN,
-           WS_PAIR_ST, WS_FQ_W, WS_FQ_G, WS_FQ_GATE, WS_FQ_P, WS_FB_G2, WS_FB_G1_0, WS_FB_G1_1, WS_FB_G1_2, WS_FB_G1_3, WS_MSM_PTS, WS_MSM_K0, WS_MSM_K1, WS_MSM_V0, WS_MSM_V1, WS_MSM_TMP, WS_MSM_RNG, WS_MSM_BK, WS_COUNT };
+           WS_PAIR_ST, WS_FQ_W, WS_FQ_G, WS_FQ_GATE, WS_FQ_P, WS_FB_G2, WS_FB_G1_0, WS_FB_G1_1, WS_FB_G1_2, WS_FB_G1_3, WS_MSM_PTS, WS_MSM_K0, WS_MSM_K1, WS_MSM_V0, WS_MSM_V1, WS_MSM_TMP, WS_MSM_RNG, WS_MSM_BK, WS_MSM_ORD, WS_COUNT };
     void* ws[WS_COUNT] = {nullptr};
     size_t ws_bytes[WS_COUNT] = {0};
     int* d_flag = nullptr;
@@ -191,9 +191,26 @@ int g1_msm_pippenger(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t*
     HIPCK(c, hipMemsetAsync(lo, 0, (nbk + 1) * 8, c->stream));
     hipLaunchKernelGGL(msm_ranges_kernel, dim3(grid_for(E)), dim3(BLOCK), 0, c->stream, E, k1, lo, hi);
     HIPCK(c, hipGetLastError());
+    // buckets in order of decreasing run length (k0 / v0 are free again after the first sort; the sorted size keys go
+    // to k1, which the ranges kernel has finished with)
+    const size_t key_cap = E > nbk ? E : nbk;
+    if (key_cap > E) {
+        if ((rc = ensure(c, c12381_ctx::WS_MSM_K0, key_cap * 4))) return rc;
+        if ((rc = ensure(c, c12381_ctx::WS_MSM_K1, key_cap * 4))) return rc;
+        if ((rc = ensure(c, c12381_ctx::WS_MSM_V0, key_cap * 4))) return rc;
+        k0 = (uint32_t*)c->ws[c12381_ctx::WS_MSM_K0]; k1 = (uint32_t*)c->ws[c12381_ctx::WS_MSM_K1]; v0 = (uint32_t*)c->ws[c12381_ctx::WS_MSM_V0];
+    }
+    if ((rc = ensure(c, c12381_ctx::WS_MSM_ORD, nbk * 4))) return rc;
+    uint32_t* order = (uint32_t*)c->ws[c12381_ctx::WS_MSM_ORD];
+    hipLaunchKernelGGL(msm_sizes_kernel, dim3(grid_for(nbk)), dim3(BLOCK), 0, c->stream, nbk, lo, hi, k0, v0);
+    HIPCK(c, hipGetLastError());
+    size_t tmp2 = 0;
+    HIPCK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, k0, k1, v0, order, (int)nbk, 0, 32, c->stream));
+    if ((rc = ensure(c, c12381_ctx::WS_MSM_TMP, tmp2 + 256))) return rc;
+    HIPCK(c, hipcub::DeviceRadixSort::SortPairs(c->ws[c12381_ctx::WS_MSM_TMP], tmp2, k0, k1, v0, order, (int)nbk, 0, 32, c->stream));
     {
         timed tm(c, 5);
-        hipLaunchKernelGGL(msm_bucket_kernel, dim3(grid_for(nbk)), dim3(BLOCK), 0, c->stream, nbk, lo, hi, v1, pts2, bk);
+        hipLaunchKernelGGL(msm_bucket_kernel, dim3(grid_for(nbk)), dim3(BLOCK), 0, c->stream, nbk, lo, hi, v1, pts2, bk, order);
         HIPCK(c, hipGetLastError());
     }
     const uint32_t chunks = (uint32_t)((nb + MSM_CHUNK - 1) / MSM_CHUNK);

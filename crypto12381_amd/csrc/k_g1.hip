@@ -254,10 +254,19 @@ __global__ void __launch_bounds__(BLOCK, 2) msm_ranges_kernel(size_t E, const ui
     if (j + 1 == E || keys[j + 1] != k) hi[k] = (uint32_t)(j + 1);
 }
 
-__global__ void __launch_bounds__(BLOCK, 2) msm_bucket_kernel(size_t nbk, const uint32_t* lo, const uint32_t* hi, const uint32_t* vals,
-                                                           const int32_t* pts2, int32_t* bk) {
+// sort key for "longest run first": buckets are handed to lanes in order of decreasing size, so the 64 lanes of a
+// wavefront sum runs of (almost) the same length instead of waiting for the longest of 64 random ones
+__global__ void __launch_bounds__(BLOCK, 2) msm_sizes_kernel(size_t nbk, const uint32_t* lo, const uint32_t* hi, uint32_t* key, uint32_t* ident) {
     const size_t b = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (b >= nbk) return;
+    key[b] = 0xffffffffu - (hi[b] - lo[b]);
+    ident[b] = (uint32_t)b;
+}
+__global__ void __launch_bounds__(BLOCK, 2) msm_bucket_kernel(size_t nbk, const uint32_t* lo, const uint32_t* hi, const uint32_t* vals,
+                                                           const int32_t* pts2, int32_t* bk, const uint32_t* order) {
+    const size_t slot = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (slot >= nbk) return;
+    const size_t b = order[slot];
     g1p acc, nn;
     msm_bucket_one(acc, lo[b], hi[b], vals, pts2);
     g1_norm1(nn, acc);
