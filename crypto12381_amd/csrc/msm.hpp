@@ -17,7 +17,7 @@
 namespace c12381 {
 
 constexpr int MSM_PT_DWORDS = 2 * NL;          // affine (x, y) in Montgomery form, normalised limbs: 112 B, seven 16-byte words
-constexpr int MSM_CHUNK = 64;                  // buckets per lane in the window reduction
+constexpr int MSM_CHUNK = 16;                  // buckets per lane in the window reduction
 
 C12381_HD int msm_window_bits(size_t n) {      // c ~ log2(2n) - 7, clamped
     int lg = 0;
