@@ -68,6 +68,8 @@ def load_library() -> ctypes.CDLL:
             getattr(lib, name).argtypes = [vp, sz, vp, vp, vp]
         for name in ("c12381_bbs_plus_sign_batch", "c12381_bbs_plus_sign_batch_dev"):
             getattr(lib, name).argtypes = [vp, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp]
+        for name in ("c12381_g1_decompress_batch_dev", "c12381_g2_decompress_batch_dev"):
+            getattr(lib, name).argtypes = [vp, sz, vp, vp, vp]
         lib.c12381_g1_msm_multi.argtypes = [ctypes.POINTER(vp), ci, sz, vp, vp, vp, ci]
         lib.c12381_g1_map_to_point_batch.argtypes = [vp, sz, vp, vp]
         lib.c12381_g1_clear_cofactor_batch.argtypes = [vp, sz, vp, vp]

@@ -641,6 +641,22 @@ int c12381_pair_eq_batch(c12381_ctx* c, size_t n, const uint8_t* a1, const uint8
 }
 
 // ---------------------------------------------------------------- decode / split pairing / GT
+int c12381_g1_decompress_batch_dev(c12381_ctx* c, size_t n, const uint8_t* in49, uint8_t* out96, uint8_t* status) {
+    int rc = bind(c); if (rc) return rc;
+    if (!in49 || !out96 || !status) return C12381_E_ARG;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(g1_decompress_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, in49, out96, status);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+int c12381_g2_decompress_batch_dev(c12381_ctx* c, size_t n, const uint8_t* in97, uint8_t* out192, uint8_t* status) {
+    int rc = bind(c); if (rc) return rc;
+    if (!in97 || !out192 || !status) return C12381_E_ARG;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(g2_decompress_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, in97, out192, status);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
 int c12381_g1_decompress_batch(c12381_ctx* c, size_t n, const uint8_t* in49, uint8_t* out96, uint8_t* status) {
     int rc = bind(c); if (rc) return rc;
     if (!in49 || !out96 || !status) return C12381_E_ARG;

@@ -122,6 +122,10 @@ int c12381_g1_decompress_batch(c12381_ctx* ctx, size_t n, const uint8_t* in49, u
 /* Batched from_bytes(point2&, bytes_view&) for 97-byte input (:146, :187-190 -> ECP2_fromOctet -> ECP2_setx);
  * any tag other than 0x04 and 0x00 is treated as compressed with sign = tag & 1, as the reference does. */
 int c12381_g2_decompress_batch(c12381_ctx* ctx, size_t n, const uint8_t* in97, uint8_t* out192, uint8_t* status);
+/* device-pointer forms (wire bytes already on the device; the 49- / 97-byte records are read bytewise, no alignment
+ * requirement on them; out and status as above) */
+int c12381_g1_decompress_batch_dev(c12381_ctx* ctx, size_t n, const uint8_t* in49, uint8_t* out96, uint8_t* status);
+int c12381_g2_decompress_batch_dev(c12381_ctx* ctx, size_t n, const uint8_t* in97, uint8_t* out192, uint8_t* status);
 
 /* split pairing and GT arithmetic (what the reference's GTMiller / GTPoint types call) ----------- */
 /* pair_ate(fp12&, point2&, point1&) alone (:199 -> 276-279 -> PAIR_ate): the Miller value as FP12_toOctet bytes. */

@@ -115,3 +115,19 @@ def test_contexts_are_independent(ctx):
     assert a == cat(g["mul49"]) and b == cat(g["mul96"])
     other.close()
     assert ctx.g1_mul(pts, sc, 49) == a                                            # closing one does not disturb the other
+
+
+def test_device_pointer_decompress(ctx):
+    import torch
+    dev = torch.device("cuda", 0)
+    for name, rec_in, rec_out, fn in (("g1", 49, 96, ctx.lib.c12381_g1_decompress_batch_dev), ("g2", 97, 192, ctx.lib.c12381_g2_decompress_batch_dev)):
+        g = golden(name)
+        comp = cat(g["compressed"])
+        n = len(comp) // rec_in
+        d_in = torch.frombuffer(bytearray(comp), dtype=torch.uint8).to(dev)
+        d_out = torch.empty(rec_out * n, dtype=torch.uint8, device=dev)
+        d_st = torch.empty(n, dtype=torch.uint8, device=dev)
+        assert fn(ctx.h, n, ctypes.c_void_p(d_in.data_ptr()), ctypes.c_void_p(d_out.data_ptr()), ctypes.c_void_p(d_st.data_ptr())) == 0
+        assert ctx.sync() == 0
+        assert list(bytes(d_st.cpu().numpy())) == g["decompress_status"]
+        assert bytes(d_out.cpu().numpy()) == cat(g["decompressed"])
