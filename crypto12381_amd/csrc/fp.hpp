@@ -28,6 +28,18 @@
 #define C12381_CONST constexpr
 #endif
 
+// A normalised limb (x & LMASK) is known to be non-negative, and LLVM then canonicalises its sign extension to a ZERO
+// extension; once such a value crosses a basic-block boundary (every accumulator of a loop does) instruction
+// selection no longer sees that bit 31 is clear, cannot use v_mad_i64_i32 for sext(a) * zext(b) and emits TWO
+// v_mad_u64_u32 plus two moves per product.  Hiding the mask result behind an empty asm keeps both operands of
+// every product plain signed 32-bit values: one v_mad_i64_i32 each.  (No instruction is emitted for the asm.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define C12381_LIMB(x) c12381::limb_opaque(x)
+namespace c12381 { __device__ __forceinline__ int32_t limb_opaque(int32_t v) { asm("" : "+v"(v)); return v; } }
+#else
+#define C12381_LIMB(x) (x)
+#endif
+
 #include "consts.hpp"
 
 #ifdef C12381_CHECK_BOUNDS
@@ -113,8 +125,8 @@ C12381_HD void fp_norm1(fp& r, const fp& a) {
     for (int i = 0; i < NL - 1; ++i) c[i] = a.l[i] >> LB;
     int32_t t13 = a.l[NL - 1] + c[NL - 2];
 #pragma unroll
-    for (int i = NL - 2; i >= 1; --i) r.l[i] = (int32_t)((uint32_t)a.l[i] & LMASK) + c[i - 1];
-    r.l[0] = (int32_t)((uint32_t)a.l[0] & LMASK);
+    for (int i = NL - 2; i >= 1; --i) r.l[i] = C12381_LIMB((int32_t)((uint32_t)a.l[i] & LMASK)) + c[i - 1];
+    r.l[0] = C12381_LIMB((int32_t)((uint32_t)a.l[0] & LMASK));
     r.l[NL - 1] = t13;
     C12381_BOUNDS({ double top = a.vb * TOP_PER_P + 4.0 + std::floor(a.lb / 268435456.0);
                     double lb = 268435456.0 + std::floor(a.lb / 268435456.0) + 1.0;
@@ -128,7 +140,7 @@ C12381_HD void fp_mul_small(fp& r, const fp& a, int32_t k) {
 #pragma unroll
     for (int i = 0; i < NL - 1; ++i) {
         t += (int64_t)a.l[i] * k;
-        r.l[i] = (int32_t)((uint32_t)t & LMASK);
+        r.l[i] = C12381_LIMB((int32_t)((uint32_t)t & LMASK));
         t >>= LB;
     }
     t += (int64_t)a.l[NL - 1] * k;
@@ -150,7 +162,7 @@ C12381_HD void fp_weak_reduce(fp& r, const fp& a) {
 #pragma unroll
     for (int i = 0; i < NL - 1; ++i) {
         t += (int64_t)n.l[i] - (int64_t)q * FP_P[i];
-        r.l[i] = (int32_t)((uint32_t)t & LMASK);
+        r.l[i] = C12381_LIMB((int32_t)((uint32_t)t & LMASK));
         t >>= LB;
     }
     t += (int64_t)n.l[NL - 1] - (int64_t)q * FP_P[NL - 1];
@@ -192,7 +204,7 @@ C12381_HD void fp_mul(fp& r, const fp& a, const fp& b) {
         for (int i = k - NL + 1; i < NL; ++i) acc += (int64_t)a.l[i] * b.l[k - i];
 #pragma unroll
         for (int i = k - NL + 1; i < NL; ++i) acc += (int64_t)m[i] * FP_P[k - i];
-        out[k - NL] = (int32_t)((uint32_t)acc & LMASK);
+        out[k - NL] = C12381_LIMB((int32_t)((uint32_t)acc & LMASK));
         acc >>= LB;
     }
     out[NL - 1] = (int32_t)acc;
@@ -231,7 +243,7 @@ C12381_HD void fp_sqr(fp& r, const fp& a) {
         if ((k & 1) == 0) acc += (int64_t)a.l[k / 2] * a.l[k / 2];
 #pragma unroll
         for (int i = k - NL + 1; i < NL; ++i) acc += (int64_t)m[i] * FP_P[k - i];
-        out[k - NL] = (int32_t)((uint32_t)acc & LMASK);
+        out[k - NL] = C12381_LIMB((int32_t)((uint32_t)acc & LMASK));
         acc >>= LB;
     }
     out[NL - 1] = (int32_t)acc;
@@ -287,7 +299,7 @@ C12381_HD void fp_reduce_cols(fp& r, ColFn col) {
         acc += col(k);
 #pragma unroll
         for (int i = k - NL + 1; i < NL; ++i) acc += (int64_t)m[i] * FP_P[k - i];
-        out[k - NL] = (int32_t)((uint32_t)acc & LMASK);
+        out[k - NL] = C12381_LIMB((int32_t)((uint32_t)acc & LMASK));
         acc >>= LB;
     }
     out[NL - 1] = (int32_t)acc;
@@ -365,7 +377,7 @@ C12381_HD void fp_from_words_be(fp& r, const uint32_t (&w)[12]) {
         const int wi = bit / 32, sh = bit % 32;            // word index from the least significant end
         uint64_t lo = w[11 - wi];
         if (wi + 1 < 12) lo |= (uint64_t)w[11 - (wi + 1)] << 32;
-        t.l[i] = (int32_t)((uint32_t)(lo >> sh) & LMASK);
+        t.l[i] = C12381_LIMB((int32_t)((uint32_t)(lo >> sh) & LMASK));
     }
     C12381_BOUNDS(t.lb = 268435456.0; t.vb = 10.0;)       // < 2^384 < 10 p
     fp r2;
