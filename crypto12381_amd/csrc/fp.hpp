@@ -220,13 +220,14 @@ C12381_HD void fp_sqr(fp& r, const fp& a) {
     C12381_BOUNDS(check_mul_operands(a, a, "fp_sqr");)
     int32_t m[NL];
     int32_t out[NL];
+    int32_t a2[NL];                      // 2a: the cross terms accumulate straight into the column (limbs <= 2^30)
+#pragma unroll
+    for (int i = 0; i < NL; ++i) a2[i] = 2 * a.l[i];
     int64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
-        int64_t x = 0;
 #pragma unroll
-        for (int i = 0; 2 * i < k; ++i) x += (int64_t)a.l[i] * a.l[k - i];
-        acc += 2 * x;
+        for (int i = 0; 2 * i < k; ++i) acc += (int64_t)a2[i] * a.l[k - i];
         if ((k & 1) == 0) acc += (int64_t)a.l[k / 2] * a.l[k / 2];
 #pragma unroll
         for (int i = 0; i < k; ++i) acc += (int64_t)m[i] * FP_P[k - i];
@@ -236,10 +237,8 @@ C12381_HD void fp_sqr(fp& r, const fp& a) {
     }
 #pragma unroll
     for (int k = NL; k < 2 * NL - 1; ++k) {
-        int64_t x = 0;
 #pragma unroll
-        for (int i = k - NL + 1; 2 * i < k; ++i) x += (int64_t)a.l[i] * a.l[k - i];
-        acc += 2 * x;
+        for (int i = k - NL + 1; 2 * i < k; ++i) acc += (int64_t)a2[i] * a.l[k - i];
         if ((k & 1) == 0) acc += (int64_t)a.l[k / 2] * a.l[k / 2];
 #pragma unroll
         for (int i = k - NL + 1; i < NL; ++i) acc += (int64_t)m[i] * FP_P[k - i];
@@ -257,28 +256,42 @@ C12381_HD void fp_sqr(fp& r, const fp& a) {
 // ------------------------------------------------------------------ lazy reduction: sums of products
 // One Montgomery reduction for a whole bilinear form  r = (sum_t +-A_t*B_t) / R mod p
 // (the reference's FP2_mul does the same trick with double-length BIGs, fp2_BLS12381.cpp:266-302).
-// `col(k)` returns the k-th column  sum_{i+j=k} (...)  of the un-reduced form, k = 0..26; the
-// engine interleaves the reduction exactly like fp_mul.  Column sums must stay below 2^63:
+// `col(k, acc)` ADDS the k-th column  sum_{i+j=k} (...)  of the un-reduced form to the running accumulator, k = 0..26
+// (straight into it: a column that is summed on the side and then added costs a 64-bit add per column and form);
+// the engine interleaves the reduction exactly like fp_mul.  Column sums must stay below 2^63:
 // with |limbs| <= LBa, LBb that is  14 * T * LBa * LBb + 14 * 2^56 + 2^40 < 2^63  for T products.
-C12381_HD int64_t fp_col(const fp& a, const fp& b, int k) {
-    int64_t x = 0;
+// Differences are formed by negating one operand's limbs once (fp_raw_neg), squares use a pre-doubled copy.
+C12381_HD void fp_col_acc(int64_t& acc, const fp& a, const fp& b, int k) {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
         const int j = k - i;
-        if (j >= 0 && j < NL) x += (int64_t)a.l[i] * b.l[j];
+        if (j >= 0 && j < NL) acc += (int64_t)a.l[i] * b.l[j];
     }
-    return x;
 }
-C12381_HD int64_t fp_col_sqr(const fp& a, int k) {
-    int64_t x = 0;
+// acc += column k of s * a^2 given a2 = 2 s a and ad = s a  (s = +1 or -1): cross terms once, diagonal term
+C12381_HD void fp_col_sqr_acc(int64_t& acc, const fp& a, const fp& a2, const fp& ad, int k) {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
         const int j = k - i;
-        if (j > i && j < NL) x += (int64_t)a.l[i] * a.l[j];
+        if (j > i && j < NL) acc += (int64_t)a2.l[i] * a.l[j];
     }
-    x *= 2;
-    if ((k & 1) == 0 && k / 2 < NL) x += (int64_t)a.l[k / 2] * a.l[k / 2];
-    return x;
+    if ((k & 1) == 0 && k / 2 < NL) acc += (int64_t)ad.l[k / 2] * a.l[k / 2];
+}
+// limb-wise -a, 2a, -2a: operands of the column scans only (never normalised, never stored)
+C12381_HD void fp_raw_neg(fp& r, const fp& a) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = -a.l[i];
+    C12381_BOUNDS(r.lb = a.lb; r.vb = a.vb;)
+}
+C12381_HD void fp_raw_dbl(fp& r, const fp& a) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = 2 * a.l[i];
+    C12381_BOUNDS(r.lb = 2 * a.lb; r.vb = 2 * a.vb;)
+}
+C12381_HD void fp_raw_neg_dbl(fp& r, const fp& a) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = -2 * a.l[i];
+    C12381_BOUNDS(r.lb = 2 * a.lb; r.vb = 2 * a.vb;)
 }
 template <class ColFn>
 C12381_HD void fp_reduce_cols(fp& r, ColFn col) {
@@ -287,7 +300,7 @@ C12381_HD void fp_reduce_cols(fp& r, ColFn col) {
     int64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
-        acc += col(k);
+        col(k, acc);
 #pragma unroll
         for (int i = 0; i < k; ++i) acc += (int64_t)m[i] * FP_P[k - i];
         m[k] = (int32_t)(((uint32_t)acc * FP_N0) & LMASK);
@@ -296,7 +309,7 @@ C12381_HD void fp_reduce_cols(fp& r, ColFn col) {
     }
 #pragma unroll
     for (int k = NL; k < 2 * NL - 1; ++k) {
-        acc += col(k);
+        col(k, acc);
 #pragma unroll
         for (int i = k - NL + 1; i < NL; ++i) acc += (int64_t)m[i] * FP_P[k - i];
         out[k - NL] = C12381_LIMB((int32_t)((uint32_t)acc & LMASK));
@@ -325,8 +338,9 @@ inline void set_lazy_bounds(fp& r, double sum_lblb, double sum_vbvb, const char*
 
 template <bool SUB>
 C12381_HD void fp_mul2(fp& r, const fp& a, const fp& b, const fp& c, const fp& d) {
-    fp t;
-    fp_reduce_cols(t, [&](int k) { return SUB ? fp_col(a, b, k) - fp_col(c, d, k) : fp_col(a, b, k) + fp_col(c, d, k); });
+    fp t, cs;
+    if (SUB) fp_raw_neg(cs, c); else cs = c;
+    fp_reduce_cols(t, [&](int k, int64_t& acc) { fp_col_acc(acc, a, b, k); fp_col_acc(acc, cs, d, k); });
     C12381_BOUNDS({ check_actual(a, "fp_mul2"); check_actual(b, "fp_mul2"); check_actual(c, "fp_mul2"); check_actual(d, "fp_mul2");
                     set_lazy_bounds(t, a.lb * b.lb + c.lb * d.lb, a.vb * b.vb + c.vb * d.vb, "fp_mul2"); })
     r = t;

@@ -34,9 +34,10 @@ C12381_HD bool fp2_is_zero(const fp2& x) { return fp_is_zero(x.a) & fp_is_zero(x
 
 // r = x * y.  Operand limb bounds: LBx * LBy <= 2^58 (e.g. 2^29 each).  Output normalised.
 C12381_HD void fp2_mul(fp2& r, const fp2& x, const fp2& y) {
-    fp ra, rb;
-    fp_reduce_cols(ra, [&](int k) { return fp_col(x.a, y.a, k) - fp_col(x.b, y.b, k); });
-    fp_reduce_cols(rb, [&](int k) { return fp_col(x.a, y.b, k) + fp_col(x.b, y.a, k); });
+    fp ra, rb, nxb;
+    fp_raw_neg(nxb, x.b);
+    fp_reduce_cols(ra, [&](int k, int64_t& acc) { fp_col_acc(acc, x.a, y.a, k); fp_col_acc(acc, nxb, y.b, k); });
+    fp_reduce_cols(rb, [&](int k, int64_t& acc) { fp_col_acc(acc, x.a, y.b, k); fp_col_acc(acc, x.b, y.a, k); });
     C12381_BOUNDS({ check_actual(x.a, "fp2_mul"); check_actual(x.b, "fp2_mul"); check_actual(y.a, "fp2_mul"); check_actual(y.b, "fp2_mul");
                     set_lazy_bounds(ra, x.a.lb * y.a.lb + x.b.lb * y.b.lb, x.a.vb * y.a.vb + x.b.vb * y.b.vb, "fp2_mul.a");
                     set_lazy_bounds(rb, x.a.lb * y.b.lb + x.b.lb * y.a.lb, x.a.vb * y.b.vb + x.b.vb * y.a.vb, "fp2_mul.b"); })
@@ -44,9 +45,12 @@ C12381_HD void fp2_mul(fp2& r, const fp2& x, const fp2& y) {
 }
 // r = x^2 = (a^2 - b^2) + 2ab i.  Operand limb bound <= 2^29.
 C12381_HD void fp2_sqr(fp2& r, const fp2& x) {
-    fp ra, rb;
-    fp_reduce_cols(ra, [&](int k) { return fp_col_sqr(x.a, k) - fp_col_sqr(x.b, k); });
-    fp_reduce_cols(rb, [&](int k) { return 2 * fp_col(x.a, x.b, k); });
+    fp ra, rb, a2, nb2, nb;
+    fp_raw_dbl(a2, x.a);
+    fp_raw_neg_dbl(nb2, x.b);
+    fp_raw_neg(nb, x.b);
+    fp_reduce_cols(ra, [&](int k, int64_t& acc) { fp_col_sqr_acc(acc, x.a, a2, x.a, k); fp_col_sqr_acc(acc, x.b, nb2, nb, k); });
+    fp_reduce_cols(rb, [&](int k, int64_t& acc) { fp_col_acc(acc, a2, x.b, k); });
     C12381_BOUNDS({ check_actual(x.a, "fp2_sqr"); check_actual(x.b, "fp2_sqr");
                     set_lazy_bounds(ra, x.a.lb * x.a.lb + x.b.lb * x.b.lb, x.a.vb * x.a.vb + x.b.vb * x.b.vb, "fp2_sqr.a");
                     set_lazy_bounds(rb, 2 * x.a.lb * x.b.lb, 2 * x.a.vb * x.b.vb, "fp2_sqr.b"); })
@@ -56,8 +60,10 @@ C12381_HD void fp2_sqr(fp2& r, const fp2& x) {
 C12381_HD void fp2_mul_fp(fp2& r, const fp2& x, const fp& s) { fp_mul(r.a, x.a, s); fp_mul(r.b, x.b, s); }
 // r = 1/x  (FP2_inv :334): conj(x) / (a^2 + b^2)
 C12381_HDN void fp2_inv(fp2& r, const fp2& x) {
-    fp n, ni, nb;
-    fp_reduce_cols(n, [&](int k) { return fp_col_sqr(x.a, k) + fp_col_sqr(x.b, k); });
+    fp n, ni, nb, a2, b2;
+    fp_raw_dbl(a2, x.a);
+    fp_raw_dbl(b2, x.b);
+    fp_reduce_cols(n, [&](int k, int64_t& acc) { fp_col_sqr_acc(acc, x.a, a2, x.a, k); fp_col_sqr_acc(acc, x.b, b2, x.b, k); });
     C12381_BOUNDS(set_lazy_bounds(n, x.a.lb * x.a.lb + x.b.lb * x.b.lb, x.a.vb * x.a.vb + x.b.vb * x.b.vb, "fp2_inv");)
     fp_inv(ni, n);
     fp_mul(r.a, x.a, ni);
@@ -78,7 +84,10 @@ C12381_HD int fp2_sign(const fp2& x) {
 // non-residue (or 0); on success w is the root of sign 0, exactly as the reference returns it.
 C12381_HDN bool fp2_sqrt(fp2& w, const fp2& u) {
     fp n, w1, w1inv, w2, hb, half, ra, rainv, rb;
-    fp_reduce_cols(n, [&](int k) { return fp_col_sqr(u.a, k) + fp_col_sqr(u.b, k); });
+    fp ua2, ub2;
+    fp_raw_dbl(ua2, u.a);
+    fp_raw_dbl(ub2, u.b);
+    fp_reduce_cols(n, [&](int k, int64_t& acc) { fp_col_sqr_acc(acc, u.a, ua2, u.a, k); fp_col_sqr_acc(acc, u.b, ub2, u.b, k); });
     C12381_BOUNDS(set_lazy_bounds(n, u.a.lb * u.a.lb + u.b.lb * u.b.lb, u.a.vb * u.a.vb + u.b.vb * u.b.vb, "fp2_sqrt");)
     const bool norm_qr = fp_sqrt_progen(w1, w1inv, n);          // w1 = sqrt(a^2 + b^2)
     fp_set_const(half, FP_HALF);
