@@ -80,6 +80,8 @@ def load_library() -> ctypes.CDLL:
             getattr(lib, name).argtypes = [vp, sz, vp, vp, vp]
         for name in ("c12381_bbs_plus_verify_batch", "c12381_bbs_plus_verify_batch_dev"):
             getattr(lib, name).argtypes = [vp, sz, sz] + [vp] * 10
+        for name in ("c12381_bbs_plus_verify_aggregate", "c12381_bbs_plus_verify_aggregate_dev"):
+            getattr(lib, name).argtypes = [vp, sz, sz] + [vp] * 11
         _lib = lib
     return _lib
 
@@ -296,6 +298,22 @@ class Context:
         self._ck(self.lib.c12381_bbs_plus_verify_batch(self.h, n, nmsg, _p(g1), _p(g2), _p(h0), _p(h) if nmsg else None, _p(w), _p(A),
                                                        _p(x), _p(r), _p(m) if nmsg else None, _p(out)), allow_point=not strict)
         return out.raw[:n]
+
+    def bbs_plus_verify_aggregate(self, g1: bytes, g2: bytes, h0: bytes, h: bytes, w: bytes, A: bytes, x: bytes, r: bytes, m: bytes,
+                                  rho: bytes) -> bool:
+        """ONE verdict for the batch by a random linear combination (rho: n x 32 B caller-drawn scalars).  True: every
+        signature verifies (up to 2^-k for k-bit rho); False settles nothing — run bbs_plus_verify."""
+        n = len(A) // 96
+        nmsg = len(h) // 96
+        out = ctypes.c_int(0)
+        self._ck(self.lib.c12381_bbs_plus_verify_aggregate(self.h, n, nmsg, _p(g1), _p(g2), _p(h0), _p(h) if nmsg else None, _p(w),
+                                                           _p(A) if n else None, _p(x) if n else None, _p(r) if n else None,
+                                                           _p(m) if nmsg and n else None, _p(rho) if n else None, ctypes.byref(out)))
+        return out.value == 1
+
+    def bbs_plus_verify_aggregate_dev(self, n, nmsg, g1, g2, h0, h, w, A, x, r, m, rho, all_ok):
+        self._ck(self.lib.c12381_bbs_plus_verify_aggregate_dev(self.h, n, nmsg, _p(g1), _p(g2), _p(h0), _p(h), _p(w), _p(A), _p(x), _p(r),
+                                                               _p(m), _p(rho), _p(all_ok)))
 
     def bbs_plus_verify_dev(self, n, nmsg, g1, g2, h0, h, w, A, x, r, m, ok):
         self._ck(self.lib.c12381_bbs_plus_verify_batch_dev(self.h, n, nmsg, _p(g1), _p(g2), _p(h0), _p(h), _p(w), _p(A), _p(x), _p(r),

@@ -43,7 +43,7 @@ struct c12381_ctx {
     std::vector<hipEvent_t> ev_chunk;     // one per chunk of a scalar-mul batch (main -> side dependencies)
     char err[256] = {0};
     enum { WS_TAB, WS_PROJ, WS_PREF, WS_IN0, WS_IN1, WS_OUT, WS_RED0, WS_RED1, WS_BBS_Q, WS_BBS_B, WS_BBS_IN,
-           WS_PAIR_ST, WS_FQ_W, WS_FQ_G, WS_FQ_GATE, WS_FQ_P, WS_FB_G2, WS_FB_G1_0, WS_FB_G1_1, WS_FB_G1_2, WS_FB_G1_3, WS_MSM_PTS, WS_MSM_K0, WS_MSM_K1, WS_MSM_V0, WS_MSM_V1, WS_MSM_TMP, WS_MSM_RNG, WS_MSM_BK, WS_MSM_ORD, WS_COUNT };
+           WS_PAIR_ST, WS_FQ_W, WS_FQ_G, WS_FQ_GATE, WS_FQ_P, WS_FB_G2, WS_FB_G1_0, WS_FB_G1_1, WS_FB_G1_2, WS_FB_G1_3, WS_MSM_PTS, WS_MSM_K0, WS_MSM_K1, WS_MSM_V0, WS_MSM_V1, WS_MSM_TMP, WS_MSM_RNG, WS_MSM_BK, WS_MSM_ORD, WS_MSM_OVF, WS_COUNT };
     void* ws[WS_COUNT] = {nullptr};
     size_t ws_bytes[WS_COUNT] = {0};
     int* d_flag = nullptr;
@@ -162,9 +162,14 @@ int stage_out(c12381_ctx* c, const staged& s, void* hout, size_t bout) {
     return 0;
 }
 
+// window width: msm_window_bits(n), or C12381_MSM_C = 4..16 (tuning runs)
+static int msm_c(size_t n) {
+    static const int forced = [] { const char* e = std::getenv("C12381_MSM_C"); const int v = e ? std::atoi(e) : 0; return v >= 4 && v <= 16 ? v : 0; }();
+    return forced ? forced : msm_window_bits(n);
+}
 // Bucket-method MSM (msm.hpp): prep -> radix sort -> bucket sums -> window reduction -> Horner -> affine.
 int g1_msm_pippenger(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
-    const int cb = msm_window_bits(n), W = msm_windows(cb);
+    const int cb = msm_c(n), W = msm_windows(cb);
     const size_t E = (size_t)2 * n * W, nb = (size_t)1 << cb, nbk = nb * W;
     int rc;
     if ((rc = ensure(c, c12381_ctx::WS_MSM_PTS, (size_t)2 * n * MSM_PT_DWORDS * 4))) return rc;
@@ -202,7 +207,18 @@ int g1_msm_pippenger(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t*
     }
     if ((rc = ensure(c, c12381_ctx::WS_MSM_ORD, nbk * 4))) return rc;
     uint32_t* order = (uint32_t*)c->ws[c12381_ctx::WS_MSM_ORD];
-    hipLaunchKernelGGL(msm_sizes_kernel, dim3(grid_for(nbk)), dim3(BLOCK), 0, c->stream, nbk, lo, hi, k0, v0);
+    // overflow bookkeeping for runs longer than MSM_RUN_CAP (k_g1.hip): counters | segment list | cut-bucket list | partial sums
+    const uint32_t run_cap = msm_run_cap(n, cb);
+    const size_t ovf_cap = E / (run_cap / 2) + 1;
+    const size_t o_seg = 256, o_big = o_seg + round_up(ovf_cap * 8, 256), o_part = o_big + round_up(ovf_cap * 16, 256);
+    if ((rc = ensure(c, c12381_ctx::WS_MSM_OVF, o_part + ovf_cap * G1_ENT_DWORDS * 4))) return rc;
+    uint8_t* ovf = (uint8_t*)c->ws[c12381_ctx::WS_MSM_OVF];
+    uint32_t* ovf_cnt = (uint32_t*)ovf;
+    uint2* ovf_seg = (uint2*)(ovf + o_seg);
+    uint4* ovf_big = (uint4*)(ovf + o_big);
+    int32_t* ovf_part = (int32_t*)(ovf + o_part);
+    HIPCK(c, hipMemsetAsync(ovf_cnt, 0, 16, c->stream));
+    hipLaunchKernelGGL(msm_sizes_kernel, dim3(grid_for(nbk)), dim3(BLOCK), 0, c->stream, nbk, lo, hi, k0, v0, run_cap, ovf_cnt, ovf_seg, ovf_big);
     HIPCK(c, hipGetLastError());
     size_t tmp2 = 0;
     HIPCK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, k0, k1, v0, order, (int)nbk, 0, 32, c->stream));
@@ -210,9 +226,16 @@ int g1_msm_pippenger(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t*
     HIPCK(c, hipcub::DeviceRadixSort::SortPairs(c->ws[c12381_ctx::WS_MSM_TMP], tmp2, k0, k1, v0, order, (int)nbk, 0, 32, c->stream));
     {
         timed tm(c, 5);
-        hipLaunchKernelGGL(msm_bucket_kernel, dim3(grid_for(nbk)), dim3(BLOCK), 0, c->stream, nbk, lo, hi, v1, pts2, bk, order);
+        hipLaunchKernelGGL(msm_bucket_kernel, dim3(grid_for(nbk)), dim3(BLOCK), 0, c->stream, nbk, lo, hi, v1, pts2, bk, order, run_cap);
         HIPCK(c, hipGetLastError());
     }
+    // uniform scalars register no overflow segment: both grids leave after reading the counters
+    hipLaunchKernelGGL(msm_overflow_kernel, dim3(grid_for(ovf_cap)), dim3(BLOCK), 0, c->stream, (const uint32_t*)ovf_cnt, (const uint2*)ovf_seg, lo, hi, v1, pts2,
+                       ovf_part, run_cap);
+    HIPCK(c, hipGetLastError());
+    hipLaunchKernelGGL(msm_overflow_combine_kernel, dim3(ovf_cap < 4096 ? (unsigned)((ovf_cap + 3) / 4) : 1024u), dim3(BLOCK), 0, c->stream,
+                       (const uint32_t*)ovf_cnt, (const uint4*)ovf_big, (const int32_t*)ovf_part, bk);
+    HIPCK(c, hipGetLastError());
     const uint32_t chunks = (uint32_t)((nb + MSM_CHUNK - 1) / MSM_CHUNK);
     size_t cur_n = (size_t)W * chunks, cur_stride = round_up(cur_n, 64);
     if ((rc = ensure(c, c12381_ctx::WS_RED0, (size_t)3 * NL * cur_stride * 4))) return rc;
@@ -1051,6 +1074,91 @@ int c12381_bbs_plus_verify_batch(c12381_ctx* c, size_t n, size_t nmsg, const uin
     if ((rc = c12381_bbs_plus_verify_batch_dev(c, n, nmsg, d + o_g1, d + o_g2, d + o_h0, d + o_h, d + o_w, d + o_A, d + o_x, d + o_r, d + o_m, d + o_ok))) return rc;
     HIPCK(c, hipMemcpyAsync(ok, d + o_ok, n, hipMemcpyDeviceToHost, c->stream));
     return read_flag(c);
+}
+
+// ---------------------------------------------------------------- BBS+ aggregate verification (optional)
+// ONE verdict for the whole batch by a random linear combination: with caller-drawn rho_j,
+//   prod_j [ e(A_j, w) e(x_j A_j - B_j, g2) ]^rho_j
+//     = e( sum_j rho_j A_j, w ) * e( sum_j (rho_j x_j) A_j - (sum_j rho_j) g1 - (sum_j rho_j r_j) h0 - sum_i (sum_j rho_j m_ij) h_i, g2 )
+// — the per-signature point arithmetic collapses into inner products mod r, two bucket products over the A_j and one
+// product of two pairings.  all_ok = 1 iff g2, w are elements of G2 and the combined product is 1; every signature the
+// per-signature entry accepts contributes a factor 1 (cofactor components of any argument pair to 1 against G2), so
+// a batch of valid signatures always yields 1, and a batch containing an invalid one yields 1 with probability at most
+// 2^-k over k-bit uniform rho_j.  all_ok = 0 settles nothing: the caller then runs the per-signature entry.
+// The reference has no such mode (it verifies one signature at a time, bbs+.cpp:57-73); the booleans of
+// c12381_bbs_plus_verify_batch stay the parity surface.
+int c12381_bbs_plus_verify_aggregate_dev(c12381_ctx* c, size_t n, size_t nmsg, const uint8_t* g1_96, const uint8_t* g2_192, const uint8_t* h0_96,
+                                         const uint8_t* h_96, const uint8_t* w_192, const uint8_t* A_96, const uint8_t* x_32, const uint8_t* r_32,
+                                         const uint8_t* m_32, const uint8_t* rho_32, uint8_t* all_ok) {
+    int rc = bind(c); if (rc) return rc;
+    if (!g1_96 || !g2_192 || !h0_96 || !w_192 || !all_ok || (n && (!A_96 || !x_32 || !r_32 || !rho_32)) || (nmsg && (!h_96 || (n && !m_32)))) return C12381_E_ARG;
+    const size_t terms = n + nmsg + 2;
+    if (terms > MSM_MAX_TERMS) return C12381_E_ARG;            // split the batch: one bucket product per call
+    if (n == 0) { HIPCK(c, hipMemsetAsync(all_ok, 1, 1, c->stream)); return 0; }
+    HIPCK(c, hipMemsetAsync(all_ok, 0, 1, c->stream));
+    if ((rc = lines_table(c, c12381_ctx::WS_FQ_W, w_192, 1))) return rc;
+    if ((rc = lines_table(c, c12381_ctx::WS_FQ_G, g2_192, 1))) return rc;
+    if ((rc = ensure(c, c12381_ctx::WS_FQ_GATE, 128 * 4))) return rc;
+    int32_t* gate = (int32_t*)c->ws[c12381_ctx::WS_FQ_GATE];
+    hipLaunchKernelGGL(gate_and_kernel, dim3(1), dim3(BLOCK), 0, c->stream, gate, (const int32_t*)c->ws[c12381_ctx::WS_FQ_W],
+                       (const int32_t*)c->ws[c12381_ctx::WS_FQ_G]);
+    HIPCK(c, hipGetLastError());
+    const size_t o_p = round_up(96 * terms, 256);
+    if ((rc = ensure(c, c12381_ctx::WS_BBS_B, o_p + 256))) return rc;
+    if ((rc = ensure(c, c12381_ctx::WS_BBS_Q, 32 * terms))) return rc;
+    uint8_t* pts = (uint8_t*)c->ws[c12381_ctx::WS_BBS_B];        // A_1 .. A_n, g1, h0, h_1 .. h_nmsg | P1, P2
+    uint8_t* sc = (uint8_t*)c->ws[c12381_ctx::WS_BBS_Q];         // rho_j x_j | -sum rho_j, -sum rho_j r_j, -sum_j rho_j m_ij
+    uint8_t *tail = sc + 32 * n, *p1 = pts + o_p, *p2 = p1 + 96;
+    hipLaunchKernelGGL(zp_op_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, 0, n, rho_32, x_32, sc);
+    HIPCK(c, hipGetLastError());
+    if ((rc = c12381_zp_inner_product_dev(c, n, rho_32, nullptr, tail))) return rc;
+    if ((rc = c12381_zp_inner_product_dev(c, n, rho_32, r_32, tail + 32))) return rc;
+    for (size_t i = 0; i < nmsg; ++i)
+        if ((rc = c12381_zp_inner_product_dev(c, n, rho_32, m_32 + 32 * n * i, tail + 64 + 32 * i))) return rc;
+    hipLaunchKernelGGL(zp_op_kernel, dim3(grid_for(nmsg + 2)), dim3(BLOCK), 0, c->stream, 3, nmsg + 2, (const uint8_t*)tail, (const uint8_t*)nullptr, tail);
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipMemcpyAsync(pts, A_96, 96 * n, hipMemcpyDeviceToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(pts + 96 * n, g1_96, 96, hipMemcpyDeviceToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(pts + 96 * (n + 1), h0_96, 96, hipMemcpyDeviceToDevice, c->stream));
+    if (nmsg) HIPCK(c, hipMemcpyAsync(pts + 96 * (n + 2), h_96, 96 * nmsg, hipMemcpyDeviceToDevice, c->stream));
+    if ((rc = c12381_g1_msm_dev(c, n, A_96, rho_32, p1, 96))) return rc;
+    if ((rc = c12381_g1_msm_dev(c, terms, pts, sc, p2, 96))) return rc;
+    uint4* st; unsigned int *fl, *ct; unsigned blocks;
+    if ((rc = pair_queue_setup(c, 1, st, fl, ct, blocks))) return rc;
+    hipLaunchKernelGGL(pair3_prod_fixed_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, (size_t)1, (const uint8_t*)p1, (const uint8_t*)p2,
+                       (const int32_t*)c->ws[c12381_ctx::WS_FQ_W] + FB_HEADER_DWORDS, (const int32_t*)c->ws[c12381_ctx::WS_FQ_G] + FB_HEADER_DWORDS, all_ok,
+                       c->d_flag, st, fl, ct, (const int32_t*)gate);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+int c12381_bbs_plus_verify_aggregate(c12381_ctx* c, size_t n, size_t nmsg, const uint8_t* g1_96, const uint8_t* g2_192, const uint8_t* h0_96,
+                                     const uint8_t* h_96, const uint8_t* w_192, const uint8_t* A_96, const uint8_t* x_32, const uint8_t* r_32,
+                                     const uint8_t* m_32, const uint8_t* rho_32, int* all_ok) {
+    int rc = bind(c); if (rc) return rc;
+    if (!g1_96 || !g2_192 || !h0_96 || !w_192 || !all_ok || (n && (!A_96 || !x_32 || !r_32 || !rho_32)) || (nmsg && (!h_96 || (n && !m_32)))) return C12381_E_ARG;
+    *all_ok = 0;
+    if (n == 0) { *all_ok = 1; return 0; }
+    const size_t o_g1 = 0, o_g2 = 96, o_h0 = 288, o_w = 384, o_h = 576, o_A = round_up(o_h + 96 * nmsg, 256), o_x = o_A + 96 * n,
+                 o_r = o_x + 32 * n, o_rho = o_r + 32 * n, o_m = o_rho + 32 * n, o_ok = round_up(o_m + 32 * n * nmsg, 256), bytes = o_ok + 256;
+    if ((rc = ensure(c, c12381_ctx::WS_BBS_IN, bytes))) return rc;
+    uint8_t* d = (uint8_t*)c->ws[c12381_ctx::WS_BBS_IN];
+    HIPCK(c, hipMemcpyAsync(d + o_g1, g1_96, 96, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d + o_g2, g2_192, 192, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d + o_h0, h0_96, 96, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d + o_w, w_192, 192, hipMemcpyHostToDevice, c->stream));
+    if (nmsg) HIPCK(c, hipMemcpyAsync(d + o_h, h_96, 96 * nmsg, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d + o_A, A_96, 96 * n, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d + o_x, x_32, 32 * n, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d + o_r, r_32, 32 * n, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d + o_rho, rho_32, 32 * n, hipMemcpyHostToDevice, c->stream));
+    if (nmsg) HIPCK(c, hipMemcpyAsync(d + o_m, m_32, 32 * n * nmsg, hipMemcpyHostToDevice, c->stream));
+    if ((rc = c12381_bbs_plus_verify_aggregate_dev(c, n, nmsg, d + o_g1, d + o_g2, d + o_h0, d + o_h, d + o_w, d + o_A, d + o_x, d + o_r, d + o_m, d + o_rho,
+                                                   d + o_ok))) return rc;
+    uint8_t verdict = 0;
+    HIPCK(c, hipMemcpyAsync(&verdict, d + o_ok, 1, hipMemcpyDeviceToHost, c->stream));
+    rc = read_flag(c);                                          // synchronises the stream
+    *all_ok = (rc == 0 && verdict == 1) ? 1 : 0;
+    return rc;
 }
 
 // BBS+ signing for a batch (bbs+.cpp:38-55): A_j = (g1 * h0^r_j * prod_i h_i^m_ij)^(1/(gamma + x_j)).  x_j, r_j are the

@@ -255,22 +255,87 @@ __global__ void __launch_bounds__(BLOCK, 2) msm_ranges_kernel(size_t E, const ui
 }
 
 // sort key for "longest run first": buckets are handed to lanes in order of decreasing size, so the 64 lanes of a
-// wavefront sum runs of (almost) the same length instead of waiting for the longest of 64 random ones
-__global__ void __launch_bounds__(BLOCK, 2) msm_sizes_kernel(size_t nbk, const uint32_t* lo, const uint32_t* hi, uint32_t* key, uint32_t* ident) {
+// wavefront sum runs of (almost) the same length instead of waiting for the longest of 64 random ones.
+// A run longer than `cap` (msm_run_cap: uniform scalars stay below it; equal, small or structured scalars give runs of up
+// to 2n, and so does a top window narrower than c bits) is cut: its bucket lane sums the first cap entries, every
+// further seg = cap/2 entries are an OVERFLOW SEGMENT summed by a lane of msm_overflow_kernel, and one wavefront per cut bucket adds the partial sums
+// (msm_overflow_combine_kernel) — so no lane ever walks more than cap entries, whatever the scalars are.
+// cnt[0] = overflow segments, cnt[1] = cut buckets (zeroed by the host before this kernel).
+__global__ void __launch_bounds__(BLOCK, 2) msm_sizes_kernel(size_t nbk, const uint32_t* lo, const uint32_t* hi, uint32_t* key, uint32_t* ident,
+                                                          uint32_t cap, uint32_t* cnt, uint2* seg, uint4* big) {
     const size_t b = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (b >= nbk) return;
-    key[b] = 0xffffffffu - (hi[b] - lo[b]);
+    const uint32_t len = hi[b] - lo[b];
+    key[b] = 0xffffffffu - (len < cap ? len : cap);
     ident[b] = (uint32_t)b;
+    if (len > cap) {
+        const uint32_t sl = cap / 2, ns = (len - cap + sl - 1) / sl;
+        const uint32_t base = atomicAdd(&cnt[0], ns);
+        const uint32_t q = atomicAdd(&cnt[1], 1u);
+        big[q] = make_uint4((uint32_t)b, base, ns, 0u);
+        for (uint32_t s = 0; s < ns; ++s) seg[base + s] = make_uint2((uint32_t)b, s);
+    }
 }
 __global__ void __launch_bounds__(BLOCK, 2) msm_bucket_kernel(size_t nbk, const uint32_t* lo, const uint32_t* hi, const uint32_t* vals,
-                                                           const int32_t* pts2, int32_t* bk, const uint32_t* order) {
+                                                           const int32_t* pts2, int32_t* bk, const uint32_t* order, uint32_t cap) {
     const size_t slot = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (slot >= nbk) return;
     const size_t b = order[slot];
     g1p acc, nn;
-    msm_bucket_one(acc, lo[b], hi[b], vals, pts2);
+    const size_t l = lo[b], h = hi[b];
+    msm_bucket_one(acc, l, h - l > cap ? l + cap : h, vals, pts2);
     g1_norm1(nn, acc);
     tab_store_g1(bk + b * G1_ENT_DWORDS, nn);
+}
+// partial sum of overflow segment q (entries [lo + cap + s seg, lo + cap + (s + 1) seg) of its run); the grid covers the
+// capacity of the segment list, lanes beyond the registered count leave at once
+__global__ void __launch_bounds__(BLOCK, 2) msm_overflow_kernel(const uint32_t* cnt, const uint2* seg, const uint32_t* lo, const uint32_t* hi,
+                                                             const uint32_t* vals, const int32_t* pts2, int32_t* part, uint32_t cap) {
+    const size_t q = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (q >= cnt[0]) return;
+    const uint2 e = seg[q];
+    const size_t sl = cap / 2, start = (size_t)lo[e.x] + cap + (size_t)e.y * sl, h = hi[e.x];
+    g1p acc, nn;
+    msm_bucket_one(acc, start, h - start > sl ? start + sl : h, vals, pts2);
+    g1_norm1(nn, acc);
+    tab_store_g1(part + q * G1_ENT_DWORDS, nn);
+}
+// bucket b += its overflow partial sums: one wavefront per cut bucket (lanes take the partial sums strided, then
+// six shuffle-and-add steps); wavefronts stride over the list of cut buckets
+__global__ void __launch_bounds__(BLOCK, 2) msm_overflow_combine_kernel(const uint32_t* cnt, const uint4* big, const int32_t* part, int32_t* bk) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const size_t wave = ((size_t)blockIdx.x * BLOCK + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * BLOCK) >> 6;
+    const uint32_t nbig = cnt[1];
+#pragma unroll 1
+    for (size_t q = wave; q < nbig; q += nwaves) {                          // wave-uniform
+        const uint4 e = big[q];
+        g1p acc, t, nn;
+        g1_set_inf(acc);
+#pragma unroll 1
+        for (uint32_t j0 = 0; j0 < e.z; j0 += 64) {
+            const uint32_t j = j0 + lane;
+            if (j < e.z) {
+                tab_load_g1(t, part + ((size_t)e.y + j) * G1_ENT_DWORDS);
+                g1_add(acc, t);
+                g1_norm1(nn, acc); acc = nn;
+            }
+        }
+        if (lane == 0) {
+            tab_load_g1(t, bk + (size_t)e.x * G1_ENT_DWORDS);
+            g1_add(acc, t);
+            g1_norm1(nn, acc); acc = nn;
+        }
+#pragma unroll 1
+        for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                t.x.l[i] = __shfl_down(acc.x.l[i], off, 64); t.y.l[i] = __shfl_down(acc.y.l[i], off, 64); t.z.l[i] = __shfl_down(acc.z.l[i], off, 64);
+            }
+            g1_add(acc, t);
+            g1_norm1(nn, acc); acc = nn;
+        }
+        if (lane == 0) tab_store_g1(bk + (size_t)e.x * G1_ENT_DWORDS, acc);
+    }
 }
 
 __global__ void __launch_bounds__(BLOCK, 2) msm_wreduce_kernel(int W, uint32_t nb, uint32_t chunks, const int32_t* bk, int32_t* out, size_t out_stride) {

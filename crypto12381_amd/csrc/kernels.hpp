@@ -35,8 +35,10 @@ __global__ void __launch_bounds__(BLOCK, 2) g1_reduce_kernel(size_t n, const int
 __global__ void __launch_bounds__(BLOCK, 2) g1_add_const_kernel(size_t n, int32_t* proj, size_t stride, const uint8_t* pt96, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) msm_prep_kernel(size_t n, const uint8_t* pts, const uint8_t* scalars, int c, int W, int32_t* pts2, uint32_t* keys, uint32_t* vals, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) msm_ranges_kernel(size_t E, const uint32_t* keys, uint32_t* lo, uint32_t* hi);
-__global__ void __launch_bounds__(BLOCK, 2) msm_bucket_kernel(size_t nbk, const uint32_t* lo, const uint32_t* hi, const uint32_t* vals, const int32_t* pts2, int32_t* bk, const uint32_t* order);
-__global__ void __launch_bounds__(BLOCK, 2) msm_sizes_kernel(size_t nbk, const uint32_t* lo, const uint32_t* hi, uint32_t* key, uint32_t* ident);
+__global__ void __launch_bounds__(BLOCK, 2) msm_bucket_kernel(size_t nbk, const uint32_t* lo, const uint32_t* hi, const uint32_t* vals, const int32_t* pts2, int32_t* bk, const uint32_t* order, uint32_t cap);
+__global__ void __launch_bounds__(BLOCK, 2) msm_sizes_kernel(size_t nbk, const uint32_t* lo, const uint32_t* hi, uint32_t* key, uint32_t* ident, uint32_t cap, uint32_t* cnt, uint2* seg, uint4* big);
+__global__ void __launch_bounds__(BLOCK, 2) msm_overflow_kernel(const uint32_t* cnt, const uint2* seg, const uint32_t* lo, const uint32_t* hi, const uint32_t* vals, const int32_t* pts2, int32_t* part, uint32_t cap);
+__global__ void __launch_bounds__(BLOCK, 2) msm_overflow_combine_kernel(const uint32_t* cnt, const uint4* big, const int32_t* part, int32_t* bk);
 __global__ void __launch_bounds__(BLOCK, 2) msm_wreduce_kernel(int W, uint32_t nb, uint32_t chunks, const int32_t* bk, int32_t* out, size_t out_stride);
 __global__ void __launch_bounds__(BLOCK, 2) g1_decompress_kernel(size_t n, const uint8_t* in, uint8_t* out, uint8_t* status);
 __global__ void __launch_bounds__(64, 1) msm_horner_kernel(const int32_t* rw, size_t stride, int W, int c, int32_t* out, size_t out_stride);

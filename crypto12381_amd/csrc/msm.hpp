@@ -18,12 +18,19 @@ namespace c12381 {
 
 constexpr int MSM_PT_DWORDS = 2 * NL;          // affine (x, y) in Montgomery form, normalised limbs: 112 B, seven 16-byte words
 constexpr int MSM_CHUNK = 16;                  // buckets per lane in the window reduction
+// entries a bucket lane sums at most (twice the mean run, at least 256); the rest of a longer run is cut into overflow
+// segments of half that length, one lane each (k_g1.hip)
+C12381_HD uint32_t msm_run_cap(size_t n, int c) { const size_t mean = (2 * n) >> c; return mean > 128 ? (uint32_t)(2 * mean) : 256u; }
 
-C12381_HD int msm_window_bits(size_t n) {      // c ~ log2(2n) - 7, clamped
+C12381_HD int msm_window_bits(size_t n) {
+    // 16 bits = 8 windows over the 128-bit halves with no narrow top window (a top window of t < c bits has 2^t buckets
+    // with 2^(c-t) times longer runs); measured on MI355X, 2^12 .. 2^22 terms: c = 16 is the fastest width throughout
+    // (tools/msm_sweep.py).  Below 2^12 terms (forced bucket mode, host simulation): c ~ log2(2n) - 7, at least 4.
+    if (n >= 4096) return 16;
     int lg = 0;
     while (((size_t)2 << lg) <= 2 * n && lg < 40) ++lg;      // lg = floor(log2(2n))
     int c = lg - 7;
-    return c < 4 ? 4 : (c > 16 ? 16 : c);
+    return c < 4 ? 4 : c;
 }
 C12381_HD int msm_windows(int c) { return (128 + c - 1) / c; }
 

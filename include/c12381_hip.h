@@ -171,6 +171,23 @@ int c12381_bbs_plus_verify_batch(c12381_ctx* ctx, size_t n, size_t nmsg, const u
 int c12381_bbs_plus_verify_batch_dev(c12381_ctx* ctx, size_t n, size_t nmsg, const uint8_t* g1_96, const uint8_t* g2_192,
                                      const uint8_t* h0_96, const uint8_t* h_96, const uint8_t* w_192, const uint8_t* A_96,
                                      const uint8_t* x_32, const uint8_t* r_32, const uint8_t* m_32, uint8_t* ok);
+/* Optional aggregate mode ("random-linear-combination batching ... behind a flag"; the reference has no
+ * counterpart, it verifies one signature per call, bbs+.cpp:57-73).  ONE verdict for the batch:
+ *   *all_ok = 1  iff g2 and w are elements of G2 and
+ *                prod_j [ e(A_j, w) e(x_j A_j - B_j, g2) ]^rho[j] == 1,   B_j = g1 + r_j h0 + sum_i m[i*n + j] h_i,
+ * evaluated as inner products mod r, two bucket products over the A_j and ONE product of two pairings.  rho: n x 32 B
+ * scalars drawn by the caller, unpredictable to whoever produced the signatures (128 random bits each suffice).
+ * If every signature passes c12381_bbs_plus_verify_batch, *all_ok = 1; if one does not, *all_ok = 1 with probability
+ * at most 2^-k over rho drawn uniformly from k-bit values (k <= 254).  *all_ok = 0 settles nothing (an invalid signature, or public keys outside G2): run the
+ * per-signature entry then.  n = 0 gives 1.  At most 2^26 - nmsg - 2 signatures per call.  The _dev form writes one
+ * byte. */
+int c12381_bbs_plus_verify_aggregate(c12381_ctx* ctx, size_t n, size_t nmsg, const uint8_t* g1_96, const uint8_t* g2_192,
+                                     const uint8_t* h0_96, const uint8_t* h_96, const uint8_t* w_192, const uint8_t* A_96,
+                                     const uint8_t* x_32, const uint8_t* r_32, const uint8_t* m_32, const uint8_t* rho_32, int* all_ok);
+int c12381_bbs_plus_verify_aggregate_dev(c12381_ctx* ctx, size_t n, size_t nmsg, const uint8_t* g1_96, const uint8_t* g2_192,
+                                         const uint8_t* h0_96, const uint8_t* h_96, const uint8_t* w_192, const uint8_t* A_96,
+                                         const uint8_t* x_32, const uint8_t* r_32, const uint8_t* m_32, const uint8_t* rho_32,
+                                         uint8_t* all_ok);
 
 /* hash-to-G1 ------------------------------------------------------------------- */
 /* G1Point::from_hash (include/crypto12381/g1_point.hpp:219-234) from the 64-byte SHA3-512 digest on: the digest as a

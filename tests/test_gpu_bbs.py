@@ -9,6 +9,12 @@ from util import R, golden, prng, scalars
 pytestmark = pytest.mark.gpu
 
 
+def _neg96(p):
+    from util import P
+    y = int.from_bytes(p[48:], "big")
+    return p[:48] + ((P - y) % P).to_bytes(48, "big")
+
+
 def _setup(orc, nmsg):
     g1 = bytes.fromhex(golden("g1")["generator"])
     g2 = bytes.fromhex(golden("g2")["generator"])
@@ -139,4 +145,80 @@ def test_bbs_plus_sign_batch(oracle_port):
     assert A[:96] == bytes(96)
     ok = ctx.bbs_plus_verify(G1p, G2p, h0, h, w, A, X, Rr, Mm)
     assert ok[1:] == b"\x01" * (n - 1)
+    ctx.close()
+
+
+def test_bbs_plus_verify_aggregate(oracle_port):
+    """Optional aggregate mode: one verdict per batch from a random linear combination.  It must be 1
+    exactly when the per-signature entry — the parity surface — accepts every signature, for batches on either side of the
+    bucket-method threshold, with signatures outside G1 (their cofactor part pairs to 1 in both evaluations), and 0
+    when a public key is outside G2 (nothing is established then)."""
+    from crypto12381_amd import Context
+    from util import cat
+    orc = oracle_port
+    nmsg = 2
+    G1p, G2p, h0, h, gamma, w = _setup(orc, nmsg)
+    ctx = Context(0)
+
+    def batch(n, seed):
+        A, X, Rr, M = [], [], [], [[] for _ in range(nmsg)]
+        for j in range(n):
+            msgs = [prng(seed + i, j) % R for i in range(nmsg)]
+            x, r = prng(seed + 10, j) % R, prng(seed + 11, j) % R
+            A.append(_sign(orc, G1p, h0, h, gamma, msgs, x, r))
+            X.append(x.to_bytes(32, "big")); Rr.append(r.to_bytes(32, "big"))
+            for i in range(nmsg):
+                M[i].append(msgs[i].to_bytes(32, "big"))
+        return b"".join(A), b"".join(X), b"".join(Rr), b"".join(b"".join(col) for col in M)
+
+    n = 24
+    A, X, Rr, Mm = batch(n, 800)
+    rho = b"".join((prng(830, j) % (1 << 128)).to_bytes(32, "big") for j in range(n))        # 128-bit coefficients
+    assert ctx.bbs_plus_verify(G1p, G2p, h0, h, w, A, X, Rr, Mm) == b"\x01" * n
+    assert ctx.bbs_plus_verify_aggregate(G1p, G2p, h0, h, w, A, X, Rr, Mm, rho) is True
+    # full-width coefficients, including 0 and values >= r (reduced like every scalar)
+    rho2 = (0).to_bytes(32, "big") + (R + 5).to_bytes(32, "big") + scalars(831, n - 2)
+    assert ctx.bbs_plus_verify_aggregate(G1p, G2p, h0, h, w, A, X, Rr, Mm, rho2) is True
+    # one wrong message / one tampered A / one wrong x: the verdict follows the per-signature booleans
+    for kind in range(3):
+        A2, X2, M2 = bytearray(A), bytearray(X), bytearray(Mm)
+        j = 5 + kind
+        if kind == 0:
+            M2[32 * (n * 1 + j) + 31] ^= 1
+        elif kind == 1:
+            A2[96 * j:96 * j + 96] = orc.g1_mul(bytes(A2[96 * j:96 * j + 96]), (3).to_bytes(32, "big"), 96)
+        else:
+            X2[32 * j + 31] ^= 2
+        per = ctx.bbs_plus_verify(G1p, G2p, h0, h, w, bytes(A2), bytes(X2), Rr, bytes(M2))
+        assert per == b"\x01" * j + b"\x00" + b"\x01" * (n - j - 1)
+        assert ctx.bbs_plus_verify_aggregate(G1p, G2p, h0, h, w, bytes(A2), bytes(X2), Rr, bytes(M2), rho) is False
+    # a signature whose A carries a cofactor component (A + T, T = [r]P' of order dividing the cofactor): the reference's
+    # equation accepts it, and so do both entries
+    off1 = cat(golden("g1")["offsubgroup_points"])
+    T = orc.g1_mul(off1[:96], (1).to_bytes(32, "big"), 96)          # PAIR_G1mul by 1 on a point outside G1: P' + [r]phi(P')
+    T = orc.g1_add(T, _neg96(off1[:96]), 96)                         # = [r]phi(P'), not infinity
+    assert T != bytes(96)
+    A3 = orc.g1_add(A[:96], T, 96) + A[96:]
+    assert A3 != A
+    assert ctx.bbs_plus_verify(G1p, G2p, h0, h, w, A3, X, Rr, Mm) == b"\x01" * n
+    assert ctx.bbs_plus_verify_aggregate(G1p, G2p, h0, h, w, A3, X, Rr, Mm, rho) is True
+    # public key outside G2: no verdict
+    off2 = cat(golden("g2")["offsubgroup_points"])
+    assert ctx.bbs_plus_verify_aggregate(G1p, G2p, h0, h, off2[:192], A, X, Rr, Mm, rho) is False
+    assert ctx.bbs_plus_verify_aggregate(G1p, off2[:192], h0, h, w, A, X, Rr, Mm, rho) is False
+    # back to valid keys (tables are rebuilt), empty batch, no message blocks
+    assert ctx.bbs_plus_verify_aggregate(G1p, G2p, h0, h, w, A, X, Rr, Mm, rho) is True
+    assert ctx.bbs_plus_verify_aggregate(G1p, G2p, h0, h, w, b"", b"", b"", b"", b"") is True
+    a0 = _sign(orc, G1p, h0, h, gamma, [], 11, 22)
+    assert ctx.bbs_plus_verify_aggregate(G1p, G2p, h0, b"", w, a0, (11).to_bytes(32, "big"), (22).to_bytes(32, "big"), b"", rho[:32]) is True
+    assert ctx.bbs_plus_verify_aggregate(G1p, G2p, h0, b"", w, a0, (12).to_bytes(32, "big"), (22).to_bytes(32, "big"), b"", rho[:32]) is False
+    # above the bucket-method threshold (4096 terms): repeat the valid batch, then break one lane
+    reps = 4200 // n + 1
+    nb = n * reps
+    Ab, Xb, Rb = A * reps, X * reps, Rr * reps
+    Mb = b"".join(Mm[32 * n * i:32 * n * (i + 1)] * reps for i in range(nmsg))
+    rhob = b"".join((prng(832, j) % (1 << 128)).to_bytes(32, "big") for j in range(nb))
+    assert ctx.bbs_plus_verify_aggregate(G1p, G2p, h0, h, w, Ab, Xb, Rb, Mb, rhob) is True
+    Xbad = bytearray(Xb); Xbad[32 * 4100 + 31] ^= 1
+    assert ctx.bbs_plus_verify_aggregate(G1p, G2p, h0, h, w, Ab, bytes(Xbad), Rb, Mb, rhob) is False
     ctx.close()

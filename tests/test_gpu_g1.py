@@ -135,6 +135,30 @@ def test_msm_bucket_method_vs_naive_and_oracle(ctx, oracle_port):
     assert ctx.g1_msm(off * reps, osc * reps, 96) == oracle_port.g1_msm(off * reps, osc * reps, 96, 16)
 
 
+def test_msm_skewed_scalars(ctx, oracle_port):
+    """Scalars that put thousands of terms into one bucket (all equal, all small, 128-bit, one giant value among zeros):
+    runs longer than the per-lane cap are cut into overflow segments and recombined — same point as the oracle's sum."""
+    n = 6000
+    g1 = bytes.fromhex(golden("g1")["generator"])
+    pts = ctx.g1_mul(g1 * n, scalars(621, n), 96)
+    k = scalars(622, 1)
+    x2 = 0xd201000000010000 ** 2
+    cases = {
+        "equal": k * n,
+        "ones": (1).to_bytes(32, "big") * n,
+        "128-bit": b"".join((int.from_bytes(scalars(623, n)[32 * j:32 * j + 32], "big") % (1 << 128)).to_bytes(32, "big") for j in range(n)),
+        "two values": b"".join((k if j % 3 else (x2 + 7).to_bytes(32, "big")) for j in range(n)),
+        "run of 257": k * 257 + scalars(624, n - 257),              # cap 256: one overflow segment holding a single entry
+        "run of 512": k * 512 + scalars(625, n - 512),              # the cap and exactly two full segments of 128
+        "zeros": bytes(32) * (n - 1) + k,
+    }
+    for name, sc in cases.items():
+        assert ctx.g1_msm(pts, sc, 96) == oracle_port.g1_msm(pts, sc, 96, 16), name
+    # equal scalars: k * (sum of the points)
+    total = ctx.g1_msm(pts, (1).to_bytes(32, "big") * n, 96)
+    assert ctx.g1_msm(pts, k * n, 96) == ctx.g1_mul(total, k, 96)
+
+
 def test_fixed_base_entry_points(ctx, oracle_port):
     """g^x_i with one base: table path for subgroup bases, generic path otherwise — always equal to the generic batch."""
     g = golden("g1")
