@@ -18,10 +18,10 @@ namespace c12381 {
 
 constexpr int MSM_PT_DWORDS = 2 * NL;          // affine (x, y) in Montgomery form, normalised limbs: 112 B, seven 16-byte words
 constexpr int MSM_CHUNK = 16;                  // buckets per lane in the window reduction
-// entries a bucket lane sums at most (twice the mean run, at least 256); the rest of a longer run is cut into overflow
-// segments of half that length, one lane each (k_g1.hip)
-C12381_HD uint32_t msm_run_cap(size_t n, int c) { const size_t mean = (2 * n) >> c; return mean > 128 ? (uint32_t)(2 * mean) : 256u; }
-
+// entries a bucket lane sums at most: twice the mean run + 32 (uniform scalars: mean + 11 sigma or more, so nothing is
+// cut); the rest of a longer run is cut into overflow segments of half that length, one lane each (k_g1.hip).  A lane
+// with a long run finishes alone at single-wavefront latency (~9 us per addition), hence a cap relative to the mean.
+C12381_HD uint32_t msm_run_cap(size_t n, int c) { const size_t mean = (2 * n) >> c; return (uint32_t)(2 * mean + 32); }
 C12381_HD int msm_window_bits(size_t n) {
     // 16 bits = 8 windows over the 128-bit halves with no narrow top window (a top window of t < c bits has 2^t buckets
     // with 2^(c-t) times longer runs); measured on MI355X, 2^12 .. 2^22 terms: c = 16 is the fastest width throughout

@@ -148,8 +148,8 @@ def test_msm_skewed_scalars(ctx, oracle_port):
         "ones": (1).to_bytes(32, "big") * n,
         "128-bit": b"".join((int.from_bytes(scalars(623, n)[32 * j:32 * j + 32], "big") % (1 << 128)).to_bytes(32, "big") for j in range(n)),
         "two values": b"".join((k if j % 3 else (x2 + 7).to_bytes(32, "big")) for j in range(n)),
-        "run of 257": k * 257 + scalars(624, n - 257),              # cap 256: one overflow segment holding a single entry
-        "run of 512": k * 512 + scalars(625, n - 512),              # the cap and exactly two full segments of 128
+        "run of 33": k * 33 + scalars(624, n - 33),                 # cap 32 at this size: one overflow segment holding a single entry
+        "run of 64": k * 64 + scalars(625, n - 64),                 # the cap and exactly two full segments of 16
         "zeros": bytes(32) * (n - 1) + k,
     }
     for name, sc in cases.items():
