@@ -91,30 +91,72 @@ C12381_HD void scalar_mod_r(uint32_t (&k)[8]) {
         for (int i = 0; i < 8; ++i) k[i] = ge ? d[i] : k[i];
     }
 }
-// k < r  ->  k = k0 + k1 * x^2 with 0 <= k0 < x^2 < 2^128 and k1 < 2^128  (restoring division;
-// replaces glv() pair_BLS12381.cpp:793-805, whose u1 = r - (e div x^2) belongs to the opposite sign
-// convention of the endomorphism).
+// k < r  ->  k = k0 + k1 * x^2 with 0 <= k0 < x^2 < 2^128 and k1 < 2^128  (replaces glv() pair_BLS12381.cpp:793-805,
+// whose u1 = r - (e div x^2) belongs to the opposite sign convention of the endomorphism).
+// Barrett division by the 128-bit constant x^2 (top bit set): q^ = floor(floor(k / 2^127) * mu / 2^129) with
+// mu = floor(2^256 / x^2) satisfies q - 2 <= q^ <= q for k < 2^256, so two conditional subtractions finish it:
+// ~60 multiply-adds instead of a 256-step restoring division (which was more than half of the MSM preparation kernel).
 C12381_HD void scalar_glv_split(uint32_t (&k0)[4], uint32_t (&k1)[4], const uint32_t (&k)[8]) {
-    uint32_t rem[5] = {0, 0, 0, 0, 0};
-    uint32_t q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 1
-    for (int bit = 255; bit >= 0; --bit) {
-        const uint32_t in = (k[bit >> 5] >> (bit & 31)) & 1u;
+    uint32_t a[5], prod[10];
 #pragma unroll
-        for (int i = 4; i >= 1; --i) rem[i] = (rem[i] << 1) | (rem[i - 1] >> 31);
-        rem[0] = (rem[0] << 1) | in;
+    for (int i = 0; i < 5; ++i) a[i] = (k[i + 3] >> 31) | (i + 4 < 8 ? k[i + 4] << 1 : 0u);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) prod[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        uint64_t carry = 0;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const uint64_t t = (uint64_t)a[i] * GLV_MU[j] + prod[i + j] + carry;
+            prod[i + j] = (uint32_t)t;
+            carry = t >> 32;
+        }
+        prod[i + 5] = (uint32_t)carry;
+    }
+    uint32_t q[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = (prod[4 + i] >> 1) | (prod[5 + i] << 31);
+    // rem = k - q * x^2, exact in 160 bits (0 <= rem < 3 x^2)
+    uint32_t qd[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint64_t carry = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (i + j < 5) {
+                const uint64_t t = (uint64_t)q[i] * GLV_X2[j] + qd[i + j] + carry;
+                qd[i + j] = (uint32_t)t;
+                carry = t >> 32;
+            }
+        }
+        if (i + 4 < 5) qd[i + 4] = (uint32_t)carry;
+    }
+    uint32_t rem[5];
+    {
+        uint64_t bw = 0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const uint64_t t = (uint64_t)k[i] - qd[i] - bw;
+            rem[i] = (uint32_t)t;
+            bw = (t >> 32) & 1;
+        }
+    }
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
         uint32_t d[5];
         uint64_t bw = 0;
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
-            uint64_t t = (uint64_t)rem[i] - (i < 4 ? GLV_X2[i] : 0u) - bw;
+            const uint64_t t = (uint64_t)rem[i] - (i < 4 ? GLV_X2[i] : 0u) - bw;
             d[i] = (uint32_t)t;
             bw = (t >> 32) & 1;
         }
         const bool ge = bw == 0;
 #pragma unroll
         for (int i = 0; i < 5; ++i) rem[i] = ge ? d[i] : rem[i];
-        q[bit >> 5] |= (ge ? 1u : 0u) << (bit & 31);
+        uint64_t c = ge ? 1u : 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { c += q[i]; q[i] = (uint32_t)c; c >>= 32; }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) { k0[i] = rem[i]; k1[i] = q[i]; }

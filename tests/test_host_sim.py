@@ -52,6 +52,12 @@ def test_sim_glv_split(sim):
     x2 = 0xd201000000010000 ** 2
     ks = [0, 1, R - 1, R, R + 5, (1 << 256) - 1, x2, x2 - 1, x2 + 1, 3 * x2 - 1] + \
          [int.from_bytes(scalars(77, 20, 1 << 256)[32 * i:32 * i + 32], "big") for i in range(20)]
+    # the split is a Barrett division by x^2 with two correction steps: walk the multiples of x^2 (quotient estimate
+    # off by 0, 1, 2), powers of two and a few thousand random values
+    qs = [int.from_bytes(scalars(78, 400)[32 * i:32 * i + 32], "big") >> (128 + (i % 120)) for i in range(400)] + [(R // x2) - j for j in range(3)]
+    ks += [q * x2 + d for q in qs for d in (-2, -1, 0, 1, 2) if 0 <= q * x2 + d < R]
+    ks += [(1 << b) + d for b in range(255) for d in (-1, 0, 1) if 0 <= (1 << b) + d < R]
+    ks += [int.from_bytes(scalars(79, 3000)[32 * i:32 * i + 32], "big") for i in range(3000)]
     for k in ks:
         k0 = (ctypes.c_uint32 * 4)()
         k1 = (ctypes.c_uint32 * 4)()

@@ -209,6 +209,8 @@ def main():
     out.append("C12381_CONST uint32_t EXP_P_MINUS_3_DIV_4[12] = {%s};\n" % words32((P - 3) // 4, 12))
     out.append("C12381_CONST uint32_t ORDER_R[8] = {%s};   // group order r (CURVE_Order)\n" % words32(R_ORD, 8))
     out.append("C12381_CONST uint32_t GLV_X2[4] = {%s};    // x^2, the GLV base: k = k0 + k1*x^2\n" % words32(X * X, 4))
+    assert (X * X) >> 127 == 1
+    out.append("C12381_CONST uint32_t GLV_MU[5] = {%s};    // floor(2^256 / x^2): Barrett reciprocal of the GLV base\n" % words32((1 << 256) // (X * X), 5))
     out.append("constexpr uint64_t BLS_X = 0x%xull;        // |x| (CURVE_Bnx); x itself is negative\n" % X)
     out.append("C12381_CONST uint32_t BLS_X_W[2] = {%s};\n" % words32(X, 2))
     out.append("\n// standard generators, Montgomery form (CURVE_Gx/Gy, CURVE_Pxa..Pyb)\n")
