@@ -741,10 +741,20 @@ int c12381_g1_clear_cofactor_batch(c12381_ctx* c, size_t n, const uint8_t* in96,
     if ((rc = stage_out(c, s, out96, 96 * n))) return rc;
     return read_flag(c);
 }
+// out[i] = 1 / (x[i] + gamma) (gamma may be null), simultaneous inversion in runs of ZP_INV_RUN (k_hash_zp.hip)
+static int zp_batch_inverse(c12381_ctx* c, size_t n, const uint8_t* x, const uint8_t* gamma, uint8_t* out) {
+    int rc;
+    if ((rc = ensure(c, c12381_ctx::WS_PREF, 32 * n))) return rc;
+    const size_t T = (n + ZP_INV_RUN - 1) / ZP_INV_RUN;
+    hipLaunchKernelGGL(zp_batch_inv_kernel, dim3(grid_for(T)), dim3(BLOCK), 0, c->stream, n, T, x, gamma, out, (uint32_t*)c->ws[c12381_ctx::WS_PREF]);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
 int c12381_zp_op_batch_dev(c12381_ctx* c, int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
     int rc = bind(c); if (rc) return rc;
     if (op < 0 || op > 4 || !a || !out || (op <= 2 && !b)) return C12381_E_ARG;
     if (n == 0) return 0;
+    if (op == 4) return zp_batch_inverse(c, n, a, nullptr, out);
     hipLaunchKernelGGL(zp_op_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, op, n, a, op <= 2 ? b : nullptr, out);
     HIPCK(c, hipGetLastError());
     return 0;
@@ -1175,8 +1185,7 @@ int c12381_bbs_plus_sign_batch_dev(c12381_ctx* c, size_t n, size_t nmsg, const u
     int32_t* red; size_t rstride, stride;
     if ((rc = bbs_message_points(c, n, nmsg, g1_96, h0_96, h_96, r_32, m_32, fixed_base_enabled(), red, rstride, stride))) return rc;
     if ((rc = g1_finish(c, n, red, rstride, d_b, 96))) return rc;
-    hipLaunchKernelGGL(zp_inv_sum_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, x_32, gamma_32, d_e);
-    HIPCK(c, hipGetLastError());
+    if ((rc = zp_batch_inverse(c, n, x_32, gamma_32, d_e))) return rc;
     return c12381_g1_mul_batch_dev(c, n, d_b, d_e, A_out96, 96);
 }
 int c12381_bbs_plus_sign_batch(c12381_ctx* c, size_t n, size_t nmsg, const uint8_t* g1_96, const uint8_t* h0_96, const uint8_t* h_96,

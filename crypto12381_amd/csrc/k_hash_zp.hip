@@ -1,7 +1,8 @@
 // Kernels either side of the point arithmetic, one element per lane:
 //   g1_from_hash_kernel   64-byte digest -> point of G1, or field element -> point of E (h2c.hpp); projective SoA
 //                         for g1_finish_kernel
-//   zp_op_kernel          scalar-field mul / add / sub / neg / inverse on canonical 32-byte values (fr.hpp)
+//   zp_op_kernel          scalar-field mul / add / sub / neg on canonical 32-byte values (fr.hpp)
+//   zp_batch_inv_kernel   simultaneous inversion (one exponentiation per 16 elements), optionally of x[i] + gamma
 //   zp_from_hash_kernel   64-byte digest -> scalar mod r
 //   zp_fold_kernel        strided partial sums of a[i] * b[i] (or of a[i]) mod r: inner products and sums
 #include "kernels_common.hpp"
@@ -77,21 +78,57 @@ __global__ void __launch_bounds__(BLOCK, 2) zp_op_kernel(int op, size_t n, const
         case 1: fr_add(r, x, y); break;
         case 2: fr_sub(r, x, y); break;
         case 3: fr_neg(r, x); break;
-        default: fr_inv(r, x); break;
+        default: fr_inv(r, x); break;              // the entry points send inversions to zp_batch_inv_kernel
     }
     fr_store32(out + 32 * i, r);
 }
 
-// out[i] = 1 / (x[i] + gamma) mod r for ONE gamma (BBS+ sign: inverse(gamma + x), bbs+.cpp:53); inverse(0) = 0
-__global__ void __launch_bounds__(BLOCK, 2) zp_inv_sum_kernel(size_t n, const uint8_t* x, const uint8_t* gamma, uint8_t* out) {
-    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    fr a, g, s, r;
-    fr_load32(a, x + 32 * i);
-    fr_load32(g, gamma);
-    fr_add(s, a, g);
-    fr_inv(r, s);
-    fr_store32(out + 32 * i, r);
+// out[i] = 1 / (x[i] + gamma) mod r  (gamma == nullptr: 1 / x[i]); inverse(0) = 0 (BIG_invmodp; unit-tests/zp_number.cpp:76).
+// Simultaneous inversion: lane t owns the ZP_INV_RUN elements t, t + T, t + 2T, ... (coalesced), multiplies them up
+// (zeros replaced by 1), inverts the product ONCE (a^(r-2), 319 multiplications) and unwinds — 3 multiplications per
+// element plus 1/16 of an exponentiation instead of a whole one.  `pref`: 8 words per element, running products.
+// out may alias x (an element is read before it is written, by the same lane).
+__global__ void __launch_bounds__(BLOCK, 2) zp_batch_inv_kernel(size_t n, size_t T, const uint8_t* x, const uint8_t* gamma, uint8_t* out, uint32_t* pref) {
+    const size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= T) return;
+    fr g, one, run;
+    fr_set_words(one, FR_R1);
+    if (gamma) fr_load32(g, gamma);
+    run = one;
+#pragma unroll 1
+    for (int j = 0; j < ZP_INV_RUN; ++j) {
+        const size_t i = t + (size_t)j * T;
+        if (i >= n) break;
+        fr a;
+        fr_load32(a, x + 32 * i);
+        if (gamma) fr_add(a, a, g);
+        if (fr_is_zero(a)) a = one;
+        fr_mul(run, run, a);
+        uint4* p = reinterpret_cast<uint4*>(pref + 8 * i);
+        p[0] = make_uint4(run.w[0], run.w[1], run.w[2], run.w[3]);
+        p[1] = make_uint4(run.w[4], run.w[5], run.w[6], run.w[7]);
+    }
+    fr inv;
+    fr_inv(inv, run);
+#pragma unroll 1
+    for (int j = ZP_INV_RUN - 1; j >= 0; --j) {
+        const size_t i = t + (size_t)j * T;
+        if (i >= n) continue;
+        fr a, prev, r;
+        fr_load32(a, x + 32 * i);
+        if (gamma) fr_add(a, a, g);
+        const bool z = fr_is_zero(a);
+        if (z) a = one;
+        if (j > 0) {
+            const uint4* p = reinterpret_cast<const uint4*>(pref + 8 * (i - T));
+            const uint4 lo = p[0], hi = p[1];
+            prev.w[0] = lo.x; prev.w[1] = lo.y; prev.w[2] = lo.z; prev.w[3] = lo.w; prev.w[4] = hi.x; prev.w[5] = hi.y; prev.w[6] = hi.z; prev.w[7] = hi.w;
+        } else prev = one;
+        fr_mul(r, inv, prev);
+        fr_mul(inv, inv, a);
+        if (z) { for (int k = 0; k < 8; ++k) r.w[k] = 0; }
+        fr_store32(out + 32 * i, r);
+    }
 }
 
 __global__ void __launch_bounds__(BLOCK, 2) zp_from_hash_kernel(size_t n, const uint8_t* digests, uint8_t* out) {

@@ -68,3 +68,18 @@ def test_zp_golden_and_ints(ctx):
     assert ctx.zp_inner_product(x) == (sum(xi) % R).to_bytes(32, "big")
     assert ctx.zp_inner_product(x[:32], y[:32]) == (xi[0] * yi[0] % R).to_bytes(32, "big")
     assert ctx.zp_inner_product(b"", b"") == bytes(32)
+
+
+def test_zp_batch_inverse_with_zeros(ctx):
+    """The inversion entry runs a simultaneous inversion over runs of 16 strided elements: zeros (inverse(0) = 0, also
+    as r and 2r) anywhere in a run — first, last, several, a whole run — must not disturb their neighbours; sizes that
+    leave the last runs short; exact values against Python."""
+    for n in (1, 15, 16, 17, 1000, 4099):
+        x = bytearray(scalars(61, n, 1 << 256))
+        T = (n + 15) // 16
+        zero_at = {0, n - 1, n // 2, T, 2 * T, min(n - 1, 3)} | ({j * T + 1 for j in range(16)} if n > 400 else set())
+        for k, i in enumerate(sorted(z for z in zero_at if 0 <= z < n)):
+            x[32 * i:32 * i + 32] = ((0, R, 2 * R)[k % 3]).to_bytes(32, "big")
+        x = bytes(x)
+        exp = b"".join(pow(int.from_bytes(x[32 * i:32 * i + 32], "big") % R, R - 2, R).to_bytes(32, "big") for i in range(n))
+        assert ctx.zp_op("inv", x) == exp, n
