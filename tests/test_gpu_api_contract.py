@@ -131,3 +131,50 @@ def test_device_pointer_decompress(ctx):
         assert ctx.sync() == 0
         assert list(bytes(d_st.cpu().numpy())) == g["decompress_status"]
         assert bytes(d_out.cpu().numpy()) == cat(g["decompressed"])
+
+
+def test_two_host_threads_two_contexts():
+    """One context per host thread (include/c12381_hip.h, "thread-compatible"): two threads drive their own contexts at
+    the same time — scalar multiplications and an MSM on one, pairings and Zp inversions on the other (ctypes releases
+    the GIL inside the calls) — and every result equals the single-threaded one."""
+    import threading
+    from crypto12381_amd import Context
+    g1g, g2g, gp = golden("g1"), golden("g2"), golden("pairing")
+    pts, sc = cat(g1g["points"]), cat(g1g["scalars"])
+    n = len(pts) // 96
+    reps = 300
+    big_pts, big_sc = pts * reps, sc * reps                          # 300 copies: above the bucket-method threshold
+    ref = Context(0)
+    want_mul = ref.g1_mul(big_pts, big_sc, 49)
+    want_msm = ref.g1_msm(big_pts, big_sc, 96)
+    p1, q2 = cat(gp["g1"]), cat(gp["g2"])
+    want_gt = ref.pair(p1 * 20, q2 * 20)
+    x = scalars(91, 5000, 1 << 256)
+    want_inv = ref.zp_op("inv", x)
+    ref.close()
+    errors = []
+
+    def worker_a():
+        try:
+            c = Context(0)
+            for _ in range(3):
+                assert c.g1_mul(big_pts, big_sc, 49) == want_mul
+                assert c.g1_msm(big_pts, big_sc, 96) == want_msm
+            c.close()
+        except BaseException as e:                                   # noqa: BLE001 — reported by the main thread
+            errors.append(("a", repr(e)))
+
+    def worker_b():
+        try:
+            c = Context(0)
+            for _ in range(3):
+                assert c.pair(p1 * 20, q2 * 20) == want_gt
+                assert c.zp_op("inv", x) == want_inv
+            c.close()
+        except BaseException as e:                                   # noqa: BLE001
+            errors.append(("b", repr(e)))
+
+    ta, tb = threading.Thread(target=worker_a), threading.Thread(target=worker_b)
+    ta.start(); tb.start(); ta.join(); tb.join()
+    assert not errors, errors
+    assert n > 0
