@@ -481,23 +481,42 @@ int c12381_g1_msm_multi(c12381_ctx** ctxs, int ngpu, size_t n, const uint8_t* pt
 }
 
 // ---------------------------------------------------------------- G2
+// finish = true: the kernel leaves projective results in WS_PROJ (the caller has sized it: 6 NL x round_up(n, 64) dwords)
+// and g2_finish converts them with one inversion per FINISH_M elements; false: per-lane conversion straight to `out`.
 static int g2_mul_dev_strided(c12381_ctx* c, size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* sc, uint8_t* out, int fmt,
-                              const int32_t* skip_if = nullptr);
+                              const int32_t* skip_if = nullptr, bool finish = false);
+static int g2_finish(c12381_ctx* c, size_t n, uint8_t* d_out, int fmt) {
+    int rc;
+    const size_t stride = round_up(n, 64);
+    if ((rc = ensure(c, c12381_ctx::WS_PREF, (size_t)2 * NL * stride * 4))) return rc;
+    size_t T = round_up((n + FINISH_M - 1) / FINISH_M, 64);
+    if (T > n) T = n;
+    hipLaunchKernelGGL(g2_finish_kernel, dim3(grid_for(T)), dim3(BLOCK), 0, c->stream, n, (const int32_t*)c->ws[c12381_ctx::WS_PROJ], stride,
+                       (int32_t*)c->ws[c12381_ctx::WS_PREF], d_out, fmt, T);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
 int c12381_g2_mul_batch_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
-    return g2_mul_dev_strided(c, n, pts, 192, sc, out, fmt);
+    int rc = bind(c); if (rc) return rc;
+    if (!pts || !sc || !out || (fmt != 97 && fmt != 192)) return C12381_E_ARG;
+    if (n == 0) return 0;
+    if ((rc = ensure(c, c12381_ctx::WS_PROJ, (size_t)6 * NL * round_up(n, 64) * 4))) return rc;
+    if ((rc = g2_mul_dev_strided(c, n, pts, 192, sc, out, fmt, nullptr, true))) return rc;
+    return g2_finish(c, n, out, fmt);
 }
 static int g2_mul_dev_strided(c12381_ctx* c, size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* sc, uint8_t* out, int fmt,
-                              const int32_t* skip_if) {
+                              const int32_t* skip_if, bool finish) {
     int rc = bind(c); if (rc) return rc;
     if (!pts || !sc || !out || (fmt != 97 && fmt != 192)) return C12381_E_ARG;
     if (n == 0) return 0;
     const size_t chunk = n < G2_CHUNK ? round_up(n, 64) : G2_CHUNK;
     if ((rc = ensure(c, c12381_ctx::WS_TAB, (size_t)G2_TAB_DWORDS * chunk * 4))) return rc;
+    int32_t* proj = finish ? (int32_t*)c->ws[c12381_ctx::WS_PROJ] : nullptr;
     for (size_t off = 0; off < n; off += chunk) {
         const size_t m = n - off < chunk ? n - off : chunk;
         timed tm(c, 2);
         hipLaunchKernelGGL(g2_mul_kernel, dim3(grid_for(m)), dim3(BLOCK), 0, c->stream, m, pts + pt_stride * off, pt_stride, sc + 32 * off,
-                           (int32_t*)c->ws[c12381_ctx::WS_TAB], chunk, out + (size_t)fmt * off, fmt, c->d_flag, skip_if);
+                           (int32_t*)c->ws[c12381_ctx::WS_TAB], chunk, out + (size_t)fmt * off, fmt, c->d_flag, skip_if, proj, round_up(n, 64), off);
         HIPCK(c, hipGetLastError());
     }
     return 0;
@@ -941,13 +960,17 @@ int c12381_g2_mul_fixed_batch_dev(c12381_ctx* c, size_t n, const uint8_t* base19
     if (!base192 || !sc || !out || (fmt != 97 && fmt != 192)) return C12381_E_ARG;
     if (n == 0) return 0;
     const int32_t* skip = nullptr;
+    const size_t stride = round_up(n, 64);
+    if ((rc = ensure(c, c12381_ctx::WS_PROJ, (size_t)6 * NL * stride * 4))) return rc;
     if (fixed_base_enabled()) {
         if ((rc = fixed_table(c, c12381_ctx::WS_FB_G2, base192, true))) return rc;
         skip = (const int32_t*)c->ws[c12381_ctx::WS_FB_G2];
-        hipLaunchKernelGGL(g2_fixed_eval_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, skip, sc, (const uint8_t*)nullptr, out, fmt, c->d_flag);
+        hipLaunchKernelGGL(g2_fixed_eval_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, skip, sc, (const uint8_t*)nullptr, out, fmt, c->d_flag,
+                           (int32_t*)c->ws[c12381_ctx::WS_PROJ], stride);
         HIPCK(c, hipGetLastError());
     }
-    return g2_mul_dev_strided(c, n, base192, 0, sc, out, fmt, skip);
+    if ((rc = g2_mul_dev_strided(c, n, base192, 0, sc, out, fmt, skip, true))) return rc;      // exactly one of the two kernels fills WS_PROJ
+    return g2_finish(c, n, out, fmt);
 }
 int c12381_g2_mul_fixed_batch(c12381_ctx* c, size_t n, const uint8_t* base192, const uint8_t* sc, uint8_t* out, int fmt) {
     int rc = bind(c); if (rc) return rc;
@@ -1034,7 +1057,7 @@ int c12381_bbs_plus_verify_batch_dev(c12381_ctx* c, size_t n, size_t nmsg, const
     if (fb && !fq) {
         if ((rc = fixed_table(c, c12381_ctx::WS_FB_G2, g2_192, true))) return rc;
         skip_g2 = (const int32_t*)c->ws[c12381_ctx::WS_FB_G2];
-        hipLaunchKernelGGL(g2_fixed_eval_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, skip_g2, x_32, w_192, d_q, 192, c->d_flag);
+        hipLaunchKernelGGL(g2_fixed_eval_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, skip_g2, x_32, w_192, d_q, 192, c->d_flag, (int32_t*)nullptr, (size_t)0);
         HIPCK(c, hipGetLastError());
     }
     if ((rc = g2_mul_dev_strided(c, n, g2_192, 0, x_32, d_b, 192, fq ? gate_generic : skip_g2))) return rc;

@@ -84,10 +84,10 @@ __global__ void __launch_bounds__(BLOCK, 2) g2_fixed_table_kernel(const uint8_t*
     fb_store_g2(buf + FB_HEADER_DWORDS + L * FB_G2_DWORDS, ax, ay);
 }
 
-// out[i] = addend + [k_i]Q (affine, canonical 192 B or 97 B); addend = one broadcast 192-byte point or nullptr.
-// Does nothing when the table is not valid.
+// out[i] = addend + [k_i]Q (affine, canonical 192 B or 97 B — or projective SoA for g2_finish_kernel when proj is given);
+// addend = one broadcast 192-byte point or nullptr.  Does nothing when the table is not valid.
 __global__ void __launch_bounds__(BLOCK, 2) g2_fixed_eval_kernel(size_t n, const int32_t* buf, const uint8_t* scalars, const uint8_t* addend192,
-                                                              uint8_t* out, int fmt, int* bad_flag) {
+                                                              uint8_t* out, int fmt, int* bad_flag, int32_t* proj, size_t proj_stride) {
     if (buf[HDR_VALID] == 0) return;
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -108,7 +108,8 @@ __global__ void __launch_bounds__(BLOCK, 2) g2_fixed_eval_kernel(size_t n, const
         g2_norm1(acc, acc);
         g2_add(acc, w);
     }
-    g2_store_affine(out + (size_t)fmt * i, acc, fmt, !wok);
+    if (proj) g2_store_proj(proj, proj_stride, i, acc, !wok);                // kernel-uniform: affine conversion by g2_finish_kernel
+    else g2_store_affine(out + (size_t)fmt * i, acc, fmt, !wok);
 }
 
 }  // namespace c12381

@@ -12,7 +12,8 @@ using namespace c12381;
 namespace c12381 {
 
 __global__ void __launch_bounds__(BLOCK, 2) g2_mul_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab,
-                                                       size_t tab_stride, uint8_t* out, int fmt, int* bad_flag, const int32_t* skip_if) {
+                                                       size_t tab_stride, uint8_t* out, int fmt, int* bad_flag, const int32_t* skip_if,
+                                                       int32_t* proj, size_t proj_stride, size_t proj_off) {
     if (skip_if && skip_if[HDR_VALID] != 0) return;          // served by a valid fixed-base table (k_fixed.hip)
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -25,7 +26,49 @@ __global__ void __launch_bounds__(BLOCK, 2) g2_mul_kernel(size_t n, const uint8_
     g2p acc;
     g2_scalar_mul(acc, qx, qy, inf || !ok, k, tab + i * (size_t)G2_TAB_DWORDS);
     if (!ok) *bad_flag = 1;
-    g2_store_affine(out + (size_t)fmt * i, acc, fmt, !ok);
+    if (proj) g2_store_proj(proj, proj_stride, proj_off + i, acc, !ok);      // kernel-uniform: affine conversion by g2_finish_kernel
+    else g2_store_affine(out + (size_t)fmt * i, acc, fmt, !ok);
+}
+
+// Simultaneous inversion (Montgomery's trick in Fp2) + affine + encode, as g1_finish_kernel: lane t owns elements
+// t, t + T, t + 2T, ... — one Fp2 inversion per lane instead of one per element (an inversion is ~11 % of a G2
+// scalar multiplication).  X = 1, Z = 0 marks an invalid input (all-0xff output), X = 0, Z = 0 is infinity.
+__global__ void __launch_bounds__(BLOCK, 2) g2_finish_kernel(size_t n, const int32_t* proj, size_t stride, int32_t* pref, uint8_t* out, int fmt, size_t T) {
+    const size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= T || t >= n) return;
+    const int32_t* zbase = proj + (size_t)4 * NL * stride;
+    fp2 run, one;
+    fp2_one(one);
+    run = one;
+    size_t last = t;
+#pragma unroll 1
+    for (size_t e = t; e < n; e += T) {
+        fp2 z;
+        soa_load_fp2(z, zbase, stride, e);
+        const bool inf = fp2_is_zero(z);
+        fp2_select(z, inf, one, z);
+        fp2_mul(run, run, z);
+        soa_store_fp2(pref, stride, e, run);
+        last = e;
+    }
+    fp2 inv;
+    fp2_inv(inv, run);
+#pragma unroll 1
+    for (size_t e = last;; e -= T) {
+        g2p p;
+        soa_load_g2(p, proj, stride, e);
+        const bool inf = fp2_is_zero(p.z);
+        const bool invalid = inf && !fp2_is_zero(p.x);
+        fp2_select(p.z, inf, one, p.z);
+        fp2 prev, zinv, ax, ay, ninv;
+        if (e >= T + t) soa_load_fp2(prev, pref, stride, e - T); else prev = one;
+        fp2_mul(zinv, inv, prev);
+        fp2_mul(ninv, inv, p.z);
+        inv = ninv;
+        fp2_mul(ax, p.x, zinv); fp2_mul(ay, p.y, zinv);
+        g2_store_xy(out + (size_t)fmt * e, ax, ay, fmt, inf, invalid);
+        if (e < T + t) break;
+    }
 }
 
 __global__ void __launch_bounds__(BLOCK, 2) g2_add_kernel(size_t n, const uint8_t* a, size_t a_stride, const uint8_t* b, uint8_t* out, int fmt,

@@ -42,7 +42,8 @@ __global__ void __launch_bounds__(BLOCK, 2) msm_overflow_combine_kernel(const ui
 __global__ void __launch_bounds__(BLOCK, 2) msm_wreduce_kernel(int W, uint32_t nb, uint32_t chunks, const int32_t* bk, int32_t* out, size_t out_stride);
 __global__ void __launch_bounds__(BLOCK, 2) g1_decompress_kernel(size_t n, const uint8_t* in, uint8_t* out, uint8_t* status);
 __global__ void __launch_bounds__(64, 1) msm_horner_kernel(const int32_t* rw, size_t stride, int W, int c, int32_t* out, size_t out_stride);
-__global__ void __launch_bounds__(BLOCK, 2) g2_mul_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab, size_t tab_stride, uint8_t* out, int fmt, int* bad_flag, const int32_t* skip_if);
+__global__ void __launch_bounds__(BLOCK, 2) g2_mul_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab, size_t tab_stride, uint8_t* out, int fmt, int* bad_flag, const int32_t* skip_if, int32_t* proj, size_t proj_stride, size_t proj_off);
+__global__ void __launch_bounds__(BLOCK, 2) g2_finish_kernel(size_t n, const int32_t* proj, size_t stride, int32_t* pref, uint8_t* out, int fmt, size_t T);
 __global__ void __launch_bounds__(BLOCK, 2) g2_add_kernel(size_t n, const uint8_t* a, size_t a_stride, const uint8_t* b, uint8_t* out, int fmt, int* bad_flag, const int32_t* skip_if);
 __global__ void __launch_bounds__(BLOCK, 2) pair_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) pair_eq_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, size_t b2_stride, uint8_t* out, int* bad_flag);
@@ -72,6 +73,6 @@ __global__ void __launch_bounds__(64, 1) fixed_cache_check_kernel(const uint8_t*
 __global__ void __launch_bounds__(BLOCK, 2) g1_fixed_table_kernel(const uint8_t* base96, int32_t* buf);
 __global__ void __launch_bounds__(BLOCK, 2) g1_fixed_eval_kernel(size_t n, const int32_t* buf, const uint8_t* scalars, int32_t* proj, size_t proj_stride, size_t proj_off);
 __global__ void __launch_bounds__(BLOCK, 2) g2_fixed_table_kernel(const uint8_t* base192, int32_t* buf);
-__global__ void __launch_bounds__(BLOCK, 2) g2_fixed_eval_kernel(size_t n, const int32_t* buf, const uint8_t* scalars, const uint8_t* addend192, uint8_t* out, int fmt, int* bad_flag);
+__global__ void __launch_bounds__(BLOCK, 2) g2_fixed_eval_kernel(size_t n, const int32_t* buf, const uint8_t* scalars, const uint8_t* addend192, uint8_t* out, int fmt, int* bad_flag, int32_t* proj, size_t proj_stride);
 
 }  // namespace c12381

@@ -75,15 +75,8 @@ __device__ __forceinline__ void g2_parse192(fp2& x, fp2& y, bool& inf, bool& ok,
     fp2_load_raw96(x, p); fp2_load_raw96(y, p + 96);
     ok = inf || g2_on_curve(x, y);
 }
-// affine + canonical encoding of one projective G2 point (per-lane inversion)
-__device__ __noinline__ void g2_store_affine(uint8_t* o, const g2p& acc, int fmt, bool invalid) {
-    const bool inf = fp2_is_zero(acc.z);
-    fp2 zn, zi, ax, ay, one;
-    fp2_one(one);
-    fp2_norm1(zn, acc.z);
-    fp2_select(zn, inf, one, zn);
-    fp2_inv(zi, zn);
-    fp2_mul(ax, acc.x, zi); fp2_mul(ay, acc.y, zi);
+// canonical encoding of one affine G2 point (or the infinity / invalid patterns)
+__device__ __noinline__ void g2_store_xy(uint8_t* o, const fp2& ax, const fp2& ay, int fmt, bool inf, bool invalid) {
     if (inf || invalid) {
         const uint32_t fill = invalid ? 0xffffffffu : 0u;
         if (fmt == 192) { uint4* q = reinterpret_cast<uint4*>(o); for (int i = 0; i < 12; ++i) q[i] = make_uint4(fill, fill, fill, fill); }
@@ -97,6 +90,24 @@ __device__ __noinline__ void g2_store_affine(uint8_t* o, const g2p& acc, int fmt
         fp_to_raw48(raw, ax.b); fp_to_raw48(raw + 12, ax.a);
         for (int j = 0; j < 24; ++j) { const uint32_t v = raw[j]; o[1 + 4 * j] = (uint8_t)v; o[2 + 4 * j] = (uint8_t)(v >> 8); o[3 + 4 * j] = (uint8_t)(v >> 16); o[4 + 4 * j] = (uint8_t)(v >> 24); }
     }
+}
+// affine + canonical encoding of one projective G2 point (per-lane inversion; the batch entry points use g2_finish_kernel)
+__device__ __noinline__ void g2_store_affine(uint8_t* o, const g2p& acc, int fmt, bool invalid) {
+    const bool inf = fp2_is_zero(acc.z);
+    fp2 zn, zi, ax, ay, one;
+    fp2_one(one);
+    fp2_norm1(zn, acc.z);
+    fp2_select(zn, inf, one, zn);
+    fp2_inv(zi, zn);
+    fp2_mul(ax, acc.x, zi); fp2_mul(ay, acc.y, zi);
+    g2_store_xy(o, ax, ay, fmt, inf, invalid);
+}
+// result of one lane for g2_finish_kernel: projective SoA; an invalid input is marked X = 1, Y = Z = 0
+__device__ __forceinline__ void g2_store_proj(int32_t* proj, size_t stride, size_t i, const g2p& acc, bool invalid) {
+    g2p o;
+    g2_norm1(o, acc);
+    if (invalid) { fp2_one(o.x); fp2_zero(o.y); fp2_zero(o.z); }
+    soa_store_g2(proj, stride, i, o);
 }
 __device__ __forceinline__ void gt_store576(uint8_t* o, const fp12& f, bool invalid) {
 #pragma unroll 1
