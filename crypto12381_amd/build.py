@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-UNITS = ["c12381_hip.hip", "k_g1.hip", "k_g2gt.hip", "k_pair3.hip", "k_hash_zp.hip", "k_fixed.hip"]
+UNITS = ["c12381_hip.hip", "k_g1.hip", "k_g2gt.hip", "k_g2h.hip", "k_pair3.hip", "k_hash_zp.hip", "k_fixed.hip"]
 LIB = os.path.join(HERE, "lib", "libc12381_hip.so")
 OBJ = os.path.join(HERE, "lib", "obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -510,11 +510,21 @@ static int g2_mul_dev_strided(c12381_ctx* c, size_t n, const uint8_t* pts, size_
     if (!pts || !sc || !out || (fmt != 97 && fmt != 192)) return C12381_E_ARG;
     if (n == 0) return 0;
     const size_t chunk = n < G2_CHUNK ? round_up(n, 64) : G2_CHUNK;
-    if ((rc = ensure(c, c12381_ctx::WS_TAB, (size_t)G2_TAB_DWORDS * chunk * 4))) return rc;
+    // C12381_G2_LANES=1 keeps the one-lane-per-point kernel for the batch entry points (A/B measurements); default:
+    // two lanes per point (k_g2h.hip), whose per-lane table records are those of G1 (2 x 1408 B per point)
+    static const bool two_lanes = [] { const char* e = std::getenv("C12381_G2_LANES"); return !(e && e[0] == '1'); }();
+    const bool pairwise = finish && two_lanes;
+    if ((rc = ensure(c, c12381_ctx::WS_TAB, (size_t)(pairwise ? 2 * G2_TAB * G1_ENT_DWORDS : G2_TAB_DWORDS) * chunk * 4))) return rc;
     int32_t* proj = finish ? (int32_t*)c->ws[c12381_ctx::WS_PROJ] : nullptr;
     for (size_t off = 0; off < n; off += chunk) {
         const size_t m = n - off < chunk ? n - off : chunk;
         timed tm(c, 2);
+        if (pairwise) {
+            hipLaunchKernelGGL(g2_mul2_kernel, dim3(grid_for(2 * m)), dim3(BLOCK), 0, c->stream, m, pts + pt_stride * off, pt_stride, sc + 32 * off,
+                               (int32_t*)c->ws[c12381_ctx::WS_TAB], c->d_flag, skip_if, proj, round_up(n, 64), off);
+            HIPCK(c, hipGetLastError());
+            continue;
+        }
         hipLaunchKernelGGL(g2_mul_kernel, dim3(grid_for(m)), dim3(BLOCK), 0, c->stream, m, pts + pt_stride * off, pt_stride, sc + 32 * off,
                            (int32_t*)c->ws[c12381_ctx::WS_TAB], chunk, out + (size_t)fmt * off, fmt, c->d_flag, skip_if, proj, round_up(n, 64), off);
         HIPCK(c, hipGetLastError());

@@ -9,17 +9,21 @@
 
 namespace c12381 {
 
-struct g2p { fp2 x, y, z; };     // (X:Y:Z), infinity = (0:1:0)
+// The point arithmetic below is written once for two element types: fp2 (one point per lane) and fp2h (fp2h.hpp: HALF an
+// Fp2 element per lane, two adjacent lanes per point — 42 dwords per point and lane instead of 84, so the complete
+// addition fits the register file).  Both provide the same fp2_* operations.
+template <class F> struct g2pt { F x, y, z; };     // (X:Y:Z), infinity = (0:1:0)
+using g2p = g2pt<fp2>;
 
-C12381_HD void g2_set_inf(g2p& p) { fp2_zero(p.x); fp2_one(p.y); fp2_zero(p.z); }
-C12381_HD void g2_norm1(g2p& r, const g2p& p) { fp2_norm1(r.x, p.x); fp2_norm1(r.y, p.y); fp2_norm1(r.z, p.z); }
-C12381_HD void g2_neg(g2p& r, const g2p& p) { r.x = p.x; fp2_neg(r.y, p.y); r.z = p.z; }
+template <class F> C12381_HD void g2_set_inf(g2pt<F>& p) { fp2_zero(p.x); fp2_one(p.y); fp2_zero(p.z); }
+template <class F> C12381_HD void g2_norm1(g2pt<F>& r, const g2pt<F>& p) { fp2_norm1(r.x, p.x); fp2_norm1(r.y, p.y); fp2_norm1(r.z, p.z); }
+template <class F> C12381_HD void g2_neg(g2pt<F>& r, const g2pt<F>& p) { r.x = p.x; fp2_neg(r.y, p.y); r.z = p.z; }
 // 3b' = 12 (1 + i): small multiply (normalising) then the lazy (1+i) map — ecp2_BLS12381.cpp:381-385
-C12381_HD void fp2_mul_b3(fp2& r, const fp2& x) { fp2 t; fp2_mul_small(t, x, 12); fp2_mul_ip(r, t); }
+template <class F> C12381_HD void fp2_mul_b3(F& r, const F& x) { F t; fp2_mul_small(t, x, 12); fp2_mul_ip(r, t); }
 
 // ECP2_dbl :358-409.  Also returns t0 = Y^2, t1 = Y*Z, t2b = 3b' Z^2 for the Miller-loop line.
-C12381_HD void g2_dbl_core(g2p& p, fp2& t0, fp2& t1, fp2& t2b) {
-    fp2 t2, x3, y3, z3, u;
+template <class F> C12381_HD void g2_dbl_core(g2pt<F>& p, F& t0, F& t1, F& t2b) {
+    F t2, x3, y3, z3, u;
     fp2_sqr(t0, p.y);
     fp2_mul(t1, p.y, p.z);
     fp2_sqr(t2, p.z);
@@ -33,25 +37,25 @@ C12381_HD void g2_dbl_core(g2p& p, fp2& t0, fp2& t1, fp2& t2b) {
     fp2_norm1(u, u);
     fp2_mul(y3, u, y3);
     fp2_add(y3, y3, x3);
-    fp2 xy;
+    F xy;
     fp2_mul(xy, p.x, p.y);
     fp2_mul(x3, u, xy);
     fp2_dbl(x3, x3);
     p.x = x3; p.y = y3; p.z = z3;
 }
-C12381_HDN void g2_dbl_ex(g2p& p, fp2& t0, fp2& t1, fp2& t2b) { g2_dbl_core(p, t0, t1, t2b); }
-C12381_HDN void g2_dbl(g2p& p) { fp2 a, b, c; g2_dbl_core(p, a, b, c); }
+template <class F> C12381_HDN void g2_dbl_ex(g2pt<F>& p, F& t0, F& t1, F& t2b) { g2_dbl_core(p, t0, t1, t2b); }
+template <class F> C12381_HDN void g2_dbl(g2pt<F>& p) { F a, b, c; g2_dbl_core(p, a, b, c); }
 // n successive doublings with the point held in registers (one load and one store of the 84 dwords per call)
-C12381_HDN void g2_dbl_n(g2p& p, int n) {
-    g2p q = p;
+template <class F> C12381_HDN void g2_dbl_n(g2pt<F>& p, int n) {
+    g2pt<F> q = p;
 #pragma unroll 1
-    for (int i = 0; i < n; ++i) { fp2 a, b, c; g2_dbl_core(q, a, b, c); }
+    for (int i = 0; i < n; ++i) { F a, b, c; g2_dbl_core(q, a, b, c); }
     p = q;
 }
 
 // ECP2_add :413-502 (complete).  P limb bound <= 2^29, Q normalised.
-C12381_HDN void g2_add(g2p& p, const g2p& q) {
-    fp2 t0, t1, t2, t3, t4, x3, y3, z3;
+template <class F> C12381_HDN void g2_add(g2pt<F>& p, const g2pt<F>& q) {
+    F t0, t1, t2, t3, t4, x3, y3, z3;
     fp2_mul(t0, p.x, q.x);
     fp2_mul(t1, p.y, q.y);
     fp2_mul(t2, p.z, q.z);
@@ -96,6 +100,7 @@ constexpr int G2_WIN = 4;
 constexpr int G2_TAB = 8;                               // entries 1..8 (signed digits)
 constexpr int G2_ENT_DWORDS = 6 * NL;                   // 84 dwords = 21 16-byte accesses
 constexpr int G2_TAB_DWORDS = G2_TAB * G2_ENT_DWORDS;   // 672 dwords per lane
+C12381_HD constexpr int g2_ent_dwords(const g2p&) { return G2_ENT_DWORDS; }
 
 C12381_HD void tab_store_g2(int32_t* ent, const g2p& p) {
     const fp* c[6] = {&p.x.a, &p.x.b, &p.y.a, &p.y.b, &p.z.a, &p.z.b};
@@ -125,8 +130,8 @@ C12381_HD void tab_load_g2(g2p& p, const int32_t* ent) {
 // psi^I(X,Y,Z) = (conj^I(X) c_x, conj^I(Y) c_y, conj^I(Z))   (ECP2_frob ecp2_BLS12381.cpp:579-590 applied I times with
 // X = 1/f as PAIR_G2mul does for the M-type twist, pair_BLS12381.cpp:944-947).  psi is a group homomorphism of the
 // twist, so psi^I(d Q) = d psi^I(Q): one table of multiples of Q serves all four sub-scalars.
-template <int I>
-C12381_HD void g2_psi(g2p& r, const g2p& p) {
+template <int I, class F>
+C12381_HD void g2_psi(g2pt<F>& r, const g2pt<F>& p) {
     if (I == 0) { r = p; return; }
     if (I == 2) {
         fp cx, cy;
@@ -134,7 +139,7 @@ C12381_HD void g2_psi(g2p& r, const g2p& p) {
         fp2_mul_fp(r.x, p.x, cx); fp2_mul_fp(r.y, p.y, cy); r.z = p.z;
         return;
     }
-    fp2 cx, cy, t;
+    F cx, cy, t;
     if (I == 1) { fp2_set_const(cx, PSI1_X_A, PSI1_X_B); fp2_set_const(cy, PSI1_Y_A, PSI1_Y_B); }
     else { fp2_set_const(cx, PSI3_X_A, PSI3_X_B); fp2_set_const(cy, PSI3_Y_A, PSI3_Y_B); }
     fp2_conj(t, p.x); fp2_mul(r.x, t, cx);
@@ -178,15 +183,15 @@ C12381_HD void gs_bias(uint32_t (&ub)[3], const uint32_t (&u)[2]) {
     c += (uint64_t)u[1] + 0x88888888u; ub[1] = (uint32_t)c; ub[2] = (uint32_t)(c >> 32);
 }
 // acc += (-1)^I sign(d) psi^I(T[|d|])
-template <int I>
-C12381_HD void g2_add_digit(g2p& acc, const int32_t* lane_tab, int d) {
+template <int I, class F>
+C12381_HD void g2_add_digit(g2pt<F>& acc, const int32_t* lane_tab, int d) {
     const int mag = d < 0 ? -d : d;
     const int idx = mag == 0 ? 1 : mag;
-    g2p q, e, inf;
-    tab_load_g2(q, lane_tab + (idx - 1) * G2_ENT_DWORDS);
+    g2pt<F> q, e, inf;
+    tab_load_g2(q, lane_tab + (idx - 1) * g2_ent_dwords(q));
     g2_psi<I>(e, q);
     const bool negate = (d < 0) != ((I & 1) != 0);
-    fp2 ny;
+    F ny;
     fp2_neg(ny, e.y);
     fp2_select(e.y, negate, ny, e.y);
     g2_set_inf(inf);
@@ -195,10 +200,10 @@ C12381_HD void g2_add_digit(g2p& acc, const int32_t* lane_tab, int d) {
     g2_add(acc, e);
 }
 
-C12381_HD bool g2_is_inf(const g2p& p) { return fp2_is_zero(p.z); }
+template <class F> C12381_HD bool g2_is_inf(const g2pt<F>& p) { return fp2_is_zero(p.z); }
 // p <- [|x|]p, plain double-and-add over the 64-bit curve parameter
-C12381_HDN void g2_mul_absx(g2p& p) {
-    g2p base, acc;
+template <class F> C12381_HDN void g2_mul_absx(g2pt<F>& p) {
+    g2pt<F> base, acc;
     g2_norm1(base, p);
     acc = base;
 #pragma unroll 1
@@ -213,8 +218,8 @@ C12381_HDN void g2_mul_absx(g2p& p) {
 // infinity for Q in G2, a point of the cofactor part otherwise.  Reproduced here (lanes with u1 == 0 or u3 == 0 only,
 // a divergent branch) so results agree with `multiply` on every point of the twist.
 // Q is in G2 iff psi(Q) = [x]Q = -[|x|]Q; off the subgroup [r]Q = [x^4]Q - [x^2]Q + Q and [r]psi^i(Q) = psi^i([r]Q).
-C12381_HDN void g2_gs_zero_digit_terms(g2p& acc, const g2p& base, bool z1, bool z3) {
-    g2p q, a1, a2, a4, t;
+template <class F> C12381_HDN void g2_gs_zero_digit_terms(g2pt<F>& acc, const g2pt<F>& base, bool z1, bool z3) {
+    g2pt<F> q, a1, a2, a4, t;
     g2_norm1(q, base);
     a1 = q;
     g2_mul_absx(a1);
@@ -222,7 +227,7 @@ C12381_HDN void g2_gs_zero_digit_terms(g2p& acc, const g2p& base, bool z1, bool 
     g2_psi<1>(t, q);
     g2_norm1(t, t);
     {
-        g2p u = a1;
+        g2pt<F> u = a1;
         g2_add(u, t);
         if (g2_is_inf(u)) return;                  // Q in G2: the extra terms vanish
     }
@@ -245,7 +250,7 @@ C12381_HDN void g2_gs_zero_digit_terms(g2p& acc, const g2p& base, bool z1, bool 
 // PAIR_G2mul pair_BLS12381.cpp:927-983: R = u0 Q - u1 psi(Q) + u2 psi^2(Q) - u3 psi^3(Q) for the base-|x| digits of
 // k mod r — exactly what the reference evaluates (ECP2_mul4 after gs() and the sign minimisation), on ANY point of
 // the twist; for Q in G2 it equals [k]Q.  64 doublings + 68 additions on one 8-entry table of multiples of Q.
-C12381_HDN void g2_scalar_mul(g2p& acc, const fp2& qx, const fp2& qy, bool q_is_inf, const uint32_t (&kin)[8], int32_t* lane_tab) {
+template <class F> C12381_HDN void g2_scalar_mul(g2pt<F>& acc, const F& qx, const F& qy, bool q_is_inf, const uint32_t (&kin)[8], int32_t* lane_tab) {
     uint32_t k[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) k[i] = kin[i];
@@ -254,7 +259,7 @@ C12381_HDN void g2_scalar_mul(g2p& acc, const fp2& qx, const fp2& qy, bool q_is_
     scalar_gs_split(u, k);
 #pragma unroll
     for (int i = 0; i < 4; ++i) gs_bias(ub[i], u[i]);
-    g2p base, t;
+    g2pt<F> base, t;
     g2_set_inf(t);
     base.x = qx; base.y = qy; fp2_one(base.z);
     fp2_select(base.x, q_is_inf, t.x, base.x);
@@ -264,17 +269,17 @@ C12381_HDN void g2_scalar_mul(g2p& acc, const fp2& qx, const fp2& qy, bool q_is_
     t = base;
     g2_dbl(t);
     {
-        g2p n;
+        g2pt<F> n;
         g2_norm1(n, t);
-        tab_store_g2(lane_tab + G2_ENT_DWORDS, n);
+        tab_store_g2(lane_tab + g2_ent_dwords(n), n);
         t = n;
     }
 #pragma unroll 1
     for (int j = 3; j <= G2_TAB; ++j) {
         g2_add(t, base);
-        g2p n;
+        g2pt<F> n;
         g2_norm1(n, t);
-        tab_store_g2(lane_tab + (j - 1) * G2_ENT_DWORDS, n);
+        tab_store_g2(lane_tab + (j - 1) * g2_ent_dwords(n), n);
         t = n;
     }
     g2_set_inf(acc);

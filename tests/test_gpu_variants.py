@@ -1,5 +1,6 @@
 """GPU parity of the code paths that are selected through the environment (A/B switches kept for measurements):
-the one-lane pairing kernels, the forced naive / bucket MSM, the generic path behind the fixed-base entry points.
+the one-lane pairing kernels, the forced naive / bucket MSM, the generic path behind the fixed-base entry points, the
+one-lane-per-point G2 kernel.
 Each variant runs in a child process (the switches are read once per process) against the golden vectors."""
 import os
 import subprocess
@@ -32,14 +33,17 @@ g2 = golden('g2')
 gen2 = bytes.fromhex(g2['generator'])
 sc2 = cat(g2['scalars'])
 assert c.g2_mul_fixed(gen2, sc2, 192) == c.g2_mul(gen2 * (len(sc2) // 32), sc2, 192)
+assert c.g2_mul(cat(g2['points']), sc2, 97) == cat(g2['mul97'])
+assert c.g2_mul(cat(g2['offsubgroup_points']), cat(g2['offsubgroup_scalars']), 192) == cat(g2['offsubgroup_mul192'])
+assert c.g2_mul(cat(g2['offsubgroup_small_points']), cat(g2['offsubgroup_small_scalars']), 192) == cat(g2['offsubgroup_small_mul192'])
 c.close()
 print('variant ok')
 """
 
 
 @pytest.mark.parametrize("env", [{"C12381_PAIR_LANES": "1"}, {"C12381_MSM": "naive"}, {"C12381_MSM": "bucket"}, {"C12381_FIXED_BASE": "0"},
-                                 {"C12381_PAIR_QUEUE": "1"}, {"C12381_PAIR_QUEUE": "0"}],
-                         ids=["one-lane-pairing", "msm-naive", "msm-bucket", "fixed-base-off", "pair-queue-on", "pair-queue-off"])
+                                 {"C12381_PAIR_QUEUE": "1"}, {"C12381_PAIR_QUEUE": "0"}, {"C12381_G2_LANES": "1"}, {}],
+                         ids=["one-lane-pairing", "msm-naive", "msm-bucket", "fixed-base-off", "pair-queue-on", "pair-queue-off", "g2-one-lane", "defaults"])
 def test_environment_selected_paths(env):
     e = dict(os.environ)
     e.update(env)
