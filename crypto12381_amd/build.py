@@ -18,11 +18,13 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # call site carries a `tail` marker (which every call passing only non-stack pointers gets); without the marker the
 # big out-of-line field routines do not save ~65 callee-saved VGPRs in their prologues (130 scratch instructions a call)
 # -fno-optimize-sibling-calls: a `tail` call marker costs an internal routine its "callee saves nothing" treatment.
-# max-ilp scheduling with the GCN register-pressure trackers: every kernel here runs at a FIXED occupancy (launch bounds:
-# 2 waves per SIMD), so the default strategy's effort to raise occupancy buys nothing, while scheduling for ILP shortens the
-# dependent multiply-add chains (A/B on MI355X, tools/ab_all.sh: G1 kernel 3.62 -> 3.52 ms, pairing 23.0 -> 22.3 ms).
+# max-ilp scheduling: every kernel here runs at a FIXED occupancy (launch bounds: 2 waves per SIMD), so the default strategy's
+# effort to raise occupancy buys nothing, while scheduling for ILP shortens the dependent multiply-add chains (A/B on MI355X,
+# tools/ab_all.sh: pairing kernel 22.8 -> 22.1 ms).  NOT combined with -amdgpu-use-amdgpu-trackers=1: that (experimental)
+# option gained another 1 %, but together with max-ilp an experimental variant of the pairing routines (Fp4 squarings as
+# calls) returned wrong values for a few lanes of a full-size batch while passing every small test — not worth the risk.
 CFLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-fno-optimize-sibling-calls",
-          "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-amdgpu-use-amdgpu-trackers=1"]
+          "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 
 
 def _headers():

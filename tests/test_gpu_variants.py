@@ -49,3 +49,50 @@ def test_environment_selected_paths(env):
     e.update(env)
     r = subprocess.run([sys.executable, "-c", CODE], env=e, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "variant ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+DIGEST_CODE = r"""
+import hashlib, sys
+sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+from util import golden, scalars
+from crypto12381_amd import Context
+c = Context(0)
+g1 = bytes.fromhex(golden('g1')['generator'])
+g2 = bytes.fromhex(golden('g2')['generator'])
+m = 1 << 12
+P = c.g1_mul(g1 * m, scalars(981, m), 96)
+Q = c.g2_mul(g2 * m, scalars(982, m), 192)
+n = 1 << 16
+Pn = P * (n // m)
+Qn = b"".join(Q[192 * ((5 * i + i // m) % m):192 * ((5 * i + i // m) % m) + 192] for i in range(n))
+print('pair', hashlib.sha256(c.pair(Pn, Qn)).hexdigest())
+print('pair_eq', hashlib.sha256(c.pair_eq(Pn, Qn, Pn[96:] + Pn[:96], Qn)).hexdigest())
+n2 = 1 << 15
+print('g2_mul', hashlib.sha256(c.g2_mul(Q * (n2 // m), scalars(983, n2, 1 << 256), 192)).hexdigest())
+n1 = 1 << 18
+sc = scalars(984, n1, 1 << 256)
+print('g1_fixed', hashlib.sha256(c.g1_mul_fixed(P[:96], sc, 96)).hexdigest())
+print('g1_mul', hashlib.sha256(c.g1_mul(P[:96] * n1, sc, 96)).hexdigest())
+c.close()
+"""
+
+
+def test_full_size_digests_across_implementations():
+    """EVERY output of full-size batches, compared between independent kernels for the same operation (digests computed in
+    child processes, the switches being per process): three-lane work-queue pairing vs the plain grid vs the one-lane
+    kernel, two-lane vs one-lane G2 multiplication, table-driven vs generic G1 multiplication.  The sampled-lane
+    comparisons against the CPU oracle (test_gpu_full_size.py, test_gpu_pairing.py) cannot see a fault that hits a few
+    lanes of a loaded machine; this can."""
+    def run(env):
+        e = dict(os.environ)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", DIGEST_CODE], env=e, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        return dict(line.split() for line in r.stdout.strip().splitlines() if " " in line)
+
+    base = run({})
+    assert base["g1_fixed"] == base["g1_mul"]                      # table-driven == generic, all 2^18 outputs
+    one = run({"C12381_PAIR_LANES": "1", "C12381_G2_LANES": "1", "C12381_FIXED_BASE": "0"})
+    assert one == base
+    plain = run({"C12381_PAIR_QUEUE": "0"})
+    assert plain["pair"] == base["pair"] and plain["pair_eq"] == base["pair_eq"]
