@@ -409,9 +409,9 @@ int c12381_g1_add_batch(c12381_ctx* c, size_t n, const uint8_t* a, const uint8_t
     return read_flag(c);
 }
 
-// MSM, round-1 algorithm: n independent GLV scalar multiplications followed by a tree sum of the
-// projective results (the reference's Π is also O(n) full scalar-muls, g1_point.hpp:389-401); only
-// the final point is canonical.  A bucket method is a later optimisation behind the same entry.
+// MSM: the bucket method (g1_msm_pippenger) from 2^12 terms; below that n independent GLV scalar multiplications followed
+// by a tree sum of the projective results (the reference's Π is also n full scalar-muls, g1_point.hpp:389-401) — exact for
+// every input, including the [r]-terms of small scalars on points outside G1.  Only the final point is canonical.
 int c12381_g1_msm_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
     int rc = bind(c); if (rc) return rc;
     if (!out || (n && (!pts || !sc)) || (fmt != 49 && fmt != 96)) return C12381_E_ARG;
