@@ -170,20 +170,21 @@ static int msm_c(size_t n) {
 // Bucket-method MSM (msm.hpp): prep -> radix sort -> bucket sums -> window reduction -> Horner -> affine.
 int g1_msm_pippenger(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
     const int cb = msm_c(n), W = msm_windows(cb);
-    const size_t E = (size_t)2 * n * W, nb = (size_t)1 << cb, nbk = nb * W;
+    // nbk digit buckets + ONE more (index nbk, key W << cb): the points whose scalar is below x^2 (msm.hpp)
+    const size_t E = msm_entries(n, W), nb = (size_t)1 << cb, nbk = nb * W, nbx = nbk + 1;
     int rc;
     if ((rc = ensure(c, c12381_ctx::WS_MSM_PTS, (size_t)2 * n * MSM_PT_DWORDS * 4))) return rc;
     if ((rc = ensure(c, c12381_ctx::WS_MSM_K0, E * 4))) return rc;
     if ((rc = ensure(c, c12381_ctx::WS_MSM_K1, E * 4))) return rc;
     if ((rc = ensure(c, c12381_ctx::WS_MSM_V0, E * 4))) return rc;
     if ((rc = ensure(c, c12381_ctx::WS_MSM_V1, E * 4))) return rc;
-    if ((rc = ensure(c, c12381_ctx::WS_MSM_RNG, (nbk + 1) * 8))) return rc;
-    if ((rc = ensure(c, c12381_ctx::WS_MSM_BK, nbk * G1_ENT_DWORDS * 4))) return rc;
+    if ((rc = ensure(c, c12381_ctx::WS_MSM_RNG, (nbx + 1) * 8))) return rc;
+    if ((rc = ensure(c, c12381_ctx::WS_MSM_BK, nbx * G1_ENT_DWORDS * 4))) return rc;
     int32_t* pts2 = (int32_t*)c->ws[c12381_ctx::WS_MSM_PTS];
     uint32_t *k0 = (uint32_t*)c->ws[c12381_ctx::WS_MSM_K0], *k1 = (uint32_t*)c->ws[c12381_ctx::WS_MSM_K1];
     uint32_t *v0 = (uint32_t*)c->ws[c12381_ctx::WS_MSM_V0], *v1 = (uint32_t*)c->ws[c12381_ctx::WS_MSM_V1];
     uint32_t* lo = (uint32_t*)c->ws[c12381_ctx::WS_MSM_RNG];
-    uint32_t* hi = lo + nbk + 1;
+    uint32_t* hi = lo + nbx + 1;
     int32_t* bk = (int32_t*)c->ws[c12381_ctx::WS_MSM_BK];
     hipLaunchKernelGGL(msm_prep_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, pts, sc, cb, W, pts2, k0, v0, c->d_flag);
     HIPCK(c, hipGetLastError());
@@ -193,19 +194,19 @@ int g1_msm_pippenger(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t*
     HIPCK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k0, k1, v0, v1, (int)E, 0, end_bit, c->stream));
     if ((rc = ensure(c, c12381_ctx::WS_MSM_TMP, tmp_bytes + 256))) return rc;
     HIPCK(c, hipcub::DeviceRadixSort::SortPairs(c->ws[c12381_ctx::WS_MSM_TMP], tmp_bytes, k0, k1, v0, v1, (int)E, 0, end_bit, c->stream));
-    HIPCK(c, hipMemsetAsync(lo, 0, (nbk + 1) * 8, c->stream));
+    HIPCK(c, hipMemsetAsync(lo, 0, (nbx + 1) * 8, c->stream));
     hipLaunchKernelGGL(msm_ranges_kernel, dim3(grid_for(E)), dim3(BLOCK), 0, c->stream, E, k1, lo, hi);
     HIPCK(c, hipGetLastError());
     // buckets in order of decreasing run length (k0 / v0 are free again after the first sort; the sorted size keys go
     // to k1, which the ranges kernel has finished with)
-    const size_t key_cap = E > nbk ? E : nbk;
+    const size_t key_cap = E > nbx ? E : nbx;
     if (key_cap > E) {
         if ((rc = ensure(c, c12381_ctx::WS_MSM_K0, key_cap * 4))) return rc;
         if ((rc = ensure(c, c12381_ctx::WS_MSM_K1, key_cap * 4))) return rc;
         if ((rc = ensure(c, c12381_ctx::WS_MSM_V0, key_cap * 4))) return rc;
         k0 = (uint32_t*)c->ws[c12381_ctx::WS_MSM_K0]; k1 = (uint32_t*)c->ws[c12381_ctx::WS_MSM_K1]; v0 = (uint32_t*)c->ws[c12381_ctx::WS_MSM_V0];
     }
-    if ((rc = ensure(c, c12381_ctx::WS_MSM_ORD, nbk * 4))) return rc;
+    if ((rc = ensure(c, c12381_ctx::WS_MSM_ORD, nbx * 4))) return rc;
     uint32_t* order = (uint32_t*)c->ws[c12381_ctx::WS_MSM_ORD];
     // overflow bookkeeping for runs longer than MSM_RUN_CAP (k_g1.hip): counters | segment list | cut-bucket list | partial sums
     const uint32_t run_cap = msm_run_cap(n, cb);
@@ -218,15 +219,15 @@ int g1_msm_pippenger(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t*
     uint4* ovf_big = (uint4*)(ovf + o_big);
     int32_t* ovf_part = (int32_t*)(ovf + o_part);
     HIPCK(c, hipMemsetAsync(ovf_cnt, 0, 16, c->stream));
-    hipLaunchKernelGGL(msm_sizes_kernel, dim3(grid_for(nbk)), dim3(BLOCK), 0, c->stream, nbk, lo, hi, k0, v0, run_cap, ovf_cnt, ovf_seg, ovf_big);
+    hipLaunchKernelGGL(msm_sizes_kernel, dim3(grid_for(nbx)), dim3(BLOCK), 0, c->stream, nbx, lo, hi, k0, v0, run_cap, ovf_cnt, ovf_seg, ovf_big);
     HIPCK(c, hipGetLastError());
     size_t tmp2 = 0;
-    HIPCK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, k0, k1, v0, order, (int)nbk, 0, 32, c->stream));
+    HIPCK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, k0, k1, v0, order, (int)nbx, 0, 32, c->stream));
     if ((rc = ensure(c, c12381_ctx::WS_MSM_TMP, tmp2 + 256))) return rc;
-    HIPCK(c, hipcub::DeviceRadixSort::SortPairs(c->ws[c12381_ctx::WS_MSM_TMP], tmp2, k0, k1, v0, order, (int)nbk, 0, 32, c->stream));
+    HIPCK(c, hipcub::DeviceRadixSort::SortPairs(c->ws[c12381_ctx::WS_MSM_TMP], tmp2, k0, k1, v0, order, (int)nbx, 0, 32, c->stream));
     {
         timed tm(c, 5);
-        hipLaunchKernelGGL(msm_bucket_kernel, dim3(grid_for(nbk)), dim3(BLOCK), 0, c->stream, nbk, lo, hi, v1, pts2, bk, order, run_cap);
+        hipLaunchKernelGGL(msm_bucket_kernel, dim3(grid_for(nbx)), dim3(BLOCK), 0, c->stream, nbx, lo, hi, v1, pts2, bk, order, run_cap);
         HIPCK(c, hipGetLastError());
     }
     // uniform scalars register no overflow segment: both grids leave after reading the counters
@@ -236,6 +237,19 @@ int g1_msm_pippenger(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t*
     hipLaunchKernelGGL(msm_overflow_combine_kernel, dim3(ovf_cap < 4096 ? (unsigned)((ovf_cap + 3) / 4) : 1024u), dim3(BLOCK), 0, c->stream,
                        (const uint32_t*)ovf_cnt, (const uint4*)ovf_big, (const int32_t*)ovf_part, bk);
     HIPCK(c, hipGetLastError());
+    // the [r]phi(S) owed by scalars below x^2 (record in the counters' page): one lane, ~1.3 ms when any scalar was small —
+    // on the side stream, behind the window reductions that the Horner lane has to wait for anyway
+    int32_t* small_term = (int32_t*)(ovf + 64);
+    if (c->ev_chunk.empty()) {
+        hipEvent_t e;
+        HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->ev_chunk.push_back(e);
+    }
+    HIPCK(c, hipEventRecord(c->ev_chunk[0], c->stream));
+    HIPCK(c, hipStreamWaitEvent(c->side, c->ev_chunk[0], 0));
+    hipLaunchKernelGGL(msm_small_term_kernel, dim3(1), dim3(64), 0, c->side, (const int32_t*)(bk + nbk * G1_ENT_DWORDS), small_term);
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipEventRecord(c->ev_side, c->side));
     const uint32_t chunks = (uint32_t)((nb + MSM_CHUNK - 1) / MSM_CHUNK);
     size_t cur_n = (size_t)W * chunks, cur_stride = round_up(cur_n, 64);
     if ((rc = ensure(c, c12381_ctx::WS_RED0, (size_t)3 * NL * cur_stride * 4))) return rc;
@@ -256,7 +270,9 @@ int g1_msm_pippenger(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t*
         slot = slot == c12381_ctx::WS_RED0 ? c12381_ctx::WS_RED1 : c12381_ctx::WS_RED0;
     }
     if ((rc = ensure(c, c12381_ctx::WS_PROJ, (size_t)3 * NL * 64 * 4))) return rc;
-    hipLaunchKernelGGL(msm_horner_kernel, dim3(1), dim3(64), 0, c->stream, cur, cur_stride, W, cb, (int32_t*)c->ws[c12381_ctx::WS_PROJ], (size_t)64);
+    HIPCK(c, hipStreamWaitEvent(c->stream, c->ev_side, 0));
+    hipLaunchKernelGGL(msm_horner_kernel, dim3(1), dim3(64), 0, c->stream, cur, cur_stride, W, cb, (int32_t*)c->ws[c12381_ctx::WS_PROJ], (size_t)64,
+                       (const int32_t*)small_term);
     HIPCK(c, hipGetLastError());
     return g1_finish(c, 1, (const int32_t*)c->ws[c12381_ctx::WS_PROJ], 64, out, fmt);
 }

@@ -371,11 +371,27 @@ __global__ void __launch_bounds__(BLOCK, 2) g1_decompress_kernel(size_t n, const
     status[i] = tag == 0 ? 1 : (ok ? 1 : 0);
 }
 
-__global__ void __launch_bounds__(64, 1) msm_horner_kernel(const int32_t* rw, size_t stride, int W, int c, int32_t* out, size_t out_stride) {
+// term = [r]phi(S) for S = bucket `sbucket`, the sum of the points whose scalar is below x^2 (msm.hpp: msm_small_term — a
+// membership test of 128 doublings in one lane when any scalar was small, an immediate return otherwise)
+__global__ void __launch_bounds__(BLOCK, 2) msm_small_term_kernel(const int32_t* sbucket, int32_t* term_out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    g1p acc;
+    g1p S, term, nn;
+    tab_load_g1(S, sbucket);
+    msm_small_term(term, S);
+    g1_norm1(nn, term);
+    tab_store_g1(term_out, nn);
+}
+
+// R = sum_w 2^(c w) R_w + term   (one lane: 128 dependent doublings)
+__global__ void __launch_bounds__(64, 1) msm_horner_kernel(const int32_t* rw, size_t stride, int W, int c, int32_t* out, size_t out_stride,
+                                                        const int32_t* term_in) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    g1p acc, term, nn;
     msm_horner(acc, rw, stride, W, c);
-    soa_store_g1(out, out_stride, 0, acc);
+    tab_load_g1(term, term_in);
+    g1_add(acc, term);
+    g1_norm1(nn, acc);
+    soa_store_g1(out, out_stride, 0, nn);
 }
 
 }  // namespace c12381

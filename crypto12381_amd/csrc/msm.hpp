@@ -2,10 +2,14 @@
 // (The reference's Π[n](g[i]^x[i]) is n full scalar multiplications, g1_point.hpp:389-401; its bucket routine
 //  ECP_muln ecp_BLS12381.cpp:1112-1148 is exported but unused.  Only the final point is observable.)
 //
-// Every term is evaluated exactly as PAIR_G1mul does — [k mod x^2] P + [k div x^2] (-phi(P)) — so the sum equals
-// the reference's sum of multiply() results even for points outside the order-r subgroup.  Structure:
+// Every term is evaluated exactly as PAIR_G1mul does — [k mod x^2] P + [k div x^2] (-phi(P)), plus the [r]phi(P) that
+// multiply() adds for scalars below x^2: [r] and phi are homomorphisms, so those terms add up to [r]phi(S) for S = the plain
+// sum of the points with a small scalar, which is ONE more bucket (key W << c) and one evaluation next to the Horner lane
+// (msm_small_term) — so the sum equals the reference's chain of multiply() results for every input, points outside the
+// order-r subgroup included.  Structure:
 //   prep     per point: parse, on-curve check, Montgomery form of P and of P' = (beta x, -y); per (half, window)
-//            one (key = window << c | digit, value = 2 i + half) entry, zero digits get the sentinel key
+//            one (key = window << c | digit, value = 2 i + half) entry, zero digits get the sentinel key (W << c) + 1;
+//            one more entry per point: key W << c if its scalar is below x^2, else the sentinel
 //   sort     device radix sort of the entries by key (hipCUB)
 //   bucket   one lane per (window, digit): sum of its run of points with the complete MIXED addition
 //   wreduce  per window sum_d d B_d by running sums over chunks of buckets, chunk offset by double-and-add
@@ -33,6 +37,7 @@ C12381_HD int msm_window_bits(size_t n) {
     return c < 4 ? 4 : c;
 }
 C12381_HD int msm_windows(int c) { return (128 + c - 1) / c; }
+C12381_HD size_t msm_entries(size_t n, int W) { return (size_t)(2 * W + 1) * n; }      // 2W digit entries + the small-scalar entry per term
 
 // P + Q for an AFFINE Q = (qx, qy) that is not the point at infinity (Renes-Costello-Batina algorithm 8, a = 0):
 // 11 products, 8 reductions.  P limb bound <= 2^29, Q normalised.
@@ -109,7 +114,9 @@ C12381_HD bool msm_prep_one(size_t i, size_t n, const uint32_t* raw_pt /*24 word
     scalar_mod_r(k);
     uint32_t k0[4], k1[4];
     scalar_glv_split(k0, k1, k);
-    const uint32_t none = (uint32_t)W << c;
+    const uint32_t extra = (uint32_t)W << c, none = extra + 1u;
+    const bool small = (k1[0] | k1[1] | k1[2] | k1[3]) == 0u;             // k mod r < x^2: multiply() owes [r]phi(P)
+    keys[(size_t)(2 * W) * n + i] = (usable && small) ? extra : none; vals[(size_t)(2 * W) * n + i] = (uint32_t)(2 * i);
     for (int w = 0; w < W; ++w) {
         const uint32_t d0 = msm_digit(k0, w, c), d1 = msm_digit(k1, w, c);
         const size_t e0 = ((size_t)w) * n + i, e1 = ((size_t)(W + w)) * n + i;
@@ -182,6 +189,12 @@ C12381_HD void msm_horner(g1p& acc, const int32_t* rw, size_t stride, int W, int
         acc = nn;
     }
     g1p nn; g1_norm1(nn, acc); acc = nn;
+}
+
+// the [r]phi(S) owed for S = the sum of the points whose scalar is below x^2 (bucket W << c); infinity when S is in G1
+C12381_HDN void msm_small_term(g1p& term, const g1p& S) {
+    g1_set_inf(term);
+    if (!g1_is_inf(S)) g1_glv_small_scalar_term(term, S);
 }
 
 }  // namespace c12381

@@ -355,7 +355,7 @@ int sim_pair3_eq_batch(size_t n, const uint8_t* a1, const uint8_t* a2, const uin
 extern "C" int sim_g1_msm_pippenger(size_t n, const uint8_t* pts96, const uint8_t* scalars32, uint8_t* out, int fmt, int force_c) {
     const int c = force_c > 0 ? force_c : msm_window_bits(n);
     const int W = msm_windows(c);
-    const size_t E = (size_t)2 * n * W;
+    const size_t E = msm_entries(n, W);
     std::vector<int32_t> pts2v((size_t)2 * n * MSM_PT_DWORDS + 4);
     int32_t* pts2 = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(pts2v.data()) + 15) & ~(uintptr_t)15);
     std::vector<uint32_t> keys(E), vals(E);
@@ -370,11 +370,11 @@ extern "C" int sim_g1_msm_pippenger(size_t n, const uint8_t* pts96, const uint8_
     std::vector<uint32_t> ks(E), vs(E);
     for (size_t j = 0; j < E; ++j) { ks[j] = keys[order[j]]; vs[j] = vals[order[j]]; }
     const size_t nb = (size_t)1 << c, nbk = nb * W;
-    std::vector<size_t> lo(nbk + 1, 0), hi(nbk + 1, 0);
+    std::vector<size_t> lo(nbk + 2, 0), hi(nbk + 2, 0);          // + the small-scalar bucket (nbk) and the sentinel
     for (size_t j = 0; j < E; ++j) { if (j == 0 || ks[j] != ks[j - 1]) lo[ks[j]] = j; if (j + 1 == E || ks[j + 1] != ks[j]) hi[ks[j]] = j + 1; }
-    std::vector<int32_t> bkv(nbk * G1_ENT_DWORDS + 4);
+    std::vector<int32_t> bkv((nbk + 1) * G1_ENT_DWORDS + 4);
     int32_t* bk = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(bkv.data()) + 15) & ~(uintptr_t)15);
-    for (size_t b = 0; b < nbk; ++b) {
+    for (size_t b = 0; b <= nbk; ++b) {
         g1p acc, nn;
         msm_bucket_one(acc, lo[b], hi[b], vs.data(), pts2);
         g1_norm1(nn, acc);
@@ -394,6 +394,14 @@ extern "C" int sim_g1_msm_pippenger(size_t n, const uint8_t* pts96, const uint8_
     }
     g1p acc;
     msm_horner(acc, rw.data(), (size_t)W, W, c);
+    {   // the [r]phi(S) owed by the scalars below x^2
+        g1p S, term, nn;
+        tab_load_g1(S, bk + nbk * G1_ENT_DWORDS);
+        msm_small_term(term, S);
+        g1_norm1(nn, term);
+        g1_add(acc, nn);
+        g1_norm1(nn, acc); acc = nn;
+    }
     if (g1_is_inf(acc)) { std::memset(out, 0, fmt); return 0; }
     fp zn, zi, ax, ay;
     fp_norm1(zn, acc.z);

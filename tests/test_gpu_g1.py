@@ -159,6 +159,29 @@ def test_msm_skewed_scalars(ctx, oracle_port):
     assert ctx.g1_msm(pts, k * n, 96) == ctx.g1_mul(total, k, 96)
 
 
+def test_msm_small_scalars_outside_the_subgroup(ctx, oracle_port):
+    """The reference's product of powers is a chain of multiply() calls, and multiply() adds [r]phi(P) for scalars below x^2 —
+    a cofactor point when P is outside G1.  The bucket method collects those terms separately; with them the product
+    equals the oracle's chain for EVERY input (4200 such terms among ordinary ones, bucket path)."""
+    g = golden("g1")
+    off, osc = cat(g["offsubgroup_small_points"]), cat(g["offsubgroup_small_scalars"])
+    reps = 300
+    n_norm = 1000
+    g1 = bytes.fromhex(g["generator"])
+    norm_pts = ctx.g1_mul(g1 * n_norm, scalars(631, n_norm), 96)
+    pts = off * reps + norm_pts + cat(g["offsubgroup_points"]) * 5
+    sc = osc * reps + scalars(632, n_norm, 1 << 256) + cat(g["offsubgroup_scalars"]) * 5
+    assert len(pts) // 96 >= 4096
+    got = ctx.g1_msm(pts, sc, 96)
+    assert got == oracle_port.g1_msm(pts, sc, 96, 16)
+    # the same terms one by one (the n-scalar-muls path below 2^12 terms is exact by construction)
+    small = ctx.g1_msm(off, osc, 96)
+    assert small == oracle_port.g1_msm(off, osc, 96, 1)
+    # unit scalars on points outside G1: every term owes [r]phi(P)
+    ones = (1).to_bytes(32, "big") * (len(off) // 96) * reps
+    assert ctx.g1_msm(off * reps, ones, 96) == oracle_port.g1_msm(off * reps, ones, 96, 16)
+
+
 def test_fixed_base_entry_points(ctx, oracle_port):
     """g^x_i with one base: table path for subgroup bases, generic path otherwise — always equal to the generic batch."""
     g = golden("g1")

@@ -225,6 +225,12 @@ def test_sim_msm_pippenger(sim, oracle_port):
     out = ctypes.create_string_buffer(49)
     assert sim.sim_g1_msm_pippenger(sz(6), pts, sc, out, 49, 5) == 0
     assert out.raw.hex() == g["offsubgroup_msm49"]
+    # scalars below x^2 on points outside G1: the [r]phi(P) terms of multiply() arrive through the extra bucket
+    spts, ssc = cat(g["offsubgroup_small_points"]), cat(g["offsubgroup_small_scalars"])
+    mixed_p, mixed_s = spts + pts + cat(g["points"])[:96 * 5], ssc + sc + cat(g["scalars"])[:32 * 5]
+    out = ctypes.create_string_buffer(96)
+    assert sim.sim_g1_msm_pippenger(sz(len(mixed_p) // 96), mixed_p, mixed_s, out, 96, 5) == 0
+    assert out.raw == oracle_port.g1_msm(mixed_p, mixed_s, 96, 1)
     m = 300
     g1 = bytes.fromhex(g["generator"])
     p = oracle_port.g1_mul(g1 * m, scalars(801, m), 96, 4)
