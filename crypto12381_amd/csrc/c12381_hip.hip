@@ -276,12 +276,12 @@ int g1_msm_pippenger(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t*
     HIPCK(c, hipGetLastError());
     return g1_finish(c, 1, (const int32_t*)c->ws[c12381_ctx::WS_PROJ], 64, out, fmt);
 }
-// C12381_MSM=naive forces the n-scalar-muls + tree-sum path (A/B measurements); default: buckets from 2^12 terms
+// C12381_MSM=naive forces the n-scalar-muls + tree-sum path (A/B measurements); default: buckets from 2 terms on (both
+// paths equal the reference's chain of multiply() calls for every input; the bucket path is the faster one at every size)
 static bool msm_use_buckets(size_t n) {
     static const int mode = [] { const char* e = std::getenv("C12381_MSM"); return e ? (e[0] == 'n' ? 1 : (e[0] == 'b' ? 2 : 0)) : 0; }();
     if (mode == 1) return false;
-    if (mode == 2) return n >= 2;
-    return n >= 4096;
+    return n >= 2;
 }
 }  // namespace
 
@@ -425,9 +425,9 @@ int c12381_g1_add_batch(c12381_ctx* c, size_t n, const uint8_t* a, const uint8_t
     return read_flag(c);
 }
 
-// MSM: the bucket method (g1_msm_pippenger) from 2^12 terms; below that n independent GLV scalar multiplications followed
-// by a tree sum of the projective results (the reference's Π is also n full scalar-muls, g1_point.hpp:389-401) — exact for
-// every input, including the [r]-terms of small scalars on points outside G1.  Only the final point is canonical.
+// MSM: the bucket method (g1_msm_pippenger); a single term (or C12381_MSM=naive) takes n independent GLV scalar
+// multiplications followed by a tree sum of the projective results (the reference's Π is also n full scalar-muls,
+// g1_point.hpp:389-401).  Both equal the reference's chain for every input.  Only the final point is canonical.
 int c12381_g1_msm_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
     int rc = bind(c); if (rc) return rc;
     if (!out || (n && (!pts || !sc)) || (fmt != 49 && fmt != 96)) return C12381_E_ARG;

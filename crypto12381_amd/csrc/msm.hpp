@@ -29,12 +29,9 @@ C12381_HD uint32_t msm_run_cap(size_t n, int c) { const size_t mean = (2 * n) >>
 C12381_HD int msm_window_bits(size_t n) {
     // 16 bits = 8 windows over the 128-bit halves with no narrow top window (a top window of t < c bits has 2^t buckets
     // with 2^(c-t) times longer runs); measured on MI355X, 2^12 .. 2^22 terms: c = 16 is the fastest width throughout
-    // (tools/msm_sweep.py).  Below 2^12 terms (forced bucket mode, host simulation): c ~ log2(2n) - 7, at least 4.
-    if (n >= 4096) return 16;
-    int lg = 0;
-    while (((size_t)2 << lg) <= 2 * n && lg < 40) ++lg;      // lg = floor(log2(2n))
-    int c = lg - 7;
-    return c < 4 ? 4 : c;
+    // (tools/msm_sweep.py).  Below 2^12 terms the 2^19 buckets of c = 16 are mostly empty work for the window reduction:
+    // c = 8 (16 windows, again no narrow one) — 2.7 ms against 3.3 ms, and against 4.3 ms for n scalar multiplications.
+    return n >= 4096 ? 16 : 8;
 }
 C12381_HD int msm_windows(int c) { return (128 + c - 1) / c; }
 C12381_HD size_t msm_entries(size_t n, int W) { return (size_t)(2 * W + 1) * n; }      // 2W digit entries + the small-scalar entry per term
