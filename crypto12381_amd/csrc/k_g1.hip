@@ -288,20 +288,46 @@ __global__ void __launch_bounds__(BLOCK, 2) msm_bucket_kernel(size_t nbk, const 
     tab_store_g1(bk + b * G1_ENT_DWORDS, nn);
 }
 // partial sum of overflow segment q (entries [lo + cap + s seg, lo + cap + (s + 1) seg) of its run); the grid covers the
-// capacity of the segment list, lanes beyond the registered count leave at once
+// capacity of the segment list, wavefronts beyond the registered count leave at once.  The 64 segments of a wavefront are
+// consecutive list entries — for a long run: of the same bucket — so the wavefront adds them up before storing
+// (segmented suffix sums by bucket over six shuffle steps): only the first lane of each run of equal buckets writes, at its
+// own list position.  A bucket's partial sums then sit at its first list position and at every later multiple of 64.
 __global__ void __launch_bounds__(BLOCK, 2) msm_overflow_kernel(const uint32_t* cnt, const uint2* seg, const uint32_t* lo, const uint32_t* hi,
                                                              const uint32_t* vals, const int32_t* pts2, int32_t* part, uint32_t cap) {
     const size_t q = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (q >= cnt[0]) return;
-    const uint2 e = seg[q];
-    const size_t sl = cap / 2, start = (size_t)lo[e.x] + cap + (size_t)e.y * sl, h = hi[e.x];
-    g1p acc, nn;
-    msm_bucket_one(acc, start, h - start > sl ? start + sl : h, vals, pts2);
-    g1_norm1(nn, acc);
-    tab_store_g1(part + q * G1_ENT_DWORDS, nn);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t total = cnt[0];
+    if (q - lane >= total) return;                                 // the whole wavefront is beyond the list
+    const bool valid = q < total;
+    uint32_t bucket = 0xffffffffu;
+    g1p acc, nn, t, cand;
+    g1_set_inf(acc);
+    if (valid) {
+        const uint2 e = seg[q];
+        bucket = e.x;
+        const size_t sl = cap / 2, start = (size_t)lo[e.x] + cap + (size_t)e.y * sl, h = hi[e.x];
+        msm_bucket_one(acc, start, h - start > sl ? start + sl : h, vals, pts2);
+    }
+    g1_norm1(nn, acc); acc = nn;
+#pragma unroll 1
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t ob = (uint32_t)__shfl_down((int)bucket, off, 64);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            t.x.l[j] = __shfl_down(acc.x.l[j], off, 64); t.y.l[j] = __shfl_down(acc.y.l[j], off, 64); t.z.l[j] = __shfl_down(acc.z.l[j], off, 64);
+        }
+        cand = acc;
+        g1_add(cand, t);
+        g1_norm1(nn, cand);
+        const bool take = lane + (uint32_t)off < 64u && ob == bucket;
+        fp_select(acc.x, take, nn.x, acc.x); fp_select(acc.y, take, nn.y, acc.y); fp_select(acc.z, take, nn.z, acc.z);
+    }
+    const uint32_t left = (uint32_t)__shfl_up((int)bucket, 1, 64);
+    if (valid && (lane == 0 || left != bucket)) tab_store_g1(part + q * G1_ENT_DWORDS, acc);
 }
-// bucket b += its overflow partial sums: one wavefront per cut bucket (lanes take the partial sums strided, then
-// six shuffle-and-add steps); wavefronts stride over the list of cut buckets
+// bucket b += its overflow partial sums (at list position `base` and at every multiple of 64 inside (base, base + ns), see
+// above): one wavefront per cut bucket, lanes take them strided, then six shuffle-and-add steps; wavefronts stride over the
+// list of cut buckets
 __global__ void __launch_bounds__(BLOCK, 2) msm_overflow_combine_kernel(const uint32_t* cnt, const uint4* big, const int32_t* part, int32_t* bk) {
     const uint32_t lane = threadIdx.x & 63u;
     const size_t wave = ((size_t)blockIdx.x * BLOCK + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * BLOCK) >> 6;
@@ -309,13 +335,16 @@ __global__ void __launch_bounds__(BLOCK, 2) msm_overflow_combine_kernel(const ui
 #pragma unroll 1
     for (size_t q = wave; q < nbig; q += nwaves) {                          // wave-uniform
         const uint4 e = big[q];
+        const uint32_t base = e.y, end = e.y + e.z, first = (base / 64u + 1u) * 64u;
+        const uint32_t heads = 1u + (end > first ? (end - 1u - first) / 64u + 1u : 0u);
         g1p acc, t, nn;
         g1_set_inf(acc);
 #pragma unroll 1
-        for (uint32_t j0 = 0; j0 < e.z; j0 += 64) {
+        for (uint32_t j0 = 0; j0 < heads; j0 += 64) {
             const uint32_t j = j0 + lane;
-            if (j < e.z) {
-                tab_load_g1(t, part + ((size_t)e.y + j) * G1_ENT_DWORDS);
+            if (j < heads) {
+                const uint32_t pos = j == 0 ? base : first + 64u * (j - 1u);
+                tab_load_g1(t, part + (size_t)pos * G1_ENT_DWORDS);
                 g1_add(acc, t);
                 g1_norm1(nn, acc); acc = nn;
             }
