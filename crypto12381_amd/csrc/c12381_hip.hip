@@ -1170,10 +1170,25 @@ int c12381_bbs_plus_verify_aggregate_dev(c12381_ctx* c, size_t n, size_t nmsg, c
     uint8_t *tail = sc + 32 * n, *p1 = pts + o_p, *p2 = p1 + 96;
     hipLaunchKernelGGL(zp_op_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, 0, n, rho_32, x_32, sc);
     HIPCK(c, hipGetLastError());
-    if ((rc = c12381_zp_inner_product_dev(c, n, rho_32, nullptr, tail))) return rc;
-    if ((rc = c12381_zp_inner_product_dev(c, n, rho_32, r_32, tail + 32))) return rc;
-    for (size_t i = 0; i < nmsg; ++i)
-        if ((rc = c12381_zp_inner_product_dev(c, n, rho_32, m_32 + 32 * n * i, tail + 64 + 32 * i))) return rc;
+    {   // tail[y] = sum_j rho_j * (1 | r_j | m_{y-2,j}): all nmsg + 2 inner products as columns of the same fold stages
+        const size_t cols = nmsg + 2;
+        const uint8_t* cur_a = rho_32;
+        size_t cur_n = n, col_stride = 0;
+        int slot = c12381_ctx::WS_RED0, first = 1;
+        for (;;) {
+            const size_t T = (cur_n + 63) / 64;
+            uint8_t* dst = tail;
+            if (T > 1) {
+                if ((rc = ensure(c, slot, round_up(32 * T * cols, 256)))) return rc;
+                dst = (uint8_t*)c->ws[slot];
+            }
+            hipLaunchKernelGGL(zp_fold_cols_kernel, dim3(grid_for(T), (unsigned)cols), dim3(BLOCK), 0, c->stream, cur_n, cur_a, col_stride, r_32, m_32, first, T, dst);
+            HIPCK(c, hipGetLastError());
+            if (T == 1) break;
+            cur_a = dst; col_stride = 32 * T; cur_n = T; first = 0;
+            slot = slot == c12381_ctx::WS_RED0 ? c12381_ctx::WS_RED1 : c12381_ctx::WS_RED0;
+        }
+    }
     hipLaunchKernelGGL(zp_op_kernel, dim3(grid_for(nmsg + 2)), dim3(BLOCK), 0, c->stream, 3, nmsg + 2, (const uint8_t*)tail, (const uint8_t*)nullptr, tail);
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipMemcpyAsync(pts, A_96, 96 * n, hipMemcpyDeviceToDevice, c->stream));

@@ -161,4 +161,27 @@ __global__ void __launch_bounds__(BLOCK, 2) zp_fold_kernel(size_t n, const uint8
     fr_store32(out + 32 * t, acc);
 }
 
+// several folds in one launch (blockIdx.y = column): column y of the first stage multiplies a[i] by 1 (y = 0), r[i] (y = 1)
+// or m[(y - 2) n + i] — the nmsg + 2 inner products of the aggregate BBS+ verification; later stages sum column y of the
+// previous stage's partial sums (a + y * a_col_stride).  out[T * y + t]
+__global__ void __launch_bounds__(BLOCK, 2) zp_fold_cols_kernel(size_t n, const uint8_t* a, size_t a_col_stride, const uint8_t* r32, const uint8_t* m32,
+                                                             int first, size_t T, uint8_t* out) {
+    const size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= T) return;
+    const size_t y = blockIdx.y;
+    const uint8_t* ap = a + a_col_stride * y;
+    const uint8_t* bp = !first || y == 0 ? nullptr : (y == 1 ? r32 : m32 + 32 * n * (y - 2));
+    fr acc;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc.w[j] = 0;
+#pragma unroll 1
+    for (size_t i = t; i < n; i += T) {
+        fr x;
+        fr_load32(x, ap + 32 * i);
+        if (bp) { fr v; fr_load32(v, bp + 32 * i); fr_mul(x, x, v); }
+        fr_add(acc, acc, x);
+    }
+    fr_store32(out + 32 * (T * y + t), acc);
+}
+
 }  // namespace c12381

@@ -67,6 +67,7 @@ __global__ void __launch_bounds__(BLOCK, 2) gt3_is_unity_kernel(size_t n, const 
 constexpr int PAIR_QUEUE_STATE_ROWS = 42;        // 16-byte rows x 64 lanes per group of 21 pairings (F, tc1, tc2, y1)
 __global__ void __launch_bounds__(BLOCK, 2) g1_from_hash_kernel(size_t n, const uint8_t* in, int mode, int32_t* proj, size_t proj_stride, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) zp_op_kernel(int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out);
+__global__ void __launch_bounds__(BLOCK, 2) zp_fold_cols_kernel(size_t n, const uint8_t* a, size_t a_col_stride, const uint8_t* r32, const uint8_t* m32, int first, size_t T, uint8_t* out);
 constexpr int ZP_INV_RUN = 16;
 __global__ void __launch_bounds__(BLOCK, 2) zp_batch_inv_kernel(size_t n, size_t T, const uint8_t* x, const uint8_t* gamma, uint8_t* out, uint32_t* pref);
 __global__ void __launch_bounds__(BLOCK, 2) zp_from_hash_kernel(size_t n, const uint8_t* digests, uint8_t* out);
