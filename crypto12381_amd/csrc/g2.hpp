@@ -147,31 +147,40 @@ C12381_HD void g2_psi(g2pt<F>& r, const g2pt<F>& p) {
     fp2_conj(r.z, p.z);
 }
 
+// 128-by-64-bit division step for the normalised 64-bit constant |x| (top bit set) with its precomputed reciprocal
+// v = floor((2^128 - 1) / |x|) - 2^64 (Moeller-Granlund, "Improved division by invariant integers", algorithm 4):
+// (u1, u0) with u1 < |x|  ->  quotient (one word), remainder in u1.
+C12381_HD uint64_t mulhi64(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (uint64_t)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+C12381_HD uint64_t div_by_absx(uint64_t& u1, uint64_t u0) {
+    uint64_t q0 = BLS_X_RECIP * u1, q1 = mulhi64(BLS_X_RECIP, u1);
+    q0 += u0; q1 += u1 + (q0 < u0 ? 1u : 0u);                 // (q1, q0) = v u1 + (u1, u0)
+    q1 += 1;
+    uint64_t r = u0 - q1 * BLS_X;
+    if (r > q0) { q1 -= 1; r += BLS_X; }
+    if (r >= BLS_X) { q1 += 1; r -= BLS_X; }
+    u1 = r;
+    return q1;
+}
 // k (< r, 8 words) -> base-|x| digits u0..u3 (each < 2^64): k = u0 + u1|x| + u2|x|^2 + u3|x|^3   (gs() pair_BLS12381.cpp:814-873)
+// Three long divisions by the one-word constant |x|, word by word from the top (nine division steps in all).
 C12381_HD void scalar_gs_split(uint32_t (&u)[4][2], const uint32_t (&k)[8]) {
-    uint32_t w[8];
+    uint64_t w[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) w[i] = k[i];
-#pragma unroll 1
+    for (int i = 0; i < 4; ++i) w[i] = (uint64_t)k[2 * i] | ((uint64_t)k[2 * i + 1] << 32);
+#pragma unroll
     for (int lvl = 0; lvl < 3; ++lvl) {
-        uint32_t rem[3] = {0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 1
-        for (int bit = 255; bit >= 0; --bit) {
-            const uint32_t in = (w[bit >> 5] >> (bit & 31)) & 1u;
-            rem[2] = (rem[2] << 1) | (rem[1] >> 31); rem[1] = (rem[1] << 1) | (rem[0] >> 31); rem[0] = (rem[0] << 1) | in;
-            uint32_t d[3]; uint64_t bw = 0;
+        uint64_t rem = 0;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { uint64_t t = (uint64_t)rem[i] - (i < 2 ? BLS_X_W[i] : 0u) - bw; d[i] = (uint32_t)t; bw = (t >> 32) & 1; }
-            const bool ge = bw == 0;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) rem[i] = ge ? d[i] : rem[i];
-            q[bit >> 5] |= (ge ? 1u : 0u) << (bit & 31);
-        }
-        u[lvl][0] = rem[0]; u[lvl][1] = rem[1];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) w[i] = q[i];
+        for (int i = 3 - lvl; i >= 0; --i) w[i] = div_by_absx(rem, w[i]);      // quotient of level lvl has 4 - lvl - 1 words (+ a zero top word)
+        u[lvl][0] = (uint32_t)rem; u[lvl][1] = (uint32_t)(rem >> 32);
     }
-    u[3][0] = w[0]; u[3][1] = w[1];
+    u[3][0] = (uint32_t)w[0]; u[3][1] = (uint32_t)(w[0] >> 32);
 }
 // signed digit of window w (0..16) of u' = u + 0x8888888888888888; window 16 is the carry nibble
 C12381_HD int gs_digit(const uint32_t (&ub)[3], int w) {

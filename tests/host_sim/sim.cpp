@@ -352,6 +352,17 @@ int sim_pair3_eq_batch(size_t n, const uint8_t* a1, const uint8_t* a2, const uin
 // ---------------------------------------------------------------- bucket-method MSM (msm.hpp), run sequentially
 #include <algorithm>
 #include "../../crypto12381_amd/csrc/msm.hpp"
+// G2 scalar decomposition check: u[0..3] as (lo, hi) word pairs
+extern "C" int sim_gs_split(const uint8_t* scalar32, uint32_t* u8) {
+    uint32_t rs[8], k[8];
+    load_raw(rs, scalar32, 8);
+    scalar_from_raw32(k, rs);
+    scalar_mod_r(k);
+    uint32_t u[4][2];
+    scalar_gs_split(u, k);
+    for (int i = 0; i < 4; ++i) { u8[2 * i] = u[i][0]; u8[2 * i + 1] = u[i][1]; }
+    return 0;
+}
 extern "C" int sim_g1_msm_pippenger(size_t n, const uint8_t* pts96, const uint8_t* scalars32, uint8_t* out, int fmt, int force_c) {
     const int c = force_c > 0 ? force_c : msm_window_bits(n);
     const int W = msm_windows(c);

@@ -67,6 +67,25 @@ def test_sim_glv_split(sim):
         assert a0 + a1 * x2 == (k % (1 << 256)) % R and a0 < x2
 
 
+def test_sim_gs_split(sim):
+    """G2 decomposition k = u0 + u1|x| + u2|x|^2 + u3|x|^3 by word-wise division with a precomputed reciprocal: digits
+    against Python integers for boundary values (multiples of |x|^j +- 1, powers of two) and random scalars."""
+    x = 0xd201000000010000
+    ks = [0, 1, x - 1, x, x + 1, x * x - 1, x * x, x ** 3 - 1, x ** 3, x ** 3 + 1, R - 1, R, R + 7, (1 << 256) - 1]
+    ks += [q * x ** j + d for j in (1, 2, 3) for q in (1, 2, x - 1, 0xffffffff, 1 << 63) for d in (-1, 0, 1) if 0 <= q * x ** j + d < R]
+    ks += [(1 << b) + d for b in range(0, 255, 3) for d in (-1, 0, 1) if (1 << b) + d >= 0]
+    ks += [int.from_bytes(scalars(88, 3000, 1 << 256)[32 * i:32 * i + 32], "big") for i in range(3000)]
+    for k in ks:
+        u = (ctypes.c_uint32 * 8)()
+        sim.sim_gs_split((k % (1 << 256)).to_bytes(32, "big"), u)
+        v = (k % (1 << 256)) % R
+        for i in range(4):
+            d = u[2 * i] | (u[2 * i + 1] << 32)
+            exp = v % x if i < 3 else v
+            assert d == exp, (hex(k), i)
+            v //= x
+
+
 def test_sim_g1_mul_golden(sim):
     g = golden("g1")
     pts, sc = cat(g["points"]), cat(g["scalars"])

@@ -213,6 +213,9 @@ def main():
     out.append("C12381_CONST uint32_t GLV_MU[5] = {%s};    // floor(2^256 / x^2): Barrett reciprocal of the GLV base\n" % words32((1 << 256) // (X * X), 5))
     out.append("constexpr uint64_t BLS_X = 0x%xull;        // |x| (CURVE_Bnx); x itself is negative\n" % X)
     out.append("C12381_CONST uint32_t BLS_X_W[2] = {%s};\n" % words32(X, 2))
+    assert X >> 63 == 1
+    out.append("constexpr uint64_t BLS_X_RECIP = 0x%xull;  // floor((2^128 - 1) / |x|) - 2^64: reciprocal for 2-by-1 word division (Moeller-Granlund)\n"
+               % (((1 << 128) - 1) // X - (1 << 64)))
     out.append("\n// standard generators, Montgomery form (CURVE_Gx/Gy, CURVE_Pxa..Pyb)\n")
     for nm, v in (("G1_GX", G1X), ("G1_GY", G1Y), ("G2_GXA", G2XA), ("G2_GXB", G2XB), ("G2_GYA", G2YA), ("G2_GYB", G2YB)):
         out.append(arr(nm, mont(v)))
