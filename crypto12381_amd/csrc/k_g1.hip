@@ -5,7 +5,8 @@
 //   g1_finish_kernel   Montgomery's simultaneous inversion over a strided chunk per lane,
 //                      affine conversion, canonical encoding (49 B / 96 B)
 //   g1_reduce_kernel   tree sum of projective points (MSM combine)
-//   msm_*_kernel       bucket-method MSM stages (msm.hpp)
+//   msm_*_kernel       bucket-method MSM stages (msm.hpp): prep, ranges, sizes (+ overflow bookkeeping), bucket, overflow,
+//                      overflow_combine, wreduce, small_term, horner
 //   g1_decompress_kernel   49-byte -> 96-byte decoding with the reference's acceptance rules
 #include "kernels_common.hpp"
 #include "msm.hpp"

@@ -1,6 +1,7 @@
 // Kernel entry points of the backend, one translation unit per family so the families compile in parallel:
 //   k_g1.hip     Fp hooks, G1 scalar multiplication / addition / finish / tree sum, MSM stages, G1 decompression
-//   k_g2gt.hip   G2 scalar multiplication / addition / decompression, one-lane pairing kernels, GT arithmetic
+//   k_g2gt.hip   G2 scalar multiplication (one lane per point) / addition / finish / decompression, one-lane pairing kernels, GT arithmetic
+//   k_g2h.hip    G2 scalar multiplication with two lanes per point (half an Fp2 element per lane)
 //   k_pair3.hip  three-lanes-per-pairing Miller loop + final exponentiation
 //   k_hash_zp.hip  hash-to-G1 and the scalar-field (Zp) helpers
 //   k_fixed.hip  fixed-base tables and their evaluation (public-parameter columns of BBS+)
@@ -15,14 +16,14 @@ namespace c12381 {
 
 constexpr int BLOCK = 256;
 constexpr int FINISH_M = 16;                     // elements per lane in the simultaneous inversion
-constexpr int TRI_PER_WAVE = 21;
+constexpr int TRI_PER_WAVE = 21;                 // pairings per 64-lane wavefront in the three-lane kernels (lane 63 idles along)
 // Header words in front of a device-built table (fixed-base multiples, line coefficients) and of a gate buffer
 constexpr int HDR_VALID = 48;                    // 1 = table usable / this path runs; kernels of the other path return at once
 constexpr int HDR_REBUILD = 49;                  // set by fixed_cache_check_kernel when the cached point differs
 constexpr int HDR_MAGIC = 50;                    // the header has been written before
 constexpr int HDR_RULE = 51;                     // validity rule the flag was computed under (line tables)
 constexpr int HDR_DWORDS = 64;                   // table data starts here
-constexpr int GATE_OTHER = 49;                   // (gate + GATE_OTHER)[HDR_VALID] = the complement of gate[HDR_VALID]                 // pairings per 64-lane wave in the three-lane kernels (lane 63 idles)
+constexpr int GATE_OTHER = 49;                   // (gate + GATE_OTHER)[HDR_VALID] = the complement of gate[HDR_VALID]
 
 __global__ void __launch_bounds__(BLOCK, 2) fp_op_kernel(int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out);
 __global__ void __launch_bounds__(BLOCK, 2) fp_mulchain_kernel(size_t n, int iters, const uint8_t* a, const uint8_t* b, uint8_t* out);
