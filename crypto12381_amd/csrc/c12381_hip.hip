@@ -256,15 +256,14 @@ int g1_msm_pippenger(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t*
     hipLaunchKernelGGL(msm_wreduce_kernel, dim3(grid_for(cur_n)), dim3(BLOCK), 0, c->stream, W, (uint32_t)nb, chunks, bk,
                        (int32_t*)c->ws[c12381_ctx::WS_RED0], cur_stride);
     HIPCK(c, hipGetLastError());
-    // per-window sums: element index = chunk * W + w, so reducing modulo (W * r) keeps windows apart
+    // per-window sums: element index = chunk * W + w; every level folds 64 points of a window per wavefront
     const int32_t* cur = (const int32_t*)c->ws[c12381_ctx::WS_RED0];
     int slot = c12381_ctx::WS_RED1;
     while (cur_n > (size_t)W) {
-        size_t groups = cur_n / W;                           // points per window still to be summed
-        size_t r = groups > 32 ? (groups + 31) / 32 : 1;     // keep r partial sums per window
-        const size_t m = (size_t)W * r, m_stride = round_up(m, 64);
+        const size_t groups = cur_n / W, out_groups = (groups + 63) / 64;
+        const size_t m = (size_t)W * out_groups, m_stride = round_up(m, 64);
         if ((rc = ensure(c, slot, (size_t)3 * NL * m_stride * 4))) return rc;
-        hipLaunchKernelGGL(g1_reduce_kernel, dim3(grid_for(m)), dim3(BLOCK), 0, c->stream, cur_n, cur, cur_stride, m, (int32_t*)c->ws[slot], m_stride);
+        hipLaunchKernelGGL(g1_wave_reduce_kernel, dim3(grid_for(m * 64)), dim3(BLOCK), 0, c->stream, groups, W, cur, cur_stride, (int32_t*)c->ws[slot], m_stride);
         HIPCK(c, hipGetLastError());
         cur = (const int32_t*)c->ws[slot]; cur_n = m; cur_stride = m_stride;
         slot = slot == c12381_ctx::WS_RED0 ? c12381_ctx::WS_RED1 : c12381_ctx::WS_RED0;

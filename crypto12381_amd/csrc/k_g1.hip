@@ -401,6 +401,31 @@ __global__ void __launch_bounds__(BLOCK, 2) g1_decompress_kernel(size_t n, const
     status[i] = tag == 0 ? 1 : (ok ? 1 : 0);
 }
 
+// One level of the per-window sums of the MSM, 64 points per wavefront: element index = group * W + w; wavefront (g, w) loads
+// the 64 points (64 g + lane) * W + w, adds them in six shuffle steps and stores element g * W + w of the next level —
+// 4096 partial sums per window become one in two levels of depth 6 instead of three levels of up to 32 dependent additions
+__global__ void __launch_bounds__(BLOCK, 2) g1_wave_reduce_kernel(size_t groups, int W, const int32_t* in, size_t in_stride, int32_t* outp, size_t out_stride) {
+    const size_t wave = ((size_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    const size_t out_groups = (groups + 63) / 64;
+    if (wave >= out_groups * (size_t)W) return;                               // wave-uniform
+    const size_t g = wave / (size_t)W, w = wave % (size_t)W;
+    const size_t src = g * 64 + lane;
+    g1p acc, t, nn;
+    g1_set_inf(acc);
+    if (src < groups) soa_load_g1(acc, in, in_stride, src * (size_t)W + w);
+#pragma unroll 1
+    for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            t.x.l[i] = __shfl_down(acc.x.l[i], off, 64); t.y.l[i] = __shfl_down(acc.y.l[i], off, 64); t.z.l[i] = __shfl_down(acc.z.l[i], off, 64);
+        }
+        g1_add(acc, t);
+        g1_norm1(nn, acc); acc = nn;
+    }
+    if (lane == 0) soa_store_g1(outp, out_stride, g * (size_t)W + w, acc);
+}
+
 // term = [r]phi(S) for S = bucket `sbucket`, the sum of the points whose scalar is below x^2 (msm.hpp: msm_small_term — a
 // membership test of 128 doublings in one lane when any scalar was small, an immediate return otherwise)
 __global__ void __launch_bounds__(BLOCK, 2) msm_small_term_kernel(const int32_t* sbucket, int32_t* term_out) {

@@ -43,6 +43,7 @@ __global__ void __launch_bounds__(BLOCK, 2) msm_overflow_combine_kernel(const ui
 __global__ void __launch_bounds__(BLOCK, 2) msm_wreduce_kernel(int W, uint32_t nb, uint32_t chunks, const int32_t* bk, int32_t* out, size_t out_stride);
 __global__ void __launch_bounds__(BLOCK, 2) g1_decompress_kernel(size_t n, const uint8_t* in, uint8_t* out, uint8_t* status);
 __global__ void __launch_bounds__(64, 1) msm_horner_kernel(const int32_t* rw, size_t stride, int W, int c, int32_t* out, size_t out_stride, const int32_t* term_in);
+__global__ void __launch_bounds__(BLOCK, 2) g1_wave_reduce_kernel(size_t groups, int W, const int32_t* in, size_t in_stride, int32_t* outp, size_t out_stride);
 __global__ void __launch_bounds__(BLOCK, 2) msm_small_term_kernel(const int32_t* sbucket, int32_t* term_out);
 __global__ void __launch_bounds__(BLOCK, 2) g2_mul_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab, size_t tab_stride, uint8_t* out, int fmt, int* bad_flag, const int32_t* skip_if, int32_t* proj, size_t proj_stride, size_t proj_off);
 __global__ void __launch_bounds__(BLOCK, 2) g2_mul2_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab, int* bad_flag, const int32_t* skip_if, int32_t* proj, size_t proj_stride, size_t proj_off);
