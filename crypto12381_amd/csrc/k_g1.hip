@@ -437,16 +437,67 @@ __global__ void __launch_bounds__(BLOCK, 2) msm_small_term_kernel(const int32_t*
     tab_store_g1(term_out, nn);
 }
 
-// R = sum_w 2^(c w) R_w + term   (one lane: 128 dependent doublings)
+// A doubling spread over FOUR lanes (the Horner chain is 112 dependent doublings in a single lane otherwise: ~1.1 ms of an
+// MSM, a third of a small one).  The point is replicated in the lanes of a quad; the eight products of g1_dbl form two rounds
+// of four independent ones — Y^2, YZ, Z^2, XY, then t1*z8, u*y3, t2*z8, u*xy — so lane r of the quad computes product r
+// of each round and the quad exchanges the results by DPP broadcasts (quad_perm [k,k,k,k]); additions are replicated.
+// Same values as g1_dbl (Y3 is the sum of two separately reduced products instead of one lazily reduced sum).
+__device__ __forceinline__ void quad_bcast(fp& r, const fp& v, int k) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        int32_t w;
+        switch (k) {                                               // the control word must be a compile-time constant
+            case 0: w = __builtin_amdgcn_mov_dpp(v.l[i], 0x00, 0xF, 0xF, true); break;
+            case 1: w = __builtin_amdgcn_mov_dpp(v.l[i], 0x55, 0xF, 0xF, true); break;
+            case 2: w = __builtin_amdgcn_mov_dpp(v.l[i], 0xAA, 0xF, 0xF, true); break;
+            default: w = __builtin_amdgcn_mov_dpp(v.l[i], 0xFF, 0xF, 0xF, true); break;
+        }
+        r.l[i] = w;
+    }
+}
+__device__ __forceinline__ void g1_dbl_quad(g1p& p, int r) {
+    fp a, b, prod, t0, t1, t2, xy, z8, u, y3s;
+    // round 1: r0 Y*Y, r1 Y*Z, r2 Z*Z, r3 X*Y
+    fp_select(a, r == 2, p.z, p.y); fp_select(a, r == 3, p.x, a);
+    fp_select(b, r == 1 || r == 2, p.z, p.y);
+    fp_mul(prod, a, b);
+    quad_bcast(t0, prod, 0); quad_bcast(t1, prod, 1); quad_bcast(t2, prod, 2); quad_bcast(xy, prod, 3);
+    fp_mul_small(z8, t0, 8);                             // 8 Y^2
+    fp_mul_small(t2, t2, 12);                            // 3b Z^2
+    fp_add(y3s, t0, t2);
+    fp_dbl(u, t2); fp_add(u, u, t2);                     // 9b Z^2
+    fp_sub(u, t0, u);
+    fp_norm1(u, u);
+    // round 2: r0 t1*z8 (Z3), r1 u*y3s, r2 t2*z8, r3 u*xy
+    fp_select(a, r == 0, t1, u); fp_select(a, r == 2, t2, a);
+    fp_select(b, r == 1, y3s, z8); fp_select(b, r == 3, xy, b);
+    fp_mul(prod, a, b);
+    fp ya, yb, xh;
+    quad_bcast(p.z, prod, 0); quad_bcast(ya, prod, 1); quad_bcast(yb, prod, 2); quad_bcast(xh, prod, 3);
+    fp_add(p.y, ya, yb);
+    fp_dbl(p.x, xh);
+}
+// R = sum_w 2^(c w) R_w + term: the Horner chain on one quad (lanes 0..3 of a wavefront), doublings spread over its lanes
 __global__ void __launch_bounds__(64, 1) msm_horner_kernel(const int32_t* rw, size_t stride, int W, int c, int32_t* out, size_t out_stride,
                                                         const int32_t* term_in) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    g1p acc, term, nn;
-    msm_horner(acc, rw, stride, W, c);
-    tab_load_g1(term, term_in);
-    g1_add(acc, term);
+    if (threadIdx.x >= 4 || blockIdx.x != 0) return;
+    const int r = (int)(threadIdx.x & 3u);
+    g1p acc, q, nn, term;
+    soa_load_g1(acc, rw, stride, (size_t)(W - 1));
+#pragma unroll 1
+    for (int w = W - 2; w >= 0; --w) {
+#pragma unroll 1
+        for (int b = 0; b < c; ++b) g1_dbl_quad(acc, r);
+        soa_load_g1(q, rw, stride, (size_t)w);
+        g1_norm1(nn, acc);
+        g1_add(nn, q);
+        acc = nn;
+    }
     g1_norm1(nn, acc);
-    soa_store_g1(out, out_stride, 0, nn);
+    tab_load_g1(term, term_in);
+    g1_add(nn, term);
+    g1_norm1(acc, nn);
+    if (r == 0) soa_store_g1(out, out_stride, 0, acc);
 }
 
 }  // namespace c12381
