@@ -8,6 +8,8 @@ import sys
 
 import pytest
 
+from util import golden as golden_g
+
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -96,3 +98,26 @@ def test_full_size_digests_across_implementations():
     assert one == base
     plain = run({"C12381_PAIR_QUEUE": "0"})
     assert plain["pair"] == base["pair"] and plain["pair_eq"] == base["pair_eq"]
+
+
+def test_ragged_sizes_vs_oracle(oracle_port):
+    """Batch sizes around the lane-grouping boundaries of the kernels (two lanes per G2 point, 21 pairings per wavefront, 64-entry
+    MSM stages, the 2^12-term switch of the window width): G2 multiplication, MSM and pairing against the CPU oracle."""
+    from crypto12381_amd import Context
+    from util import scalars
+    ctx = Context(0)
+    g1 = bytes.fromhex(golden_g("g1")["generator"])
+    g2 = bytes.fromhex(golden_g("g2")["generator"])
+    m = 4200
+    P = ctx.g1_mul(g1 * m, scalars(961, m), 96)
+    Q = ctx.g2_mul(g2 * 300, scalars(962, 300), 192)
+    assert Q[:192 * 40] == oracle_port.g2_mul(g2 * 40, scalars(962, 40), 192, 8)
+    for n in (1, 2, 3, 31, 32, 33, 63, 64, 65, 127, 129, 300):
+        sc = scalars(963 + n, n, 1 << 256)
+        assert ctx.g2_mul(Q[:192 * n], sc, 97) == oracle_port.g2_mul(Q[:192 * n], sc, 97, 16), n
+    for n in (2, 3, 5, 63, 64, 65, 255, 257, 1023, 4095, 4096, 4097):
+        sc = scalars(964 + n, n, 1 << 256)
+        assert ctx.g1_msm(P[:96 * n], sc, 96) == oracle_port.g1_msm(P[:96 * n], sc, 96, 16), n
+    for n in (1, 2, 20, 21, 22, 41, 42, 43, 63, 64, 85):
+        assert ctx.pair(P[:96 * n], Q[:192 * n]) == oracle_port.pair(P[:96 * n], Q[:192 * n], 16), n
+    ctx.close()
