@@ -460,12 +460,17 @@ C12381_HDN void miller_lines_precompute(int32_t* tab, const fp2& qx, const fp2& 
         }
     }
 }
-// f *= line(tab[k]) evaluated at P = (px, py); every lane of the triple forms the three coefficients itself
+// f *= line(tab[k]) evaluated at P = (px, py): role 0 forms l0 = c0 py, role 1 forms l2 = c2 px (role 2 repeats role 1), and
+// the triple shares the two products — one Fp2-by-Fp product per lane instead of two
 C12381_HDN void miller3_fixed_line(fp4& F, const int32_t* tab, int k, const fp& px, const fp& py, bool skip, const tri& t) {
-    fp2 c0, c1, c2, l0, l2, one2, zero2;
+    fp2 c0, c1, c2, l0, l2, one2, zero2, cs, prod;
+    fp ps;
     fq_load_line(c0, c1, c2, tab + (size_t)k * FQ_LINE_DWORDS);
-    fp2_mul_fp(l0, c0, py);
-    fp2_mul_fp(l2, c2, px);
+    fp2_select(cs, t.role == 0, c0, c2);
+    fp_select(ps, t.role == 0, py, px);
+    fp2_mul_fp(prod, cs, ps);
+    tri_fetch_fp2(l0, prod, 0, t);
+    tri_fetch_fp2(l2, prod, 1, t);
     fp2_one(one2); fp2_zero(zero2);
     fp2_select(l0, skip, one2, l0); fp2_select(c1, skip, zero2, c1); fp2_select(l2, skip, zero2, l2);
     f12t_mul_line_core(F, l0, c1, l2, t);
