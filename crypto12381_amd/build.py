@@ -1,9 +1,11 @@
 """Build the HIP shared library in-tree (crypto12381_amd/lib/libc12381_hip.so) for gfx950.
 
-One hipcc compile per translation unit (csrc/*.hip, in parallel, objects cached under lib/obj/ by mtime of the
-sources they include), then one link."""
+One hipcc compile per translation unit (csrc/*.hip, in parallel), then one link.  Objects are cached under lib/obj/ and
+reused only when (a) no source or header is newer and (b) the stamp next to the object — a hash of the exact command
+line and of `hipcc --version` — matches: an object built with other flags or another compiler is never linked in."""
 from __future__ import annotations
 
+import hashlib
 import os
 import subprocess
 from concurrent.futures import ThreadPoolExecutor
@@ -39,14 +41,34 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+_HIPCC_VERSION = None
+
+
+def _stamp(unit: str) -> str:
+    """hash of everything besides the sources that decides what the object contains"""
+    global _HIPCC_VERSION
+    if _HIPCC_VERSION is None:
+        _HIPCC_VERSION = subprocess.run([HIPCC, "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
+    return hashlib.sha256("\0".join([HIPCC, *CFLAGS, unit, _HIPCC_VERSION]).encode()).hexdigest()
+
+
+def _stamp_ok(unit: str) -> bool:
+    path = os.path.join(OBJ, unit[:-4] + ".stamp")
+    try:
+        return open(path).read().strip() == _stamp(unit)
+    except OSError:
+        return False
+
+
 def needs_build() -> bool:
-    return _stale(LIB, _headers() + [os.path.join(CSRC, u) for u in UNITS])
+    return (_stale(LIB, _headers() + [os.path.join(CSRC, u) for u in UNITS])
+            or not all(_stamp_ok(u) and os.path.exists(os.path.join(OBJ, u[:-4] + ".o")) for u in UNITS))
 
 
 def _compile(unit: str, force: bool, verbose: bool) -> str:
     src = os.path.join(CSRC, unit)
     obj = os.path.join(OBJ, unit[:-4] + ".o")
-    if force or _stale(obj, _headers() + [src]):
+    if force or _stale(obj, _headers() + [src]) or not _stamp_ok(unit):
         cmd = [HIPCC, *CFLAGS, "-c", "-o", obj, src]
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -59,6 +81,8 @@ def _compile(unit: str, force: bool, verbose: bool) -> str:
         # shared out-of-line routines a 512-register budget and drags all of them to occupancy 1 — treat that as an error
         if "failed to meet occupancy target" in r.stderr:
             raise RuntimeError("%s: a kernel missed its occupancy target (see the compiler warning above)" % unit)
+        with open(os.path.join(OBJ, unit[:-4] + ".stamp"), "w") as f:
+            f.write(_stamp(unit) + "\n")
     return obj
 
 

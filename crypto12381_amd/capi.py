@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("C12381_LIB") or os.path.join(_HERE, "lib", "libc12381_hip.so")   # C12381_LIB: A/B builds of the same ABI
 
-E_ARG, E_HIP, E_POINT, E_NOMEM = -1, -2, -3, -4
+E_ARG, E_HIP, E_POINT, E_NOMEM, E_INTERNAL = -1, -2, -3, -4, -5
 
 
 class C12381Error(RuntimeError):

@@ -24,6 +24,7 @@ using namespace c12381;
 namespace {
 constexpr size_t G1_CHUNK = (size_t)1 << 17;     // elements per scalar-mul launch = resident lanes at 2 waves/SIMD; table slab 176 MiB (fits the 256 MiB Infinity Cache)
 constexpr size_t G2_CHUNK = (size_t)1 << 17;     // G2 table slab = 352 MiB (2688-byte record per lane)
+constexpr int FLAG_WORDS = 4;                    // device status words (read_flag)
 // terms per bucket-method pass (2 * n * windows sort items < 2^31); C12381_MSM_MAX_TERMS lowers it so that tests reach
 // the multi-part path with small inputs
 const size_t MSM_MAX_TERMS = [] {
@@ -137,11 +138,19 @@ int g1_finish(c12381_ctx* c, size_t n, const int32_t* proj, size_t stride, uint8
     HIPCK(c, hipGetLastError());
     return 0;
 }
+// Status words raised by the kernels since the last read: [0] an input point was not on the curve (its outputs are 0xff),
+// [1] a library-internal failure (a work-queue hand-over timed out: the affected outputs are 0xff as well).  Every host
+// entry point ends here, so a word raised by an earlier asynchronous _dev call is reported by the next host call or
+// c12381_sync() on the same context, whichever comes first — _dev callers separate logical operations with c12381_sync().
 int read_flag(c12381_ctx* c) {
-    HIPCK(c, hipMemcpyAsync(c->h_flag, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));
+    HIPCK(c, hipMemcpyAsync(c->h_flag, c->d_flag, FLAG_WORDS * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemsetAsync(c->d_flag, 0, FLAG_WORDS * sizeof(int), c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
-    return *c->h_flag ? C12381_E_POINT : 0;
+    if (c->h_flag[1]) {
+        std::snprintf(c->err, sizeof c->err, "internal: a pairing work-queue hand-over timed out; the affected outputs are 0xff");
+        return C12381_E_INTERNAL;
+    }
+    return c->h_flag[0] ? C12381_E_POINT : 0;
 }
 // stage host buffers: copies up to three inputs in, runs body, copies output back
 struct staged {
@@ -300,8 +309,8 @@ int c12381_create(int device, c12381_ctx** out) {
     c->own_stream = true;
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming) != hipSuccess) { c12381_destroy(c); return C12381_E_HIP; }
-    if (hipMalloc((void**)&c->d_flag, sizeof(int)) != hipSuccess || hipHostMalloc((void**)&c->h_flag, sizeof(int)) != hipSuccess ||
-        hipMemset(c->d_flag, 0, sizeof(int)) != hipSuccess) { c12381_destroy(c); return C12381_E_HIP; }
+    if (hipMalloc((void**)&c->d_flag, FLAG_WORDS * sizeof(int)) != hipSuccess || hipHostMalloc((void**)&c->h_flag, FLAG_WORDS * sizeof(int)) != hipSuccess ||
+        hipMemset(c->d_flag, 0, FLAG_WORDS * sizeof(int)) != hipSuccess) { c12381_destroy(c); return C12381_E_HIP; }
     *out = c;
     return 0;
 }
@@ -377,8 +386,7 @@ int c12381_fp_op_batch(c12381_ctx* c, int op, size_t n, const uint8_t* a, const 
     if ((rc = stage_in(c, s, a, 48 * n, op <= 2 ? b : nullptr, op <= 2 ? 48 * n : 0, 48 * n))) return rc;
     if ((rc = c12381_fp_op_batch_dev(c, op, n, s.in0, s.in1, s.out))) return rc;
     if ((rc = stage_out(c, s, out, 48 * n))) return rc;
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return read_flag(c);
 }
 int c12381_fp_mulchain_dev(c12381_ctx* c, size_t n, int iters, const uint8_t* a, const uint8_t* b, uint8_t* out) {
     int rc = bind(c); if (rc) return rc;
@@ -585,6 +593,13 @@ static int pair_queue_mode() {
     static const int v = [] { const char* e = std::getenv("C12381_PAIR_QUEUE"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
     return v;
 }
+// bound of the hand-over spin in the queue kernels (k_pair3.hip queue_wait): 2^20 sleeps of 4096 cycles, about two
+// seconds — three orders of magnitude beyond a task.  C12381_PAIR_SPIN_LIMIT overrides it; a negative value makes every
+// wait fail (tests of the poison path).
+static int pair_spin_limit() {
+    static const int v = [] { const char* e = std::getenv("C12381_PAIR_SPIN_LIMIT"); return e ? std::atoi(e) : (1 << 20); }();
+    return v;
+}
 static bool pair_use_queue(size_t n) {
     const int m = pair_queue_mode();
     if (m >= 0) return m == 1;
@@ -610,7 +625,7 @@ static int launch_pair(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8_t
     else if (pair_use_queue(n)) {
         uint4* st; unsigned int *fl, *ct; unsigned blocks; int rc;
         if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
-        hipLaunchKernelGGL(pair3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag, st, fl, ct);
+        hipLaunchKernelGGL(pair3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag, st, fl, ct, pair_spin_limit());
     } else hipLaunchKernelGGL(pair3_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag);
     HIPCK(c, hipGetLastError());
     return 0;
@@ -621,7 +636,7 @@ static int launch_pair_eq(c12381_ctx* c, size_t n, const uint8_t* a1, const uint
     else if (pair_use_queue(n)) {
         uint4* st; unsigned int *fl, *ct; unsigned blocks; int rc;
         if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
-        hipLaunchKernelGGL(pair3_eq_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, a1, a2, b1, b2, b2_stride, ok, c->d_flag, st, fl, ct, skip_if);
+        hipLaunchKernelGGL(pair3_eq_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, a1, a2, b1, b2, b2_stride, ok, c->d_flag, st, fl, ct, skip_if, pair_spin_limit());
     } else hipLaunchKernelGGL(pair3_eq_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, a1, a2, b1, b2, b2_stride, ok, c->d_flag, skip_if);
     HIPCK(c, hipGetLastError());
     return 0;
@@ -634,7 +649,7 @@ int c12381_pair_batch_dev(c12381_ctx* c, size_t n, const uint8_t* g1, const uint
         uint4* st; unsigned int *fl, *ct; unsigned blocks;
         if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
         timed tm(c, 3);
-        hipLaunchKernelGGL(pair3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag, st, fl, ct);
+        hipLaunchKernelGGL(pair3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag, st, fl, ct, pair_spin_limit());
         HIPCK(c, hipGetLastError());
         return 0;
     }
@@ -664,7 +679,7 @@ int c12381_pair_fixed_g2_batch_dev(c12381_ctx* c, size_t n, const uint8_t* g1, c
     if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
     timed tm(c, 3);
     hipLaunchKernelGGL(pair3_fixed_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, g1, (const int32_t*)c->ws[c12381_ctx::WS_FQ_P], gt, c->d_flag,
-                       st, fl, ct);
+                       st, fl, ct, pair_spin_limit());
     HIPCK(c, hipGetLastError());
     return 0;
 }
@@ -734,8 +749,7 @@ int c12381_g1_decompress_batch(c12381_ctx* c, size_t n, const uint8_t* in49, uin
     HIPCK(c, hipGetLastError());
     if ((rc = stage_out(c, s, out96, 96 * n))) return rc;
     HIPCK(c, hipMemcpyAsync(status, s.in1, n, hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return read_flag(c);
 }
 // ---------------------------------------------------------------- hash-to-G1, Zp helpers
 static int g1_map_common(c12381_ctx* c, size_t n, const uint8_t* d_in, int mode, uint8_t* d_out, int fmt) {
@@ -761,8 +775,7 @@ int c12381_g1_from_hash_batch(c12381_ctx* c, size_t n, const uint8_t* digests, u
     if ((rc = stage_in(c, s, digests, 64 * n, nullptr, 0, (size_t)fmt * n))) return rc;
     if ((rc = g1_map_common(c, n, s.in0, 0, s.out, fmt))) return rc;
     if ((rc = stage_out(c, s, out, (size_t)fmt * n))) return rc;
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return read_flag(c);
 }
 int c12381_g1_map_to_point_batch(c12381_ctx* c, size_t n, const uint8_t* u48, uint8_t* out96) {
     int rc = bind(c); if (rc) return rc;
@@ -772,8 +785,7 @@ int c12381_g1_map_to_point_batch(c12381_ctx* c, size_t n, const uint8_t* u48, ui
     if ((rc = stage_in(c, s, u48, 48 * n, nullptr, 0, 96 * n))) return rc;
     if ((rc = g1_map_common(c, n, s.in0, 1, s.out, 96))) return rc;
     if ((rc = stage_out(c, s, out96, 96 * n))) return rc;
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return read_flag(c);
 }
 int c12381_g1_clear_cofactor_batch(c12381_ctx* c, size_t n, const uint8_t* in96, uint8_t* out96) {
     int rc = bind(c); if (rc) return rc;
@@ -811,8 +823,7 @@ int c12381_zp_op_batch(c12381_ctx* c, int op, size_t n, const uint8_t* a, const 
     if ((rc = stage_in(c, s, a, 32 * n, op <= 2 ? b : nullptr, op <= 2 ? 32 * n : 0, 32 * n))) return rc;
     if ((rc = c12381_zp_op_batch_dev(c, op, n, s.in0, s.in1, s.out))) return rc;
     if ((rc = stage_out(c, s, out, 32 * n))) return rc;
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return read_flag(c);
 }
 int c12381_zp_from_hash_batch(c12381_ctx* c, size_t n, const uint8_t* digests, uint8_t* out) {
     int rc = bind(c); if (rc) return rc;
@@ -823,8 +834,7 @@ int c12381_zp_from_hash_batch(c12381_ctx* c, size_t n, const uint8_t* digests, u
     hipLaunchKernelGGL(zp_from_hash_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, s.in0, s.out);
     HIPCK(c, hipGetLastError());
     if ((rc = stage_out(c, s, out, 32 * n))) return rc;
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return read_flag(c);
 }
 // strided partial sums, 64 terms per lane and stage, ping-pong between two reduction slots
 int c12381_zp_inner_product_dev(c12381_ctx* c, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
@@ -856,8 +866,7 @@ int c12381_zp_inner_product(c12381_ctx* c, size_t n, const uint8_t* a, const uin
     if ((rc = stage_in(c, s, a, 32 * n, b, b ? 32 * n : 0, 32))) return rc;
     if ((rc = c12381_zp_inner_product_dev(c, n, s.in0, b ? s.in1 : nullptr, s.out))) return rc;
     if ((rc = stage_out(c, s, out, 32))) return rc;
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return read_flag(c);
 }
 
 int c12381_g2_decompress_batch(c12381_ctx* c, size_t n, const uint8_t* in97, uint8_t* out192, uint8_t* status) {
@@ -870,8 +879,7 @@ int c12381_g2_decompress_batch(c12381_ctx* c, size_t n, const uint8_t* in97, uin
     HIPCK(c, hipGetLastError());
     if ((rc = stage_out(c, s, out192, 192 * n))) return rc;
     HIPCK(c, hipMemcpyAsync(status, s.in1, n, hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return read_flag(c);
 }
 int c12381_miller_batch(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* out576) {
     int rc = bind(c); if (rc) return rc;
@@ -896,8 +904,7 @@ int c12381_gt_op_batch(c12381_ctx* c, int op, size_t n, const uint8_t* a576, con
     else hipLaunchKernelGGL(gt3_op_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, op, n, s.in0, s.in1, s.out);
     HIPCK(c, hipGetLastError());
     if ((rc = stage_out(c, s, out576, 576 * n))) return rc;
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return read_flag(c);
 }
 int c12381_fexp_batch(c12381_ctx* c, size_t n, const uint8_t* in576, uint8_t* out576) { return c12381_gt_op_batch(c, 3, n, in576, nullptr, out576); }
 int c12381_gt_is_unity_batch(c12381_ctx* c, size_t n, const uint8_t* a576, uint8_t* out) {
@@ -910,8 +917,7 @@ int c12381_gt_is_unity_batch(c12381_ctx* c, size_t n, const uint8_t* a576, uint8
     else hipLaunchKernelGGL(gt3_is_unity_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, s.in0, s.out);
     HIPCK(c, hipGetLastError());
     if ((rc = stage_out(c, s, out, n))) return rc;
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return read_flag(c);
 }
 
 // Fixed-base tables (fixed_base.hpp): make sure slot `slot` holds the table of the point at `d_base`; everything is
@@ -1104,7 +1110,7 @@ int c12381_bbs_plus_verify_batch_dev(c12381_ctx* c, size_t n, size_t nmsg, const
         if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
         hipLaunchKernelGGL(pair3_prod_fixed_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, A_96, d_b,
                            (const int32_t*)c->ws[c12381_ctx::WS_FQ_W] + FB_HEADER_DWORDS, (const int32_t*)c->ws[c12381_ctx::WS_FQ_G] + FB_HEADER_DWORDS, ok,
-                           c->d_flag, st, fl, ct, gate_generic);
+                           c->d_flag, st, fl, ct, gate_generic, pair_spin_limit());
         HIPCK(c, hipGetLastError());
     }
     return launch_pair_eq(c, n, A_96, d_q, d_b, g2_192, (size_t)0, ok, gate_generic);
@@ -1200,7 +1206,7 @@ int c12381_bbs_plus_verify_aggregate_dev(c12381_ctx* c, size_t n, size_t nmsg, c
     if ((rc = pair_queue_setup(c, 1, st, fl, ct, blocks))) return rc;
     hipLaunchKernelGGL(pair3_prod_fixed_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, (size_t)1, (const uint8_t*)p1, (const uint8_t*)p2,
                        (const int32_t*)c->ws[c12381_ctx::WS_FQ_W] + FB_HEADER_DWORDS, (const int32_t*)c->ws[c12381_ctx::WS_FQ_G] + FB_HEADER_DWORDS, all_ok,
-                       c->d_flag, st, fl, ct, (const int32_t*)gate);
+                       c->d_flag, st, fl, ct, (const int32_t*)gate, pair_spin_limit());
     HIPCK(c, hipGetLastError());
     return 0;
 }

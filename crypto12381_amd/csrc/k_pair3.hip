@@ -62,6 +62,35 @@ __device__ __forceinline__ void st_load(T& x, const uint4* rows, unsigned lane) 
     for (int r = 0; r < ROWS; ++r) { const uint4 v = rows[(size_t)r * 64 + lane]; w[4 * r] = (int32_t)v.x; w[4 * r + 1] = (int32_t)v.y; w[4 * r + 2] = (int32_t)v.z; w[4 * r + 3] = (int32_t)v.w; }
 }
 
+// ---- hand-over protocol of the work queue.  flags[g] = number of finished phases of group g, bit 31 = the group is
+// POISONED: a wavefront gave up waiting for its predecessor (bounded spin), so the group's state is not to be trusted.
+// A poisoned task skips its arithmetic and passes the mark on (successors then start at once instead of spinning
+// through their own bound), the last phase writes 0xff to every output of the group and raises bad_flag[1], which the
+// host reports as C12381_E_INTERNAL — a library-internal failure never looks like valid output or like a bad input point.
+// Publishing is an atomic max, so a predecessor that was merely slow cannot clear the mark afterwards.
+constexpr unsigned int Q_POISON = 0x80000000u;
+// spin_limit < 0 (tests only, C12381_PAIR_SPIN_LIMIT): every wait is treated as timed out
+__device__ __forceinline__ bool queue_wait(unsigned int* flags, size_t g, unsigned int p, int spin_limit) {
+    if (p == 0) return false;
+    int spins = 0;
+    for (;;) {
+        const unsigned int v = (unsigned int)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&flags[g], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
+        if (spin_limit < 0 || (v & Q_POISON)) return true;
+        if (v >= p) return false;
+        if (++spins > spin_limit) return true;
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
+__device__ __forceinline__ void queue_publish(unsigned int* flags, size_t g, unsigned int p, bool poisoned, unsigned lane) {
+    __threadfence();
+    if (lane == 0) __hip_atomic_fetch_max(&flags[g], (poisoned ? Q_POISON : 0u) | (p + 1u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void gt_poison(uint8_t* o576, int role) {
+    uint4* q = reinterpret_cast<uint4*>(o576 + (role == 0 ? 384 : (role == 1 ? 192 : 0)));
+#pragma unroll
+    for (int j = 0; j < 12; ++j) q[j] = make_uint4(~0u, ~0u, ~0u, ~0u);
+}
+
 }  // namespace
 
 namespace c12381 {
@@ -125,10 +154,11 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_kernel(size_t n, const uint
 // steps of the final exponentiation (f12t_final_exp_step) — handed out through one atomic counter to a grid that just
 // fills the machine; a wavefront that finishes takes the next task, so the tail is a tenth as long.  Tasks are numbered phase-major
 // and a task of phase p waits (spins on the group's flag) only for a task of phase p-1, which never waits for anything
-// of phase >= p: no cycle, every wavefront reaches the end of the queue.  The spin is bounded as a last line of defence.
+// of phase >= p: no cycle, every wavefront reaches the end of the queue.  The spin is bounded as a last line of defence
+// (queue_wait above: a time-out poisons the group instead of letting it run on stale state).
 template <bool EQ>
 __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, size_t b2_stride,
-                                                 uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, fp4& H) {
+                                                 uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit, fp4& H) {
     const unsigned lane = threadIdx.x & 63u;
     const unsigned trip = lane / 3u;
     tri t;
@@ -151,15 +181,14 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
         const size_t e = g * TRI_PER_WAVE + (lane == 63u ? TRI_PER_WAVE - 1 : trip);
         const bool active = lane < 63u && e < n;
         const size_t i = e < n ? e : n - 1;          // inactive lanes shadow the last element: same instruction stream
-        if (p > 0) {
-            int spins = 0;
-            while ((unsigned int)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&flags[g], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < p) {
-                __builtin_amdgcn_s_sleep(64);
-                if (++spins > (1 << 20)) { if (lane == 0) *bad_flag = 2; break; }
-            }
-        }
+        const bool poisoned = queue_wait(flags, g, p, spin_limit);
         uint4* st = state + g * (size_t)ROWS * 64;
-        if (p < MILLER_TASKS) {
+        if (poisoned) {
+            if (p == TASKS - 1 && active) {
+                bad_flag[1] = 1;
+                if (EQ) { if (t.role == 0) out[e] = 0xff; } else gt_poison(out + 576 * e, t.role);
+            }
+        } else if (p < MILLER_TASKS) {
             fp px, py, px2, py2; fp2 qx, qy, qx2, qy2; bool pinf, qinf, pinf2 = true, qinf2 = true, ok, okb = true;
             pair_inputs(px, py, pinf, qx, qy, qinf, ok, a1 + 96 * i, a2 + 192 * i);
             if (!ok) { pinf = true; qinf = true; }
@@ -226,22 +255,21 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
                 }
             }
         }
-        __threadfence();
-        if (lane == 0) __hip_atomic_store(&flags[g], p + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        queue_publish(flags, g, p, poisoned, lane);
     }
 }
 
 __global__ void __launch_bounds__(BLOCK, 2) pair3_queue_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag, uint4* state,
-                                                            unsigned int* flags, unsigned int* counter) {
+                                                            unsigned int* flags, unsigned int* counter, int spin_limit) {
     __shared__ fp4_slot slots[BLOCK];
-    pair3_queue_body<false>(n, g1, g2, nullptr, nullptr, 0, gt, bad_flag, state, flags, counter, slots[threadIdx.x].v);
+    pair3_queue_body<false>(n, g1, g2, nullptr, nullptr, 0, gt, bad_flag, state, flags, counter, spin_limit, slots[threadIdx.x].v);
 }
 __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_queue_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2,
                                                                size_t b2_stride, uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags,
-                                                               unsigned int* counter, const int32_t* skip_if) {
+                                                               unsigned int* counter, const int32_t* skip_if, int spin_limit) {
     if (skip_if && skip_if[HDR_VALID] != 0) return;
     __shared__ fp4_slot slots[BLOCK];
-    pair3_queue_body<true>(n, a1, a2, b1, b2, b2_stride, out, bad_flag, state, flags, counter, slots[threadIdx.x].v);
+    pair3_queue_body<true>(n, a1, a2, b1, b2, b2_stride, out, bad_flag, state, flags, counter, spin_limit, slots[threadIdx.x].v);
 }
 
 // ------------------------------------------------------------------ both G2 arguments fixed for the batch
@@ -278,7 +306,7 @@ __global__ void __launch_bounds__(BLOCK, 2) gate_and_kernel(int32_t* gate, const
 template <bool TWO>
 __device__ __forceinline__ void pair3_fixed_queue_body(size_t n, const uint8_t* a96, const uint8_t* c96, const int32_t* tabw, const int32_t* tabg,
                                                        uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter,
-                                                       bool table_ok, fp4& H) {
+                                                       int spin_limit, bool table_ok, fp4& H) {
     const unsigned lane = threadIdx.x & 63u;
     const unsigned trip = lane / 3u;
     tri t;
@@ -297,16 +325,10 @@ __device__ __forceinline__ void pair3_fixed_queue_body(size_t n, const uint8_t* 
         const size_t e = g * TRI_PER_WAVE + (lane == 63u ? TRI_PER_WAVE - 1 : trip);
         const bool active = lane < 63u && e < n;
         const size_t i = e < n ? e : n - 1;
-        if (p > 0) {
-            int spins = 0;
-            while ((unsigned int)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&flags[g], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < p) {
-                __builtin_amdgcn_s_sleep(64);
-                if (++spins > (1 << 20)) { if (lane == 0) *bad_flag = 2; break; }
-            }
-        }
+        const bool poisoned = queue_wait(flags, g, p, spin_limit);
         uint4* st = state + g * (size_t)ROWS * 64;
         fp ax, ay, cx, cy; bool ainf, cinf = true, oka, okc = true;
-        if (p < MILLER_TASKS || p == TASKS - 1) {
+        if (!poisoned && (p < MILLER_TASKS || p == TASKS - 1)) {
             g1_parse96(ax, ay, ainf, oka, a96 + 96 * i);
             if (!oka || !table_ok) ainf = true;
             if (TWO) {
@@ -314,7 +336,12 @@ __device__ __forceinline__ void pair3_fixed_queue_body(size_t n, const uint8_t* 
                 if (!okc) cinf = true;
             }
         }
-        if (p < MILLER_TASKS) {
+        if (poisoned) {
+            if (p == TASKS - 1 && active) {
+                bad_flag[1] = 1;
+                if (TWO) { if (t.role == 0) out[e] = 0xff; } else gt_poison(out + 576 * e, t.role);
+            }
+        } else if (p < MILLER_TASKS) {
             if (p == 0) f12t_one(H, t); else st_load<fp4, ST_ROWS_F>(H, st + ST_F * 64, lane);
             const int hi = 64 - 16 * (int)p, lo = hi - 15;
             if (TWO) miller3_range2_fixed(H, ax, ay, ainf, tabw, cx, cy, cinf, tabg, hi, lo, t);
@@ -349,22 +376,21 @@ __device__ __forceinline__ void pair3_fixed_queue_body(size_t n, const uint8_t* 
                 }
             }
         }
-        __threadfence();
-        if (lane == 0) __hip_atomic_store(&flags[g], p + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        queue_publish(flags, g, p, poisoned, lane);
     }
 }
 __global__ void __launch_bounds__(BLOCK, 2) pair3_prod_fixed_queue_kernel(size_t n, const uint8_t* a96, const uint8_t* c96, const int32_t* tabw,
                                                                        const int32_t* tabg, uint8_t* out, int* bad_flag, uint4* state,
-                                                                       unsigned int* flags, unsigned int* counter, const int32_t* run_if) {
+                                                                       unsigned int* flags, unsigned int* counter, const int32_t* run_if, int spin_limit) {
     if (run_if[HDR_VALID] == 0) return;
     __shared__ fp4_slot slots[BLOCK];
-    pair3_fixed_queue_body<true>(n, a96, c96, tabw, tabg, out, bad_flag, state, flags, counter, true, slots[threadIdx.x].v);
+    pair3_fixed_queue_body<true>(n, a96, c96, tabw, tabg, out, bad_flag, state, flags, counter, spin_limit, true, slots[threadIdx.x].v);
 }
 // gt[i] = e(P_i, Q) for ONE Q given by its coefficient table (header at `buf`, lines behind it)
 __global__ void __launch_bounds__(BLOCK, 2) pair3_fixed_queue_kernel(size_t n, const uint8_t* g1_96, const int32_t* buf, uint8_t* gt, int* bad_flag,
-                                                                  uint4* state, unsigned int* flags, unsigned int* counter) {
+                                                                  uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit) {
     __shared__ fp4_slot slots[BLOCK];
-    pair3_fixed_queue_body<false>(n, g1_96, nullptr, buf + HDR_DWORDS, nullptr, gt, bad_flag, state, flags, counter, buf[HDR_VALID] != 0, slots[threadIdx.x].v);
+    pair3_fixed_queue_body<false>(n, g1_96, nullptr, buf + HDR_DWORDS, nullptr, gt, bad_flag, state, flags, counter, spin_limit, buf[HDR_VALID] != 0, slots[threadIdx.x].v);
 }
 
 // ------------------------------------------------------------------ split pairing and GT arithmetic on triples

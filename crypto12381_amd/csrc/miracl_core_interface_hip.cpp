@@ -17,6 +17,7 @@
 #include <crypto12381/miracl_core_interface.hpp>
 
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -28,13 +29,22 @@ namespace {
 using crypto12381::detail::chunk_t;
 namespace mc = crypto12381::detail::miracl_core;
 
+// one context per host thread, created on first use and destroyed when the thread exits
+struct thread_ctx {
+    c12381_ctx* p = nullptr;
+    thread_ctx() {
+        if (c12381_create(0, &p) != 0) {                    // no CPU fallback
+            std::fprintf(stderr, "crypto12381 HIP backend: no usable HIP device (c12381_create failed)\n");
+            std::abort();
+        }
+    }
+    ~thread_ctx() { if (p) c12381_destroy(p); }
+    thread_ctx(const thread_ctx&) = delete;
+    thread_ctx& operator=(const thread_ctx&) = delete;
+};
 c12381_ctx* ctx() {
-    thread_local c12381_ctx* c = [] {
-        c12381_ctx* p = nullptr;
-        if (c12381_create(0, &p) != 0) std::abort();        // no CPU fallback
-        return p;
-    }();
-    return c;
+    thread_local thread_ctx t;
+    return t.p;
 }
 inline uint8_t* raw(mc::point1& p) { return reinterpret_cast<uint8_t*>(&p); }
 inline uint8_t* raw(mc::point2& p) { return reinterpret_cast<uint8_t*>(&p); }
@@ -88,7 +98,15 @@ void big48(uint8_t out[48], const chunk_t (&k)[7]) {
     }
     for (int i = 0; i < 6; ++i) for (int j = 0; j < 8; ++j) out[47 - (8 * i + j)] = (uint8_t)(w[i] >> (8 * j));
 }
-inline void ck(int rc) { (void)rc; }                   // boundary functions are noexcept and total
+// The seam is noexcept and total: it has no way to report a failed call, and a caller that carried on with an unchanged
+// or poisoned POD would sign / verify garbage.  Every failure of the backend (HIP error, out of memory, a point that
+// is not on the curve — impossible for PODs that came through from_bytes —, an internal time-out) therefore ends the
+// process with a message, exactly like a missing device does in ctx().
+inline void ck(int rc) {
+    if (rc == 0) return;
+    std::fprintf(stderr, "crypto12381 HIP backend: call failed with code %d (%s)\n", rc, c12381_last_error(ctx()));
+    std::abort();
+}
 
 const char* G1_GEN_HEX =
     "17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb"

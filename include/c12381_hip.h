@@ -43,7 +43,9 @@ enum {
     C12381_E_ARG = -1,      /* bad argument (null pointer, unknown format or op) */
     C12381_E_HIP = -2,      /* HIP runtime error; see c12381_last_error */
     C12381_E_POINT = -3,    /* at least one input point is not on the curve (its output is all 0xff) */
-    C12381_E_NOMEM = -4
+    C12381_E_NOMEM = -4,
+    C12381_E_INTERNAL = -5  /* library-internal failure (a work-queue hand-over between wavefronts timed out); the
+                               affected outputs are all 0xff, never stale values; see c12381_last_error */
 };
 
 /* context -------------------------------------------------------------------------------- */
@@ -52,8 +54,9 @@ void c12381_destroy(c12381_ctx* ctx);
 const char* c12381_last_error(const c12381_ctx* ctx);
 /* use an existing hipStream_t (passed as void*) for all work of this context; NULL = own stream */
 int c12381_set_stream(c12381_ctx* ctx, void* hip_stream);
-/* wait for the context's stream; returns C12381_E_POINT if any kernel since the last sync saw an
- * invalid input point */
+/* wait for the context's stream; returns C12381_E_INTERNAL / C12381_E_POINT if any kernel since the last
+ * status read (every host entry point and every c12381_sync reads and clears the status) raised one:
+ * callers of _dev entry points separate logical operations with c12381_sync() */
 int c12381_sync(c12381_ctx* ctx);
 /* Per-kernel timing with HIP events on the context's stream (used by bench.py for the roofline
  * figure).  enable != 0 starts a fresh recording; kind: 0 = G1 scalar-mul kernel, 1 = G1 finish

@@ -178,3 +178,48 @@ def test_two_host_threads_two_contexts():
     ta.start(); tb.start(); ta.join(); tb.join()
     assert not errors, errors
     assert n > 0
+
+
+POISON_CODE = r"""
+import ctypes, sys
+sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+from util import cat, golden
+from crypto12381_amd import Context
+from crypto12381_amd.capi import _p, E_INTERNAL
+c = Context(0)
+g = golden('pairing')
+g1, g2 = cat(g['g1']), cat(g['g2'])
+n = len(g1) // 96
+# pairings: every hand-over of the work queue "times out" (C12381_PAIR_SPIN_LIMIT=-1): status E_INTERNAL, outputs poisoned
+out = ctypes.create_string_buffer(576 * n)
+rc = c.lib.c12381_pair_batch(c.h, n, _p(g1), _p(g2), _p(out))
+assert rc == E_INTERNAL, rc
+assert out.raw == b'\xff' * (576 * n), 'outputs of a failed hand-over must be poisoned'
+assert b'internal' in c.lib.c12381_last_error(c.h)
+# the status is cleared by the read: an operation that does not use the queue succeeds afterwards
+gg = golden('g1')
+assert c.g1_mul(cat(gg['points']), cat(gg['scalars']), 49) == cat(gg['mul49'])
+# boolean form
+m = len(g['eq'])
+ok = ctypes.create_string_buffer(m)
+rc = c.lib.c12381_pair_eq_batch(c.h, m, _p(cat(g['eq_a1'])), _p(cat(g['eq_a2'])), _p(cat(g['eq_b1'])), _p(cat(g['eq_b2'])), _p(ok))
+assert rc == E_INTERNAL and ok.raw == b'\xff' * m, (rc, ok.raw)
+# one fixed G2 argument
+rc = c.lib.c12381_pair_fixed_g2_batch(c.h, n, _p(g1), _p(g2[:192]), _p(out))
+assert rc == E_INTERNAL and out.raw == b'\xff' * (576 * n), rc
+c.close()
+print('poison ok')
+"""
+
+
+def test_queue_timeout_is_an_internal_error_with_poisoned_outputs():
+    """k_pair3.hip queue_wait: a hand-over that times out must not surface as 'invalid point' with plausible bytes.  The
+    branch is forced in a child process (negative spin limit = every wait fails; queue forced on for a small batch)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update({"C12381_PAIR_SPIN_LIMIT": "-1", "C12381_PAIR_QUEUE": "1"})
+    r = subprocess.run([sys.executable, "-c", POISON_CODE], env=e, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "poison ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
