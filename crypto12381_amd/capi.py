@@ -231,6 +231,9 @@ class Context:
     def g1_mul_fixed_dev(self, n, base_ptr, sc_ptr, out_ptr, fmt=49):
         self._ck(self.lib.c12381_g1_mul_fixed_batch_dev(self.h, n, _p(base_ptr), _p(sc_ptr), _p(out_ptr), fmt))
 
+    def g2_mul_fixed_dev(self, n, base_ptr, sc_ptr, out_ptr, fmt=97):
+        self._ck(self.lib.c12381_g2_mul_fixed_batch_dev(self.h, n, _p(base_ptr), _p(sc_ptr), _p(out_ptr), fmt))
+
     def g1_map_to_point(self, u48: bytes) -> bytes:
         n = len(u48) // 48
         out = ctypes.create_string_buffer(max(96 * n, 1))

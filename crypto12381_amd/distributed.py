@@ -44,3 +44,28 @@ def msm_sharded(local_msm: Callable[[bytes, bytes, int], bytes], pts_shard: byte
         gathered = b"".join(bytes(p.cpu().numpy().tobytes()) for p in parts)
     one = (1).to_bytes(32, "big")
     return local_msm(gathered, one * (len(gathered) // 96), out_fmt)
+
+
+def msm_sharded_tensors(local_msm_t: Callable[[torch.Tensor, torch.Tensor, int], torch.Tensor], pts_shard: torch.Tensor,
+                        scalars_shard: torch.Tensor, out_fmt: int = 49, group=None) -> torch.Tensor:
+    """Device-resident form of msm_sharded: the partial point never visits the host.
+
+    local_msm_t(points96 uint8 tensor, scalars32 uint8 tensor, fmt) -> uint8 tensor of fmt bytes on the same device
+    (on the GPU box: c12381_g1_msm_dev on the context's stream; the CPU tests inject the oracle on CPU tensors).
+    The exchange is ONE all_gather_into_tensor of 96 B per rank on the tensors' own device — RCCL over xGMI when the
+    process group is "nccl" —, the combine is the local product of the N partial points with unit scalars, again
+    through local_msm_t, so every rank ends with the same bytes."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    dev = pts_shard.device
+    if pts_shard.numel():
+        partial = local_msm_t(pts_shard, scalars_shard, 96)
+    else:
+        partial = torch.zeros(96, dtype=torch.uint8, device=dev)          # empty shard: the point at infinity
+    if world == 1:
+        gathered = partial
+    else:
+        gathered = torch.empty(96 * world, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(gathered, partial.contiguous(), group=group)
+    ones = torch.zeros(world, 32, dtype=torch.uint8, device=dev)
+    ones[:, 31] = 1
+    return local_msm_t(gathered, ones.reshape(-1), out_fmt)

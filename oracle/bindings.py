@@ -139,6 +139,37 @@ class Oracle:
         self._ck(self._f("pair_batch")(_sz(n), g1, g2, o, nthreads), "pair_batch")
         return o.raw[:576 * n]
 
+    def miller_t(self, g1: bytes, g2: bytes, nthreads: int = 1) -> bytes:
+        n = len(g1) // 96
+        o = self._buf(576 * n)
+        self._ck(self._f("miller_batch_t")(_sz(n), g1, g2, o, nthreads), "miller_batch_t"); return o.raw[:576 * n]
+
+    def fexp_t(self, f: bytes, nthreads: int = 1) -> bytes:
+        n = len(f) // 576
+        o = self._buf(576 * n)
+        self._ck(self._f("fexp_batch_t")(_sz(n), f, o, nthreads), "fexp_batch_t"); return o.raw[:576 * n]
+
+    def bbs_plus_verify(self, g1: bytes, g2: bytes, h0: bytes, h: bytes, w: bytes, A: bytes, x: bytes, r: bytes, m: bytes, nthreads: int = 1) -> bytes:
+        """examples/bbs-plus/src/bbs+.cpp:57-73 per signature; m is message-major (block i of signature j at (i*n + j)*32)"""
+        n, nmsg = len(A) // 96, len(h) // 96
+        o = self._buf(n)
+        self._ck(self._f("bbs_plus_verify_batch")(_sz(n), _sz(nmsg), g1, g2, h0, h, w, A, x, r, m, o, nthreads), "bbs_plus_verify_batch")
+        return o.raw[:n]
+
+    def bbs_plus_verify_wire(self, g1_g2_h0: bytes, h49: bytes, pk97: bytes, sigs145: bytes, msgs: bytes, msg_len: int, nthreads: int = 1) -> bytes:
+        """the same from the serialized forms: pp.g1_g2_h0 (195 B), pp.h (49 B each), pk (97 B), signatures (145 B), raw messages"""
+        n, nh = len(sigs145) // 145, len(h49) // 49
+        o = self._buf(n)
+        self._ck(self._f("bbs_plus_verify_wire_batch")(_sz(n), _sz(nh), _sz(msg_len), g1_g2_h0, h49, pk97, sigs145, msgs, o, nthreads),
+                 "bbs_plus_verify_wire_batch")
+        return o.raw[:n]
+
+    def encode_to_zp(self, msg: bytes) -> bytes:
+        """encode_to<Zp> (zp_number.hpp:1011-1037): 31-byte units -> 32-byte scalars"""
+        nblk = (len(msg) + 30) // 31
+        o = self._buf(32 * nblk)
+        self._ck(self._f("encode_to_zp")(_sz(len(msg)), msg, o), "encode_to_zp"); return o.raw[:32 * nblk]
+
     def miller(self, g1: bytes, g2: bytes) -> bytes:
         n = len(g1) // 96
         o = self._buf(576 * n)

@@ -922,6 +922,139 @@ int orc_gt_op_batch(int op, size_t n, const uint8_t* a576, const uint8_t* b, uin
     return 0;
 }
 
+static int zr_geq_fwd(const uint64_t* a) { for (int i = 3; i >= 0; i--) { if (a[i] > RORD[i]) return 1; if (a[i] < RORD[i]) return 0; } return 1; }
+/* threaded forms of the split pairing (CPU baselines) */
+static void miller_range(size_t lo, size_t hi, void* c) {
+    pair_ctx* m = (pair_ctx*)c;
+    for (size_t i = lo; i < hi; i++) {
+        g1p P; g2p Q; fp12 f;
+        if (!g1_load96(&P, m->a1 + 96 * i) || !g2_load192(&Q, m->a2 + 192 * i)) { m->bad = 1; continue; }
+        pair_ate(&f, &Q, &P);
+        fp12_to_bytes(m->out + 576 * i, &f);
+    }
+}
+int orc_miller_batch_t(size_t n, const uint8_t* g1_96, const uint8_t* g2_192, uint8_t* out576, int nthreads) {
+    INIT();
+    pair_ctx m = {g1_96, g2_192, NULL, NULL, out576, 0};
+    par_for(n, nthreads, miller_range, &m);
+    return m.bad ? -2 : 0;
+}
+static void fexp_range(size_t lo, size_t hi, void* c) {
+    pair_ctx* m = (pair_ctx*)c;
+    for (size_t i = lo; i < hi; i++) { fp12 f; fp12_from_bytes(&f, m->a1 + 576 * i); pair_fexp(&f); fp12_to_bytes(m->out + 576 * i, &f); }
+}
+int orc_fexp_batch_t(size_t n, const uint8_t* in576, uint8_t* out576, int nthreads) {
+    INIT();
+    pair_ctx m = {in576, NULL, NULL, NULL, out576, 0};
+    par_for(n, nthreads, fexp_range, &m);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ BBS+ verification
+ * examples/bbs-plus/src/bbs+.cpp:57-73:  pair(A, w * (g2^x)) == pair(g1 * (h0^r) * Π[n](h[i]^m[i]), g2), evaluated with the
+ * boundary's operations: multiply (PAIR_G2mul / PAIR_G1mul), add, and pair == pair as liner_pair.hpp:339-350 (two PAIR_ate,
+ * FP12_conj, FP12_mul, one PAIR_fexp, FP12_isunity).  Messages message-major: block i of signature j at m32[(i * n + j) * 32]. */
+typedef struct {
+    size_t n, nmsg; g1p G1p, H0; g1p* H; g2p G2p, W;
+    const uint8_t *A, *x, *r, *m; uint8_t* ok;
+    /* wire form */
+    const uint8_t *sig, *msgs; size_t msg_len;
+} bbs_ctx;
+static int bbs_verify_one(const bbs_ctx* b, const g1p* A, const uint64_t x[4], const uint64_t r[4], const uint64_t (*m)[4]) {
+    g2p Q = b->G2p; g2_mul(&Q, x);
+    g2p Wc = b->W; g2_add(&Wc, &Q);
+    g1p B = b->G1p, T = b->H0;
+    g1_mul(&T, r); g1_add(&B, &T);
+    for (size_t i = 0; i < b->nmsg; i++) { g1p Hi = b->H[i]; g1_mul(&Hi, m[i]); g1_add(&B, &Hi); }
+    fp12 f, g, gc;
+    pair_ate(&f, &Wc, A); pair_ate(&g, &b->G2p, &B);
+    fp12_conj(&gc, &g); fp12_mul(&f, &gc); pair_fexp(&f);
+    return fp12_is_unity(&f);
+}
+static void bbs_range(size_t lo, size_t hi, void* c) {
+    bbs_ctx* b = (bbs_ctx*)c;
+    uint64_t (*m)[4] = (uint64_t (*)[4])malloc((b->nmsg ? b->nmsg : 1) * sizeof *m);
+    for (size_t j = lo; j < hi; j++) {
+        g1p A; uint64_t x[4], r[4];
+        if (!g1_load96(&A, b->A + 96 * j)) { b->ok[j] = 0xff; continue; }
+        scalar_load(x, b->x + 32 * j); scalar_load(r, b->r + 32 * j);
+        for (size_t i = 0; i < b->nmsg; i++) scalar_load(m[i], b->m + 32 * (i * b->n + j));
+        b->ok[j] = (uint8_t)bbs_verify_one(b, &A, x, r, (const uint64_t (*)[4])m);
+    }
+    free(m);
+}
+int orc_bbs_plus_verify_batch(size_t n, size_t nmsg, const uint8_t* g1_96, const uint8_t* g2_192, const uint8_t* h0_96, const uint8_t* h_96,
+                              const uint8_t* w_192, const uint8_t* A_96, const uint8_t* x32, const uint8_t* r32, const uint8_t* m32,
+                              uint8_t* ok, int nthreads) {
+    INIT();
+    bbs_ctx b; memset(&b, 0, sizeof b);
+    b.n = n; b.nmsg = nmsg; b.A = A_96; b.x = x32; b.r = r32; b.m = m32; b.ok = ok;
+    if (!g1_load96(&b.G1p, g1_96) || !g1_load96(&b.H0, h0_96) || !g2_load192(&b.G2p, g2_192) || !g2_load192(&b.W, w_192)) return -2;
+    b.H = (g1p*)malloc((nmsg ? nmsg : 1) * sizeof *b.H);
+    for (size_t i = 0; i < nmsg; i++) if (!g1_load96(&b.H[i], h_96 + 96 * i)) { free(b.H); return -2; }
+    par_for(n, nthreads, bbs_range, &b);
+    free(b.H);
+    return 0;
+}
+/* wire formats (see ref_wrap.cpp ref_bbs_plus_verify_wire_batch for the citations): parse<G1>/<G2> = leading 0x00 -> infinity,
+ * else ECP_fromOctet / ECP2_fromOctet; parse<Zp> = 48 big-endian bytes below r; encode_to<Zp> = 31-byte units behind a 0x01 byte */
+static int wire_g1(g1p* P, const uint8_t* s) {
+    if (s[0] == 0) { g1_inf(P); return 1; }
+    if (s[0] != 0x02 && s[0] != 0x03) return 0;             /* a 49-byte view cannot hold the 0x04 form */
+    fp x; fp_from_bytes(&x, s + 1); return g1_setx(P, &x, s[0] & 1);
+}
+static int wire_g2(g2p* P, const uint8_t* s) {
+    if (s[0] == 0) { g2_inf(P); return 1; }
+    if (s[0] == 0x04) return 0;
+    fp2 x; fp2_from_bytes(&x, s + 1); return g2_setx(P, &x, s[0] & 1);
+}
+static int wire_zp(uint64_t k[4], const uint8_t* b48) {
+    for (int i = 0; i < 16; i++) if (b48[i]) return 0;       /* >= 2^256 > r */
+    for (int i = 0; i < 4; i++) { uint64_t w = 0; for (int j = 0; j < 8; j++) w = (w << 8) | b48[16 + (3 - i) * 8 + j]; k[i] = w; }
+    return !zr_geq_fwd(k);
+}
+static void encode_unit(uint64_t k[4], const uint8_t* msg, size_t msg_len, size_t i) {
+    uint8_t buf[32] = {0};
+    buf[0] = 1;
+    const size_t len = (i + 1) * 31 <= msg_len ? 31 : msg_len - i * 31;
+    memcpy(buf + 1, msg + 31 * i, len);
+    for (int w = 0; w < 4; w++) { uint64_t v = 0; for (int j = 0; j < 8; j++) v = (v << 8) | buf[(3 - w) * 8 + j]; k[w] = v; }
+}
+static void bbs_wire_range(size_t lo, size_t hi, void* c) {
+    bbs_ctx* b = (bbs_ctx*)c;
+    uint64_t (*m)[4] = (uint64_t (*)[4])malloc((b->nmsg ? b->nmsg : 1) * sizeof *m);
+    for (size_t j = lo; j < hi; j++) {
+        const uint8_t* s = b->sig + 145 * j;
+        g1p A; uint64_t x[4], r[4];
+        if (!wire_g1(&A, s) || !wire_zp(x, s + 49) || !wire_zp(r, s + 97)) { b->ok[j] = 0xff; continue; }
+        for (size_t i = 0; i < b->nmsg; i++) encode_unit(m[i], b->msgs + b->msg_len * j, b->msg_len, i);
+        b->ok[j] = (uint8_t)bbs_verify_one(b, &A, x, r, (const uint64_t (*)[4])m);
+    }
+    free(m);
+}
+int orc_bbs_plus_verify_wire_batch(size_t n, size_t nh, size_t msg_len, const uint8_t* g1_g2_h0_195, const uint8_t* h49, const uint8_t* pk97,
+                                   const uint8_t* sig145, const uint8_t* msgs, uint8_t* ok, int nthreads) {
+    INIT();
+    bbs_ctx b; memset(&b, 0, sizeof b);
+    const size_t nblk = (msg_len + 30) / 31;
+    if (nblk > nh) return -2;
+    b.n = n; b.nmsg = nblk; b.ok = ok; b.sig = sig145; b.msgs = msgs; b.msg_len = msg_len;
+    if (!wire_g1(&b.G1p, g1_g2_h0_195) || !wire_g2(&b.G2p, g1_g2_h0_195 + 49) || !wire_g1(&b.H0, g1_g2_h0_195 + 146) || !wire_g2(&b.W, pk97)) return -2;
+    b.H = (g1p*)malloc((nblk ? nblk : 1) * sizeof *b.H);
+    for (size_t i = 0; i < nblk; i++) if (!wire_g1(&b.H[i], h49 + 49 * i)) { free(b.H); return -2; }
+    par_for(n, nthreads, bbs_wire_range, &b);
+    free(b.H);
+    return 0;
+}
+int orc_encode_to_zp(size_t msg_len, const uint8_t* msg, uint8_t* out32) {
+    const size_t nblk = (msg_len + 30) / 31;
+    for (size_t i = 0; i < nblk; i++) {
+        uint64_t k[4]; encode_unit(k, msg, msg_len, i);
+        for (int w = 0; w < 4; w++) for (int j = 0; j < 8; j++) out32[32 * i + (3 - w) * 8 + j] = (uint8_t)(k[w] >> (8 * (7 - j)));
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------ hash-to-G1
  * G1Point::from_hash, include/crypto12381/g1_point.hpp:219-234, from the digest on:
  * ECP_map2point ecp_BLS12381.cpp:1495-1626 (simplified SWU on E' + 11-isogeny, hint-sharing FP_qr/FP_inv/FP_sqrt

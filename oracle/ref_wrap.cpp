@@ -508,4 +508,155 @@ int ref_zp_from_hash_batch(size_t n, const uint8_t* digests64, uint8_t* out32) {
     return 0;
 }
 
+
+// ---- threaded forms of the split pairing (CPU baselines of bench.py; same loops as ref_miller_batch / ref_fexp_batch)
+int ref_miller_batch_t(size_t n, const uint8_t* g1_96, const uint8_t* g2_192, uint8_t* out576, int nthreads) {
+    int bad = 0;
+    par_for(n, nthreads, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            mc::point1 P; mc::point2 Q; mc::fp12 f;
+            if (!g1_load(P, g1_96 + 96 * i) || !g2_load(Q, g2_192 + 192 * i)) { bad = 1; continue; }
+            mc::pair_ate(f, Q, P);
+            mc::bytes_view v{0, 576, (char*)out576 + 576 * i};
+            mc::to_bytes(v, f);
+        }
+    });
+    return bad ? -2 : 0;
+}
+int ref_fexp_batch_t(size_t n, const uint8_t* in576, uint8_t* out576, int nthreads) {
+    par_for(n, nthreads, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            mc::fp12 f; char buf[576];
+            std::memcpy(buf, in576 + 576 * i, 576);
+            mc::bytes_view vi{576, 576, buf};
+            mc::from_bytes(f, vi);
+            mc::pair_final_exponentiation(f);
+            mc::bytes_view vo{0, 576, (char*)out576 + 576 * i};
+            mc::to_bytes(vo, f);
+        }
+    });
+    return 0;
+}
+
+// ---- BBS+ verification, the reference's op sequence (examples/bbs-plus/src/bbs+.cpp:57-73) at boundary level:
+//   pair(A, w * (g2^x)) == pair(g1 * (h0^r) * Π[n](h[i]^m[i]), g2)
+// g2^x -> multiply(point2&, big); w * . -> add; h0^r, h[i]^m[i] -> multiply(point1&, big); products -> add;
+// == -> two pair_ate, conjugate, multiply, one final exponentiation, is_unity (liner_pair.hpp:339-350).
+// Messages are message-major: m32[(i * n + j) * 32] is block i of signature j (the layout of c12381_bbs_plus_verify_batch).
+static int bbs_verify_one(mc::point1& G1p, mc::point2& G2p, mc::point1& H0, std::vector<mc::point1>& H, mc::point2& W,
+                          mc::point1& A, const mc::big& x, const mc::big& r, const std::vector<mc::big>& m) {
+    mc::point2 Q = G2p;
+    mc::multiply(Q, x);
+    mc::point2 Wc = W;
+    mc::add(Wc, Q);                                    // w * g2^x
+    mc::point1 B = G1p, T = H0;
+    mc::multiply(T, r);
+    mc::add(B, T);
+    for (size_t i = 0; i < m.size(); ++i) {
+        mc::point1 Hi = H[i];
+        mc::multiply(Hi, m[i]);
+        mc::add(B, Hi);
+    }
+    mc::fp12 f, g, gc;
+    mc::point2 G2c = G2p;
+    mc::pair_ate(f, Wc, A);
+    mc::pair_ate(g, G2c, B);
+    mc::conjugate(gc, g);
+    mc::multiply(f, gc);
+    mc::pair_final_exponentiation(f);
+    return mc::is_unity(f) ? 1 : 0;
+}
+int ref_bbs_plus_verify_batch(size_t n, size_t nmsg, const uint8_t* g1_96, const uint8_t* g2_192, const uint8_t* h0_96, const uint8_t* h_96,
+                              const uint8_t* w_192, const uint8_t* A_96, const uint8_t* x32, const uint8_t* r32, const uint8_t* m32,
+                              uint8_t* ok, int nthreads) {
+    mc::point1 G1p, H0; mc::point2 G2p, W;
+    std::vector<mc::point1> H(nmsg);
+    if (!g1_load(G1p, g1_96) || !g1_load(H0, h0_96) || !g2_load(G2p, g2_192) || !g2_load(W, w_192)) return -2;
+    for (size_t i = 0; i < nmsg; ++i) if (!g1_load(H[i], h_96 + 96 * i)) return -2;
+    par_for(n, nthreads, [&](size_t lo, size_t hi) {
+        for (size_t j = lo; j < hi; ++j) {
+            mc::point1 A;
+            if (!g1_load(A, A_96 + 96 * j)) { ok[j] = 0xff; continue; }
+            mc::big x, r; std::vector<mc::big> m(nmsg);
+            scalar_from32(x, x32 + 32 * j); scalar_from32(r, r32 + 32 * j);
+            for (size_t i = 0; i < nmsg; ++i) scalar_from32(m[i], m32 + 32 * (i * n + j));
+            mc::point1 g = G1p, h0 = H0; mc::point2 g2 = G2p, w = W;
+            std::vector<mc::point1> h = H;
+            ok[j] = (uint8_t)bbs_verify_one(g, g2, h0, h, w, A, x, r, m);
+        }
+    });
+    return 0;
+}
+
+// ---- the same from the WIRE formats the example exchanges (bbs+.cpp:57-73 with the header layer's decoders restated):
+//   pp.g1_g2_h0 = serialize(g1, g2, h0) = 49 + 97 + 49 bytes, pp.h = 49 bytes each, pk = 97 bytes,
+//   signature = serialize(A, x, r) = 49 + 48 + 48 bytes, message = raw bytes.
+// parse<G1>/parse<G2> (g1_point.hpp:87-111, g2_point.hpp:71-95): leading 0x00 = infinity, otherwise from_bytes, failure throws;
+// parse<Zp> (zp_number.hpp:226-236): 48 big-endian bytes, value >= r throws;
+// encode_to<Zp> (zp_number.hpp:1011-1037): 31-byte units, byte 16 of the 48-byte field set to 1, a short last unit is
+// left-aligned in its 31 bytes; more units than h entries throws "message is too long".
+// ok[j] = 1 / 0 = the boolean verify() returns, 0xff = the reference would throw (malformed signature); return -2 when the
+// public material itself does not parse or the message is too long (verify() throws for every signature then).
+static int wire_g1(mc::point1& P, const uint8_t* b49) {
+    if (b49[0] == 0) { mc::get_infinity(P); return 1; }
+    char buf[49]; std::memcpy(buf, b49, 49);
+    mc::bytes_view v{49, 49, buf};
+    return mc::from_bytes(P, v);
+}
+static int wire_g2(mc::point2& P, const uint8_t* b97) {
+    if (b97[0] == 0) { mc::get_infinity(P); return 1; }
+    char buf[97]; std::memcpy(buf, b97, 97);
+    mc::bytes_view v{97, 97, buf};
+    return mc::from_bytes(P, v);
+}
+static int wire_zp(mc::big& k, const uint8_t* b48) {
+    mc::from_bytes(k, (const char*)b48);
+    mc::big order; BIG_rcopy(order, CURVE_Order);
+    return mc::compare(k, order) < 0;
+}
+int ref_bbs_plus_verify_wire_batch(size_t n, size_t nh, size_t msg_len, const uint8_t* g1_g2_h0_195, const uint8_t* h49, const uint8_t* pk97,
+                                   const uint8_t* sig145, const uint8_t* msgs, uint8_t* ok, int nthreads) {
+    mc::point1 G1p, H0; mc::point2 G2p, W;
+    const size_t nblk = (msg_len + 30) / 31;
+    if (nblk > nh) return -2;
+    std::vector<mc::point1> H(nblk);
+    if (!wire_g1(G1p, g1_g2_h0_195) || !wire_g2(G2p, g1_g2_h0_195 + 49) || !wire_g1(H0, g1_g2_h0_195 + 146) || !wire_g2(W, pk97)) return -2;
+    for (size_t i = 0; i < nblk; ++i) if (!wire_g1(H[i], h49 + 49 * i)) return -2;
+    par_for(n, nthreads, [&](size_t lo, size_t hi) {
+        for (size_t j = lo; j < hi; ++j) {
+            const uint8_t* s = sig145 + 145 * j;
+            mc::point1 A; mc::big x, r;
+            if (!wire_g1(A, s) || !wire_zp(x, s + 49) || !wire_zp(r, s + 97)) { ok[j] = 0xff; continue; }
+            std::vector<mc::big> m(nblk);
+            const uint8_t* msg = msgs + msg_len * j;
+            for (size_t i = 0; i < nblk; ++i) {
+                uint8_t buf[48] = {0};
+                buf[16] = 1;
+                const size_t len = (i + 1) * 31 <= msg_len ? 31 : msg_len - i * 31;
+                std::memcpy(buf + 17, msg + 31 * i, len);
+                mc::from_bytes(m[i], (const char*)buf);
+            }
+            mc::point1 g = G1p, h0 = H0; mc::point2 g2 = G2p, w = W;
+            std::vector<mc::point1> h = H;
+            ok[j] = (uint8_t)bbs_verify_one(g, g2, h0, h, w, A, x, r, m);
+        }
+    });
+    return 0;
+}
+// encode_to<Zp> alone (zp_number.hpp:1011-1037): msg_len bytes -> ceil(msg_len / 31) scalars of 32 bytes (the 48-byte field's low 32)
+int ref_encode_to_zp(size_t msg_len, const uint8_t* msg, uint8_t* out32) {
+    const size_t nblk = (msg_len + 30) / 31;
+    for (size_t i = 0; i < nblk; ++i) {
+        uint8_t buf[48] = {0};
+        buf[16] = 1;
+        const size_t len = (i + 1) * 31 <= msg_len ? 31 : msg_len - i * 31;
+        std::memcpy(buf + 17, msg + 31 * i, len);
+        mc::big k; char o[48];
+        mc::from_bytes(k, (const char*)buf);
+        mc::to_bytes(o, k);
+        std::memcpy(out32 + 32 * i, o + 16, 32);
+    }
+    return 0;
+}
+
 } // extern "C"

@@ -28,7 +28,16 @@ def _worker(rank, world, port, pts, sc, expect, q):
         orc = Oracle("port")
         res = msm_sharded(lambda p, s, fmt: orc.g1_msm(p, s, fmt, 1),
                           shard_bytes(pts, 96, rank, world), shard_bytes(sc, 32, rank, world), 49)
-        q.put((rank, res == expect))
+        # tensor form (the bench's strong-scaled MSM leg uses it with device tensors and the nccl backend)
+        import torch
+        from crypto12381_amd.distributed import msm_sharded_tensors
+
+        def local_t(p, s, fmt):
+            return torch.frombuffer(bytearray(orc.g1_msm(p.numpy().tobytes(), s.numpy().tobytes(), fmt, 1)), dtype=torch.uint8)
+        tp = torch.frombuffer(bytearray(shard_bytes(pts, 96, rank, world)), dtype=torch.uint8)
+        ts = torch.frombuffer(bytearray(shard_bytes(sc, 32, rank, world)), dtype=torch.uint8)
+        res_t = msm_sharded_tensors(local_t, tp, ts, 49).numpy().tobytes()
+        q.put((rank, res == expect and res_t == expect))
     finally:
         dist.destroy_process_group()
 
