@@ -12,6 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("C12381_LIB") or os.path.join(_HERE, "lib", "libc12381_hip.so")   # C12381_LIB: A/B builds of the same ABI
 
 E_ARG, E_HIP, E_POINT, E_NOMEM, E_INTERNAL = -1, -2, -3, -4, -5
+F_IN_SUBGROUP = 1
+F_MILLER_ONLY = 2
 
 
 class C12381Error(RuntimeError):
@@ -50,8 +52,16 @@ def load_library() -> ctypes.CDLL:
             getattr(lib, name).argtypes = [vp, sz, vp, vp, vp, ci]
         for name in ("c12381_g2_mul_batch", "c12381_g2_mul_batch_dev", "c12381_g2_add_batch"):
             getattr(lib, name).argtypes = [vp, sz, vp, vp, vp, ci]
+        for name in ("c12381_g1_sum_of_products", "c12381_g1_sum_of_products_dev"):
+            getattr(lib, name).argtypes = [vp, sz, vp, vp, vp, ci]
+        for name in ("c12381_g2_msm", "c12381_g2_msm_dev"):
+            getattr(lib, name).argtypes = [vp, sz, vp, vp, vp, ci]
+        for name in ("c12381_g1_mul_batch_flags", "c12381_g1_mul_batch_flags_dev", "c12381_g2_mul_batch_flags", "c12381_g2_mul_batch_flags_dev"):
+            getattr(lib, name).argtypes = [vp, sz, vp, vp, vp, ci, ctypes.c_uint]
         for name in ("c12381_pair_batch", "c12381_pair_batch_dev"):
             getattr(lib, name).argtypes = [vp, sz, vp, vp, vp]
+        for name in ("c12381_pair_product_batch", "c12381_pair_product_batch_dev"):
+            getattr(lib, name).argtypes = [vp, sz, ci, vp, vp, vp, ctypes.c_uint]
         for name in ("c12381_pair_eq_batch", "c12381_pair_eq_batch_dev"):
             getattr(lib, name).argtypes = [vp, sz, vp, vp, vp, vp, vp]
         for name in ("c12381_g1_decompress_batch", "c12381_g2_decompress_batch"):
@@ -80,6 +90,8 @@ def load_library() -> ctypes.CDLL:
             getattr(lib, name).argtypes = [vp, sz, vp, vp, vp]
         for name in ("c12381_bbs_plus_verify_batch", "c12381_bbs_plus_verify_batch_dev"):
             getattr(lib, name).argtypes = [vp, sz, sz] + [vp] * 10
+        for name in ("c12381_bbs_plus_verify_wire_batch", "c12381_bbs_plus_verify_wire_batch_dev"):
+            getattr(lib, name).argtypes = [vp, sz, sz, sz] + [vp] * 6
         for name in ("c12381_bbs_plus_verify_aggregate", "c12381_bbs_plus_verify_aggregate_dev"):
             getattr(lib, name).argtypes = [vp, sz, sz] + [vp] * 11
         _lib = lib
@@ -153,6 +165,24 @@ class Context:
         self._ck(self.lib.c12381_g1_mul_batch(self.h, n, _p(pts), _p(scalars), _p(out), fmt), allow_point=not strict)
         return out.raw[:fmt * n]
 
+    def g1_mul_flags(self, pts: bytes, scalars: bytes, fmt: int = 49, flags: int = 0) -> bytes:
+        n = len(pts) // 96
+        out = ctypes.create_string_buffer(max(fmt * n, 1))
+        self._ck(self.lib.c12381_g1_mul_batch_flags(self.h, n, _p(pts), _p(scalars), _p(out), fmt, flags))
+        return out.raw[:fmt * n]
+
+    def g2_mul_flags(self, pts: bytes, scalars: bytes, fmt: int = 97, flags: int = 0) -> bytes:
+        n = len(pts) // 192
+        out = ctypes.create_string_buffer(max(fmt * n, 1))
+        self._ck(self.lib.c12381_g2_mul_batch_flags(self.h, n, _p(pts), _p(scalars), _p(out), fmt, flags))
+        return out.raw[:fmt * n]
+
+    def g1_mul_flags_dev(self, n, pts_ptr, sc_ptr, out_ptr, fmt=49, flags=0):
+        self._ck(self.lib.c12381_g1_mul_batch_flags_dev(self.h, n, _p(pts_ptr), _p(sc_ptr), _p(out_ptr), fmt, flags))
+
+    def g2_mul_flags_dev(self, n, pts_ptr, sc_ptr, out_ptr, fmt=97, flags=0):
+        self._ck(self.lib.c12381_g2_mul_batch_flags_dev(self.h, n, _p(pts_ptr), _p(sc_ptr), _p(out_ptr), fmt, flags))
+
     def g1_add(self, a: bytes, b: bytes, fmt: int = 96, strict: bool = True) -> bytes:
         n = len(a) // 96
         out = ctypes.create_string_buffer(max(fmt * n, 1))
@@ -171,6 +201,18 @@ class Context:
         self._ck(self.lib.c12381_g2_mul_batch(self.h, n, _p(pts), _p(scalars), _p(out), fmt), allow_point=not strict)
         return out.raw[:fmt * n]
 
+    def g1_sum_of_products(self, pts: bytes, scalars: bytes, fmt: int = 49) -> bytes:
+        n = len(pts) // 96
+        out = ctypes.create_string_buffer(fmt)
+        self._ck(self.lib.c12381_g1_sum_of_products(self.h, n, _p(pts) if n else None, _p(scalars) if n else None, _p(out), fmt))
+        return out.raw[:fmt]
+
+    def g2_msm(self, pts: bytes, scalars: bytes | None, fmt: int = 97) -> bytes:
+        n = len(pts) // 192
+        out = ctypes.create_string_buffer(fmt)
+        self._ck(self.lib.c12381_g2_msm(self.h, n, _p(pts) if n else None, _p(scalars) if scalars else None, _p(out), fmt))
+        return out.raw[:fmt]
+
     def g2_add(self, a: bytes, b: bytes, fmt: int = 192, strict: bool = True) -> bytes:
         n = len(a) // 192
         out = ctypes.create_string_buffer(max(fmt * n, 1))
@@ -181,6 +223,13 @@ class Context:
         n = len(g1) // 96
         out = ctypes.create_string_buffer(max(576 * n, 1))
         self._ck(self.lib.c12381_pair_batch(self.h, n, _p(g1), _p(g2), _p(out)), allow_point=not strict)
+        return out.raw[:576 * n]
+
+    def pair_product(self, g1s: bytes, g2s: bytes, k: int, flags: int = 0) -> bytes:
+        """g1s / g2s: k argument-major arrays of n points; returns n GT (or Miller) values"""
+        n = len(g1s) // (96 * k)
+        out = ctypes.create_string_buffer(max(576 * n, 1))
+        self._ck(self.lib.c12381_pair_product_batch(self.h, n, k, _p(g1s), _p(g2s), _p(out), flags))
         return out.raw[:576 * n]
 
     def pair_fixed_g2(self, g1: bytes, g2_one: bytes, strict: bool = True) -> bytes:
@@ -300,6 +349,14 @@ class Context:
         out = ctypes.create_string_buffer(max(n, 1))
         self._ck(self.lib.c12381_bbs_plus_verify_batch(self.h, n, nmsg, _p(g1), _p(g2), _p(h0), _p(h) if nmsg else None, _p(w), _p(A),
                                                        _p(x), _p(r), _p(m) if nmsg else None, _p(out)), allow_point=not strict)
+        return out.raw[:n]
+
+    def bbs_plus_verify_wire(self, g1_g2_h0: bytes, h49: bytes, pk97: bytes, sigs145: bytes, msgs: bytes, msg_len: int, strict: bool = True) -> bytes:
+        """serialized public parameters / key / signatures (49 + 48 + 48 B) and raw messages in, one byte per signature out"""
+        n, nh = len(sigs145) // 145, len(h49) // 49
+        out = ctypes.create_string_buffer(max(n, 1))
+        self._ck(self.lib.c12381_bbs_plus_verify_wire_batch(self.h, n, nh, msg_len, _p(g1_g2_h0), _p(h49) if nh else None, _p(pk97), _p(sigs145),
+                                                            _p(msgs) if msg_len else None, _p(out)), allow_point=not strict)
         return out.raw[:n]
 
     def bbs_plus_verify_aggregate(self, g1: bytes, g2: bytes, h0: bytes, h: bytes, w: bytes, A: bytes, x: bytes, r: bytes, m: bytes,

@@ -43,7 +43,7 @@ struct c12381_ctx {
     hipEvent_t ev_side = nullptr;
     std::vector<hipEvent_t> ev_chunk;     // one per chunk of a scalar-mul batch (main -> side dependencies)
     char err[256] = {0};
-    enum { WS_TAB, WS_PROJ, WS_PREF, WS_IN0, WS_IN1, WS_OUT, WS_RED0, WS_RED1, WS_BBS_Q, WS_BBS_B, WS_BBS_IN,
+    enum { WS_TAB, WS_PROJ, WS_PREF, WS_IN0, WS_IN1, WS_OUT, WS_RED0, WS_RED1, WS_BBS_Q, WS_BBS_B, WS_BBS_IN, WS_BBS_WIRE, WS_BBS_WIRE_IN,
            WS_PAIR_ST, WS_FQ_W, WS_FQ_G, WS_FQ_GATE, WS_FQ_P, WS_FB_G2, WS_FB_G1_0, WS_FB_G1_1, WS_FB_G1_2, WS_FB_G1_3, WS_MSM_PTS, WS_MSM_K0, WS_MSM_K1, WS_MSM_V0, WS_MSM_V1, WS_MSM_TMP, WS_MSM_RNG, WS_MSM_BK, WS_MSM_ORD, WS_MSM_OVF, WS_COUNT };
     void* ws[WS_COUNT] = {nullptr};
     size_t ws_bytes[WS_COUNT] = {0};
@@ -95,8 +95,10 @@ struct timed {
 
 // scalar multiplication of n elements into the projective SoA workspace (stride = padded n)
 // (results land at proj[proj_off + i]; pt_stride 96 = per-lane points, 0 = one broadcast point)
+// in_g1: the caller asserts every point lies in G1 (C12381_F_IN_SUBGROUP): the [r]phi(P) terms of scalars below x^2 are then
+// the point at infinity and the fix-up pass — a membership test as long as a scalar multiplication per such lane — is not launched
 int g1_mul_to_proj(c12381_ctx* c, size_t n, const uint8_t* d_pts, const uint8_t* d_sc, size_t stride, size_t pt_stride = 96,
-                   size_t proj_off = 0, const int32_t* skip_if = nullptr) {
+                   size_t proj_off = 0, const int32_t* skip_if = nullptr, bool in_g1 = false) {
     const size_t chunk = n < G1_CHUNK ? round_up(n, 64) : G1_CHUNK;
     int rc;
     if ((rc = ensure(c, c12381_ctx::WS_TAB, (size_t)G1_TAB_DWORDS * chunk * 4))) return rc;
@@ -111,6 +113,7 @@ int g1_mul_to_proj(c12381_ctx* c, size_t n, const uint8_t* d_pts, const uint8_t*
         }
         // the reference's small-scalar term (g1.hpp) for this chunk: empty unless some k mod r < x^2, and then a few lanes
         // at single-wavefront latency (~1 ms) — on the side stream, so it overlaps the next chunk
+        if (in_g1) continue;
         const size_t ci = off / chunk;
         while (c->ev_chunk.size() <= ci) {
             hipEvent_t e;
@@ -123,6 +126,7 @@ int g1_mul_to_proj(c12381_ctx* c, size_t n, const uint8_t* d_pts, const uint8_t*
                            (int32_t*)c->ws[c12381_ctx::WS_PROJ], stride, proj_off + off, skip_if);
         HIPCK(c, hipGetLastError());
     }
+    if (in_g1) return 0;
     HIPCK(c, hipEventRecord(c->ev_side, c->side));
     HIPCK(c, hipStreamWaitEvent(c->stream, c->ev_side, 0));
     return 0;
@@ -398,23 +402,29 @@ int c12381_fp_mulchain_dev(c12381_ctx* c, size_t n, int iters, const uint8_t* a,
 }
 
 // ---------------------------------------------------------------- G1
-int c12381_g1_mul_batch_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
+int c12381_g1_mul_batch_flags_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt, unsigned flags) {
     int rc = bind(c); if (rc) return rc;
-    if (!pts || !sc || !out || (fmt != 49 && fmt != 96)) return C12381_E_ARG;
+    if (!pts || !sc || !out || (fmt != 49 && fmt != 96) || (flags & ~(unsigned)C12381_F_IN_SUBGROUP)) return C12381_E_ARG;
     if (n == 0) return 0;
     const size_t stride = round_up(n, 64);
-    if ((rc = g1_mul_to_proj(c, n, pts, sc, stride))) return rc;
+    if ((rc = g1_mul_to_proj(c, n, pts, sc, stride, 96, 0, nullptr, (flags & C12381_F_IN_SUBGROUP) != 0))) return rc;
     return g1_finish(c, n, (const int32_t*)c->ws[c12381_ctx::WS_PROJ], stride, out, fmt);
 }
-int c12381_g1_mul_batch(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
+int c12381_g1_mul_batch_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
+    return c12381_g1_mul_batch_flags_dev(c, n, pts, sc, out, fmt, 0u);
+}
+int c12381_g1_mul_batch_flags(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt, unsigned flags) {
     int rc = bind(c); if (rc) return rc;
-    if (!pts || !sc || !out || (fmt != 49 && fmt != 96)) return C12381_E_ARG;
+    if (!pts || !sc || !out || (fmt != 49 && fmt != 96) || (flags & ~(unsigned)C12381_F_IN_SUBGROUP)) return C12381_E_ARG;
     if (n == 0) return 0;
     staged s;
     if ((rc = stage_in(c, s, pts, 96 * n, sc, 32 * n, (size_t)fmt * n))) return rc;
-    if ((rc = c12381_g1_mul_batch_dev(c, n, s.in0, s.in1, s.out, fmt))) return rc;
+    if ((rc = c12381_g1_mul_batch_flags_dev(c, n, s.in0, s.in1, s.out, fmt, flags))) return rc;
     if ((rc = stage_out(c, s, out, (size_t)fmt * n))) return rc;
     return read_flag(c);
+}
+int c12381_g1_mul_batch(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
+    return c12381_g1_mul_batch_flags(c, n, pts, sc, out, fmt, 0u);
 }
 int c12381_g1_add_batch(c12381_ctx* c, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out, int fmt) {
     int rc = bind(c); if (rc) return rc;
@@ -482,6 +492,40 @@ int c12381_g1_msm(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc
     if ((rc = stage_out(c, s, out, (size_t)fmt))) return rc;
     return read_flag(c);
 }
+// sum_of_products(point1&, int n, point1*, const big*) exactly as the boundary defines it (-> ECP_muln, a plain Pippenger): the sum
+// of the TRUE multiples [k_i mod r]P_i for any curve points.  On G1 it equals c12381_g1_msm — use that for throughput; this entry
+// exists so that the seam function has the reference's value for every input (n plain ladders + tree sum; the seam is scalar).
+int c12381_g1_sum_of_products_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
+    int rc = bind(c); if (rc) return rc;
+    if (!out || (n && (!pts || !sc)) || (fmt != 49 && fmt != 96)) return C12381_E_ARG;
+    if (n == 0) { HIPCK(c, hipMemsetAsync(out, 0, fmt, c->stream)); return 0; }
+    const size_t stride = round_up(n, 64);
+    if ((rc = ensure(c, c12381_ctx::WS_PROJ, (size_t)3 * NL * stride * 4))) return rc;
+    hipLaunchKernelGGL(g1_mul_plain_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, pts, sc, (int32_t*)c->ws[c12381_ctx::WS_PROJ], stride, c->d_flag);
+    HIPCK(c, hipGetLastError());
+    const int32_t* cur = (const int32_t*)c->ws[c12381_ctx::WS_PROJ];
+    size_t cur_n = n, cur_stride = stride;
+    int slot = c12381_ctx::WS_RED0;
+    while (cur_n > 1) {
+        const size_t m = cur_n > 4096 ? round_up(cur_n / 32, 64) : (cur_n > 64 ? 64 : 1);
+        const size_t m_stride = round_up(m, 64);
+        if ((rc = ensure(c, slot, (size_t)3 * NL * m_stride * 4))) return rc;
+        hipLaunchKernelGGL(g1_reduce_kernel, dim3(grid_for(m)), dim3(BLOCK), 0, c->stream, cur_n, cur, cur_stride, m, (int32_t*)c->ws[slot], m_stride);
+        HIPCK(c, hipGetLastError());
+        cur = (const int32_t*)c->ws[slot]; cur_n = m; cur_stride = m_stride;
+        slot = slot == c12381_ctx::WS_RED0 ? c12381_ctx::WS_RED1 : c12381_ctx::WS_RED0;
+    }
+    return g1_finish(c, 1, cur, cur_stride, out, fmt);
+}
+int c12381_g1_sum_of_products(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
+    int rc = bind(c); if (rc) return rc;
+    if (!out || (n && (!pts || !sc)) || (fmt != 49 && fmt != 96)) return C12381_E_ARG;
+    staged s;
+    if ((rc = stage_in(c, s, pts, 96 * n, sc, 32 * n, (size_t)fmt))) return rc;
+    if ((rc = c12381_g1_sum_of_products_dev(c, n, s.in0, s.in1, s.out, fmt))) return rc;
+    if ((rc = stage_out(c, s, out, (size_t)fmt))) return rc;
+    return read_flag(c);
+}
 // One host process driving several GPUs: terms are split contiguously over the contexts, every
 // context runs its local MSM on its own device from its own host thread, and the partial points (96 B each) are
 // summed on the first context — the elliptic-curve "all-reduce" has no RCCL reduction op, the payload is ngpu x 96 B.
@@ -507,7 +551,7 @@ int c12381_g1_msm_multi(c12381_ctx** ctxs, int ngpu, size_t n, const uint8_t* pt
 // finish = true: the kernel leaves projective results in WS_PROJ (the caller has sized it: 6 NL x round_up(n, 64) dwords)
 // and g2_finish converts them with one inversion per FINISH_M elements; false: per-lane conversion straight to `out`.
 static int g2_mul_dev_strided(c12381_ctx* c, size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* sc, uint8_t* out, int fmt,
-                              const int32_t* skip_if = nullptr, bool finish = false);
+                              const int32_t* skip_if = nullptr, bool finish = false, bool in_g2 = false);
 static int g2_finish(c12381_ctx* c, size_t n, uint8_t* d_out, int fmt) {
     int rc;
     const size_t stride = round_up(n, 64);
@@ -519,16 +563,19 @@ static int g2_finish(c12381_ctx* c, size_t n, uint8_t* d_out, int fmt) {
     HIPCK(c, hipGetLastError());
     return 0;
 }
-int c12381_g2_mul_batch_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
+int c12381_g2_mul_batch_flags_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt, unsigned flags) {
     int rc = bind(c); if (rc) return rc;
-    if (!pts || !sc || !out || (fmt != 97 && fmt != 192)) return C12381_E_ARG;
+    if (!pts || !sc || !out || (fmt != 97 && fmt != 192) || (flags & ~(unsigned)C12381_F_IN_SUBGROUP)) return C12381_E_ARG;
     if (n == 0) return 0;
     if ((rc = ensure(c, c12381_ctx::WS_PROJ, (size_t)6 * NL * round_up(n, 64) * 4))) return rc;
-    if ((rc = g2_mul_dev_strided(c, n, pts, 192, sc, out, fmt, nullptr, true))) return rc;
+    if ((rc = g2_mul_dev_strided(c, n, pts, 192, sc, out, fmt, nullptr, true, (flags & C12381_F_IN_SUBGROUP) != 0))) return rc;
     return g2_finish(c, n, out, fmt);
 }
+int c12381_g2_mul_batch_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
+    return c12381_g2_mul_batch_flags_dev(c, n, pts, sc, out, fmt, 0u);
+}
 static int g2_mul_dev_strided(c12381_ctx* c, size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* sc, uint8_t* out, int fmt,
-                              const int32_t* skip_if, bool finish) {
+                              const int32_t* skip_if, bool finish, bool in_g2) {
     int rc = bind(c); if (rc) return rc;
     if (!pts || !sc || !out || (fmt != 97 && fmt != 192)) return C12381_E_ARG;
     if (n == 0) return 0;
@@ -544,24 +591,68 @@ static int g2_mul_dev_strided(c12381_ctx* c, size_t n, const uint8_t* pts, size_
         timed tm(c, 2);
         if (pairwise) {
             hipLaunchKernelGGL(g2_mul2_kernel, dim3(grid_for(2 * m)), dim3(BLOCK), 0, c->stream, m, pts + pt_stride * off, pt_stride, sc + 32 * off,
-                               (int32_t*)c->ws[c12381_ctx::WS_TAB], c->d_flag, skip_if, proj, round_up(n, 64), off);
+                               (int32_t*)c->ws[c12381_ctx::WS_TAB], c->d_flag, skip_if, proj, round_up(n, 64), off, in_g2 ? 1 : 0);
             HIPCK(c, hipGetLastError());
             continue;
         }
         hipLaunchKernelGGL(g2_mul_kernel, dim3(grid_for(m)), dim3(BLOCK), 0, c->stream, m, pts + pt_stride * off, pt_stride, sc + 32 * off,
-                           (int32_t*)c->ws[c12381_ctx::WS_TAB], chunk, out + (size_t)fmt * off, fmt, c->d_flag, skip_if, proj, round_up(n, 64), off);
+                           (int32_t*)c->ws[c12381_ctx::WS_TAB], chunk, out + (size_t)fmt * off, fmt, c->d_flag, skip_if, proj, round_up(n, 64), off, in_g2 ? 1 : 0);
         HIPCK(c, hipGetLastError());
     }
     return 0;
 }
-int c12381_g2_mul_batch(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
+int c12381_g2_mul_batch_flags(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt, unsigned flags) {
     int rc = bind(c); if (rc) return rc;
-    if (!pts || !sc || !out || (fmt != 97 && fmt != 192)) return C12381_E_ARG;
+    if (!pts || !sc || !out || (fmt != 97 && fmt != 192) || (flags & ~(unsigned)C12381_F_IN_SUBGROUP)) return C12381_E_ARG;
     if (n == 0) return 0;
     staged s;
     if ((rc = stage_in(c, s, pts, 192 * n, sc, 32 * n, (size_t)fmt * n))) return rc;
-    if ((rc = c12381_g2_mul_batch_dev(c, n, s.in0, s.in1, s.out, fmt))) return rc;
+    if ((rc = c12381_g2_mul_batch_flags_dev(c, n, s.in0, s.in1, s.out, fmt, flags))) return rc;
     if ((rc = stage_out(c, s, out, (size_t)fmt * n))) return rc;
+    return read_flag(c);
+}
+int c12381_g2_mul_batch(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
+    return c12381_g2_mul_batch_flags(c, n, pts, sc, out, fmt, 0u);
+}
+// Π q_i^{x_i} in G2 (scalars == NULL: the plain product of the points, g2_point.hpp:225-236).  The reference evaluates it as n
+// multiply(point2&, big) calls and a chain of add(point2&, point2&); here: the batched scalar multiplication into the
+// projective workspace, then a tree sum (two levels), one affine conversion.  Only the final point is canonical.
+int c12381_g2_msm_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
+    int rc = bind(c); if (rc) return rc;
+    if (!out || (n && !pts) || (fmt != 97 && fmt != 192)) return C12381_E_ARG;
+    if (n == 0) { HIPCK(c, hipMemsetAsync(out, 0, fmt, c->stream)); return 0; }
+    const size_t stride = round_up(n, 64);
+    if ((rc = ensure(c, c12381_ctx::WS_PROJ, (size_t)6 * NL * stride * 4))) return rc;
+    if (sc) {
+        if ((rc = g2_mul_dev_strided(c, n, pts, 192, sc, out, fmt, nullptr, true))) return rc;
+    } else {
+        hipLaunchKernelGGL(g2_lift_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, pts, (int32_t*)c->ws[c12381_ctx::WS_PROJ], stride, c->d_flag);
+        HIPCK(c, hipGetLastError());
+    }
+    const int32_t* cur = (const int32_t*)c->ws[c12381_ctx::WS_PROJ];
+    size_t cur_n = n, cur_stride = stride;
+    int slot = c12381_ctx::WS_RED0;
+    while (cur_n > 1) {
+        const size_t m = cur_n > 4096 ? round_up(cur_n / 32, 64) : (cur_n > 64 ? 64 : 1);
+        const size_t m_stride = round_up(m, 64);
+        if ((rc = ensure(c, slot, (size_t)6 * NL * m_stride * 4))) return rc;
+        hipLaunchKernelGGL(g2_reduce_kernel, dim3(grid_for(m)), dim3(BLOCK), 0, c->stream, cur_n, cur, cur_stride, m, (int32_t*)c->ws[slot], m_stride);
+        HIPCK(c, hipGetLastError());
+        cur = (const int32_t*)c->ws[slot]; cur_n = m; cur_stride = m_stride;
+        slot = slot == c12381_ctx::WS_RED0 ? c12381_ctx::WS_RED1 : c12381_ctx::WS_RED0;
+    }
+    if ((rc = ensure(c, c12381_ctx::WS_PREF, (size_t)2 * NL * 64 * 4))) return rc;
+    hipLaunchKernelGGL(g2_finish_kernel, dim3(1), dim3(BLOCK), 0, c->stream, (size_t)1, cur, cur_stride, (int32_t*)c->ws[c12381_ctx::WS_PREF], out, fmt, (size_t)1);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+int c12381_g2_msm(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
+    int rc = bind(c); if (rc) return rc;
+    if (!out || (n && !pts) || (fmt != 97 && fmt != 192)) return C12381_E_ARG;
+    staged s;
+    if ((rc = stage_in(c, s, pts, 192 * n, sc, sc ? 32 * n : 0, (size_t)fmt))) return rc;
+    if ((rc = c12381_g2_msm_dev(c, n, s.in0, sc ? s.in1 : nullptr, s.out, fmt))) return rc;
+    if ((rc = stage_out(c, s, out, (size_t)fmt))) return rc;
     return read_flag(c);
 }
 int c12381_g2_add_batch(c12381_ctx* c, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out, int fmt) {
@@ -663,6 +754,26 @@ int c12381_pair_batch(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8_t*
     staged s;
     if ((rc = stage_in(c, s, g1, 96 * n, g2, 192 * n, 576 * n))) return rc;
     if ((rc = c12381_pair_batch_dev(c, n, s.in0, s.in1, s.out))) return rc;
+    if ((rc = stage_out(c, s, gt, 576 * n))) return rc;
+    return read_flag(c);
+}
+// Product of k pairings per element with shared squarings (pair3_prod_kernel)
+int c12381_pair_product_batch_dev(c12381_ctx* c, size_t n, int k, const uint8_t* g1s, const uint8_t* g2s, uint8_t* gt, unsigned flags) {
+    int rc = bind(c); if (rc) return rc;
+    if (!g1s || !g2s || !gt || k < 1 || k > MAX_PROD || (flags & ~(unsigned)C12381_F_MILLER_ONLY)) return C12381_E_ARG;
+    if (n == 0) return 0;
+    timed tm(c, 3);
+    hipLaunchKernelGGL(pair3_prod_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, k, g1s, g2s, gt, c->d_flag, (flags & C12381_F_MILLER_ONLY) ? 1 : 0);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+int c12381_pair_product_batch(c12381_ctx* c, size_t n, int k, const uint8_t* g1s, const uint8_t* g2s, uint8_t* gt, unsigned flags) {
+    int rc = bind(c); if (rc) return rc;
+    if (!g1s || !g2s || !gt || k < 1 || k > MAX_PROD || (flags & ~(unsigned)C12381_F_MILLER_ONLY)) return C12381_E_ARG;
+    if (n == 0) return 0;
+    staged s;
+    if ((rc = stage_in(c, s, g1s, 96 * n * (size_t)k, g2s, 192 * n * (size_t)k, 576 * n))) return rc;
+    if ((rc = c12381_pair_product_batch_dev(c, n, k, s.in0, s.in1, s.out, flags))) return rc;
     if ((rc = stage_out(c, s, gt, 576 * n))) return rc;
     return read_flag(c);
 }
@@ -1136,6 +1247,59 @@ int c12381_bbs_plus_verify_batch(c12381_ctx* c, size_t n, size_t nmsg, const uin
     HIPCK(c, hipMemcpyAsync(d + o_r, r_32, 32 * n, hipMemcpyHostToDevice, c->stream));
     if (nmsg) HIPCK(c, hipMemcpyAsync(d + o_m, m_32, 32 * n * nmsg, hipMemcpyHostToDevice, c->stream));
     if ((rc = c12381_bbs_plus_verify_batch_dev(c, n, nmsg, d + o_g1, d + o_g2, d + o_h0, d + o_h, d + o_w, d + o_A, d + o_x, d + o_r, d + o_m, d + o_ok))) return rc;
+    HIPCK(c, hipMemcpyAsync(ok, d + o_ok, n, hipMemcpyDeviceToHost, c->stream));
+    return read_flag(c);
+}
+
+// ---------------------------------------------------------------- BBS+ verification from the wire formats
+// The whole caller pattern of examples/bbs-plus/src/bbs+.cpp:57-73 on ONE stream: decode the public points and the signatures'
+// A (g1/g2_decompress_kernel), parse x and r, encode the message bytes (bbs_wire_prep_kernel), then the
+// verification pipeline above (f2).  Every message has msg_len bytes (ceil(msg_len / 31) units; more units than h entries is
+// the reference's "message is too long": C12381_E_ARG).  ok[j] = 1 / 0, or 0xff where the reference would throw.
+int c12381_bbs_plus_verify_wire_batch_dev(c12381_ctx* c, size_t n, size_t nh, size_t msg_len, const uint8_t* g1_g2_h0_195, const uint8_t* h_49,
+                                          const uint8_t* pk_97, const uint8_t* sig_145, const uint8_t* msgs, uint8_t* ok) {
+    int rc = bind(c); if (rc) return rc;
+    const size_t nblk = (msg_len + 30) / 31;
+    if (!g1_g2_h0_195 || !pk_97 || !sig_145 || !ok || (nh && !h_49) || (msg_len && !msgs) || nblk > nh) return C12381_E_ARG;
+    if (n == 0) return 0;
+    const size_t npub1 = 2 + nblk;
+    // slab: [pub G1 49s][pub G2 97s][pub G1 96s: g1, h0, h...][pub G2 192s: g2, w][status pub1][status pub2] | per signature: a49, A96, x, r, m, status x2
+    const size_t o_p49 = 0, o_p97 = round_up(o_p49 + 49 * npub1, 16), o_p96 = round_up(o_p97 + 2 * 97, 256), o_p192 = o_p96 + 96 * npub1,
+                 o_st1 = round_up(o_p192 + 384, 16), o_st2 = o_st1 + round_up(npub1, 16), o_a49 = round_up(o_st2 + 16, 256),
+                 o_A = round_up(o_a49 + 49 * n, 256), o_x = o_A + 96 * n, o_r = o_x + 32 * n, o_m = o_r + 32 * n,
+                 o_ss = round_up(o_m + 32 * n * nblk, 256), o_sa = o_ss + round_up(n, 256), bytes = o_sa + round_up(n, 256);
+    if ((rc = ensure(c, c12381_ctx::WS_BBS_WIRE, bytes))) return rc;
+    uint8_t* d = (uint8_t*)c->ws[c12381_ctx::WS_BBS_WIRE];
+    hipLaunchKernelGGL(bbs_wire_pub_kernel, dim3(grid_for(49 * npub1 + 2 * 97)), dim3(BLOCK), 0, c->stream, nblk, g1_g2_h0_195, h_49, pk_97, d + o_p49, d + o_p97);
+    HIPCK(c, hipGetLastError());
+    hipLaunchKernelGGL(g1_decompress_kernel, dim3(grid_for(npub1)), dim3(BLOCK), 0, c->stream, npub1, d + o_p49, d + o_p96, d + o_st1);
+    hipLaunchKernelGGL(g2_decompress_kernel, dim3(1), dim3(BLOCK), 0, c->stream, (size_t)2, d + o_p97, d + o_p192, d + o_st2);
+    HIPCK(c, hipGetLastError());
+    hipLaunchKernelGGL(bbs_wire_prep_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, msg_len, nblk, sig_145, msgs, d + o_a49, d + o_x, d + o_r, d + o_m, d + o_ss);
+    hipLaunchKernelGGL(g1_decompress_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, d + o_a49, d + o_A, d + o_sa);
+    HIPCK(c, hipGetLastError());
+    if ((rc = c12381_bbs_plus_verify_batch_dev(c, n, nblk, d + o_p96, d + o_p192, d + o_p96 + 96, d + o_p96 + 192, d + o_p192 + 192, d + o_A, d + o_x, d + o_r,
+                                               d + o_m, ok))) return rc;
+    hipLaunchKernelGGL(bbs_wire_finish_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, npub1, d + o_ss, d + o_sa, d + o_st1, d + o_st2, ok, c->d_flag);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+int c12381_bbs_plus_verify_wire_batch(c12381_ctx* c, size_t n, size_t nh, size_t msg_len, const uint8_t* g1_g2_h0_195, const uint8_t* h_49,
+                                      const uint8_t* pk_97, const uint8_t* sig_145, const uint8_t* msgs, uint8_t* ok) {
+    int rc = bind(c); if (rc) return rc;
+    const size_t nblk = (msg_len + 30) / 31;
+    if (!g1_g2_h0_195 || !pk_97 || !sig_145 || !ok || (nh && !h_49) || (msg_len && !msgs) || nblk > nh) return C12381_E_ARG;
+    if (n == 0) return 0;
+    const size_t o_pp = 0, o_pk = 256, o_h = 512, o_sig = round_up(o_h + 49 * nh, 256), o_msg = round_up(o_sig + 145 * n, 256),
+                 o_ok = round_up(o_msg + msg_len * n, 256), bytes = o_ok + round_up(n, 256);
+    if ((rc = ensure(c, c12381_ctx::WS_BBS_WIRE_IN, bytes))) return rc;
+    uint8_t* d = (uint8_t*)c->ws[c12381_ctx::WS_BBS_WIRE_IN];
+    HIPCK(c, hipMemcpyAsync(d + o_pp, g1_g2_h0_195, 195, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d + o_pk, pk_97, 97, hipMemcpyHostToDevice, c->stream));
+    if (nh) HIPCK(c, hipMemcpyAsync(d + o_h, h_49, 49 * nh, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d + o_sig, sig_145, 145 * n, hipMemcpyHostToDevice, c->stream));
+    if (msg_len) HIPCK(c, hipMemcpyAsync(d + o_msg, msgs, msg_len * n, hipMemcpyHostToDevice, c->stream));
+    if ((rc = c12381_bbs_plus_verify_wire_batch_dev(c, n, nh, msg_len, d + o_pp, d + o_h, d + o_pk, d + o_sig, d + o_msg, d + o_ok))) return rc;
     HIPCK(c, hipMemcpyAsync(ok, d + o_ok, n, hipMemcpyDeviceToHost, c->stream));
     return read_flag(c);
 }

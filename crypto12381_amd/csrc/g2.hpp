@@ -259,7 +259,9 @@ template <class F> C12381_HDN void g2_gs_zero_digit_terms(g2pt<F>& acc, const g2
 // PAIR_G2mul pair_BLS12381.cpp:927-983: R = u0 Q - u1 psi(Q) + u2 psi^2(Q) - u3 psi^3(Q) for the base-|x| digits of
 // k mod r — exactly what the reference evaluates (ECP2_mul4 after gs() and the sign minimisation), on ANY point of
 // the twist; for Q in G2 it equals [k]Q.  64 doublings + 68 additions on one 8-entry table of multiples of Q.
-template <class F> C12381_HDN void g2_scalar_mul(g2pt<F>& acc, const F& qx, const F& qy, bool q_is_inf, const uint32_t (&kin)[8], int32_t* lane_tab) {
+// in_g2: the caller asserts Q lies in G2 (C12381_F_IN_SUBGROUP) — the [r]psi^i(Q) terms are then the point at infinity and
+// their evaluation (a membership test of 64 doublings per affected lane) is skipped.
+template <class F> C12381_HDN void g2_scalar_mul(g2pt<F>& acc, const F& qx, const F& qy, bool q_is_inf, const uint32_t (&kin)[8], int32_t* lane_tab, bool in_g2 = false) {
     uint32_t k[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) k[i] = kin[i];
@@ -301,7 +303,7 @@ template <class F> C12381_HDN void g2_scalar_mul(g2pt<F>& acc, const F& qx, cons
         g2_add_digit<3>(acc, lane_tab, gs_digit(ub[3], w));
     }
     const bool z1 = (u[1][0] | u[1][1]) == 0u, z3 = (u[3][0] | u[3][1]) == 0u;
-    if (z1 || z3) g2_gs_zero_digit_terms(acc, base, z1, z3);
+    if ((z1 || z3) && !in_g2) g2_gs_zero_digit_terms(acc, base, z1, z3);
 }
 
 // ECP2_setx ecp2_BLS12381.cpp:322-344: y = sqrt(x^3 + 4(1+i)) with FP2_sign(y) == s.

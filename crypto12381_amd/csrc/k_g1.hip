@@ -202,6 +202,37 @@ __global__ void __launch_bounds__(BLOCK, 2) g1_reduce_kernel(size_t n, const int
     soa_store_g1(outp, out_stride, j, acc);
 }
 
+// [k mod r]P by plain double-and-add on the complete formulas, no endomorphism: the TRUE multiple for every curve point — the term
+// of the boundary's sum_of_products (-> ECP_muln ecp_BLS12381.cpp:1112-1148), which multiply()'s GLV form equals only on G1.
+// Uniform schedule: 255 doublings, every addition executed with the point or infinity selected by the bit.
+__global__ void __launch_bounds__(BLOCK, 2) g1_mul_plain_kernel(size_t n, const uint8_t* pts, const uint8_t* scalars, int32_t* proj, size_t proj_stride, int* bad_flag) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    g1p base, acc, inf_pt;
+    bool inf, ok;
+    g1_parse96(base.x, base.y, inf, ok, pts + 96 * i);
+    fp_one(base.z);
+    g1_set_inf(inf_pt);
+    if (inf || !ok) base = inf_pt;
+    uint32_t raw[8], k[8];
+    load_raw32(raw, scalars + 32 * i);
+    scalar_from_raw32(k, raw);
+    scalar_mod_r(k);
+    acc = inf_pt;
+#pragma unroll 1
+    for (int b = 254; b >= 0; --b) {
+        g1_dbl(acc);
+        g1p nn, q;
+        g1_norm1(nn, acc);
+        const bool bit = ((k[b >> 5] >> (b & 31)) & 1u) != 0;
+        fp_select(q.x, bit, base.x, inf_pt.x); fp_select(q.y, bit, base.y, inf_pt.y); fp_select(q.z, bit, base.z, inf_pt.z);
+        g1_add(nn, q);
+        g1_norm1(acc, nn);
+    }
+    if (!ok) { *bad_flag = 1; fp_one(acc.x); fp_zero(acc.y); fp_zero(acc.z); }
+    soa_store_g1(proj, proj_stride, i, acc);
+}
+
 // proj[i] += P for one affine point P broadcast to every lane (BBS+: the constant g1 term)
 __global__ void __launch_bounds__(BLOCK, 2) g1_add_const_kernel(size_t n, int32_t* proj, size_t stride, const uint8_t* pt96, int* bad_flag) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;

@@ -13,7 +13,7 @@ namespace c12381 {
 
 __global__ void __launch_bounds__(BLOCK, 2) g2_mul_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab,
                                                        size_t tab_stride, uint8_t* out, int fmt, int* bad_flag, const int32_t* skip_if,
-                                                       int32_t* proj, size_t proj_stride, size_t proj_off) {
+                                                       int32_t* proj, size_t proj_stride, size_t proj_off, int in_g2) {
     if (skip_if && skip_if[HDR_VALID] != 0) return;          // served by a valid fixed-base table (k_fixed.hip)
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(BLOCK, 2) g2_mul_kernel(size_t n, const uint8_
     load_raw32(raw, scalars + 32 * i);
     scalar_from_raw32(k, raw);
     g2p acc;
-    g2_scalar_mul(acc, qx, qy, inf || !ok, k, tab + i * (size_t)G2_TAB_DWORDS);
+    g2_scalar_mul(acc, qx, qy, inf || !ok, k, tab + i * (size_t)G2_TAB_DWORDS, in_g2 != 0);
     if (!ok) *bad_flag = 1;
     if (proj) g2_store_proj(proj, proj_stride, proj_off + i, acc, !ok);      // kernel-uniform: affine conversion by g2_finish_kernel
     else g2_store_affine(out + (size_t)fmt * i, acc, fmt, !ok);
@@ -69,6 +69,40 @@ __global__ void __launch_bounds__(BLOCK, 2) g2_finish_kernel(size_t n, const int
         g2_store_xy(out + (size_t)fmt * e, ax, ay, fmt, inf, invalid);
         if (e < T + t) break;
     }
+}
+
+// ---- product of G2 points (g2_point.hpp:225-236: the header's product over G2Point is a chain of add(point2&, point2&);
+// with eager exponents, Π q_i^{x_i} is n multiply() calls followed by that chain).  g2_lift_kernel turns affine inputs into the
+// projective SoA of the scalar-multiplication kernels; g2_reduce_kernel is one level of the tree sum (lane j adds elements
+// j, j + m, ...); an element that is not on the twist marks the whole product invalid (X = 1, Z = 0, as g2_finish_kernel reads it).
+__global__ void __launch_bounds__(BLOCK, 2) g2_lift_kernel(size_t n, const uint8_t* pts, int32_t* proj, size_t stride, int* bad_flag) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    g2p p, inf_pt;
+    bool inf, ok;
+    g2_parse192(p.x, p.y, inf, ok, pts + 192 * i);
+    fp2_one(p.z);
+    g2_set_inf(inf_pt);
+    fp2_select(p.x, inf, inf_pt.x, p.x); fp2_select(p.y, inf, inf_pt.y, p.y); fp2_select(p.z, inf, inf_pt.z, p.z);
+    if (!ok) *bad_flag = 1;
+    g2_store_proj(proj, stride, i, p, !ok);
+}
+__global__ void __launch_bounds__(BLOCK, 2) g2_reduce_kernel(size_t n, const int32_t* in, size_t in_stride, size_t m, int32_t* outp, size_t out_stride) {
+    const size_t j = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= m) return;
+    g2p acc;
+    g2_set_inf(acc);
+    bool bad = false;
+#pragma unroll 1
+    for (size_t i = j; i < n; i += m) {
+        g2p q, nn;
+        soa_load_g2(q, in, in_stride, i);
+        bad = bad || (fp2_is_zero(q.z) && !fp2_is_zero(q.x));
+        g2_add(acc, q);
+        g2_norm1(nn, acc);
+        acc = nn;
+    }
+    g2_store_proj(outp, out_stride, j, acc, bad);
 }
 
 __global__ void __launch_bounds__(BLOCK, 2) g2_add_kernel(size_t n, const uint8_t* a, size_t a_stride, const uint8_t* b, uint8_t* out, int fmt,

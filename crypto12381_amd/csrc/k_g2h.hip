@@ -11,7 +11,7 @@ using namespace c12381;
 namespace c12381 {
 
 __global__ void __launch_bounds__(BLOCK, 2) g2_mul2_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab,
-                                                        int* bad_flag, const int32_t* skip_if, int32_t* proj, size_t proj_stride, size_t proj_off) {
+                                                        int* bad_flag, const int32_t* skip_if, int32_t* proj, size_t proj_stride, size_t proj_off, int in_g2) {
     if (skip_if && skip_if[HDR_VALID] != 0) return;          // served by a valid fixed-base table (k_fixed.hip)
     const size_t lane = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const size_t i = lane >> 1;                              // both lanes of a pair take every branch together
@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(BLOCK, 2) g2_mul2_kernel(size_t n, const uint8
     load_raw32(raw, scalars + 32 * i);
     scalar_from_raw32(k, raw);
     g2hp acc;
-    g2_scalar_mul(acc, hx, hy, inf || !ok, k, tab + lane * (size_t)G2H_TAB_DWORDS);
+    g2_scalar_mul(acc, hx, hy, inf || !ok, k, tab + lane * (size_t)G2H_TAB_DWORDS, in_g2 != 0);
     if (!ok) *bad_flag = 1;
     g2h_store_proj(proj, proj_stride, proj_off + i, acc, !ok);
 }

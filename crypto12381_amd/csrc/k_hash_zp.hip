@@ -184,4 +184,72 @@ __global__ void __launch_bounds__(BLOCK, 2) zp_fold_cols_kernel(size_t n, const 
     fr_store32(out + 32 * (T * y + t), acc);
 }
 
+
+// ------------------------------------------------------------------ BBS+ wire formats (the caller side of config 5)
+// examples/bbs-plus/src/bbs+.cpp:57-73 starts from serialized values: parse<G1, G2, G1>(pp.g1_g2_h0) (49 + 97 + 49 bytes),
+// parse<G1>(pp.h) (49 bytes each), parse<G2>(pk) (97 bytes), encode_to<Zp>(message), parse<G1, Zp, Zp>(signature) (49 + 48 + 48).
+// bbs_wire_pub_kernel gathers the public points into the strides the decompression kernels read; bbs_wire_prep_kernel does the
+// per-signature part: A -> 49-byte array, x and r -> 32-byte scalars with parse<Zp>'s range check (48 big-endian bytes below r,
+// zp_number.hpp:226-236), message bytes -> encode_to<Zp> units (zp_number.hpp:1011-1037: 31-byte units behind a 0x01 byte, a short
+// last unit left-aligned), message-major.  status[j] = 0: the reference would throw for signature j.
+__global__ void __launch_bounds__(BLOCK, 2) bbs_wire_pub_kernel(size_t nblk, const uint8_t* g1_g2_h0, const uint8_t* h49, const uint8_t* pk97,
+                                                             uint8_t* g1s49, uint8_t* g2s97) {
+    const size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t n1 = (2 + nblk) * 49, n2 = 2 * 97;
+    if (t < n1) {
+        const size_t e = t / 49, b = t % 49;
+        g1s49[t] = e == 0 ? g1_g2_h0[b] : (e == 1 ? g1_g2_h0[146 + b] : h49[49 * (e - 2) + b]);
+    } else if (t < n1 + n2) {
+        const size_t u = t - n1, e = u / 97, b = u % 97;
+        g2s97[u] = e == 0 ? g1_g2_h0[49 + b] : pk97[b];
+    }
+}
+__device__ __forceinline__ bool wire_zp(uint8_t* out32, const uint8_t* b48) {
+    uint32_t hi = 0, w[8];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) hi |= b48[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {                     // w[0] = least significant word
+        const uint8_t* q = b48 + 16 + 4 * (7 - i);
+        w[i] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | (uint32_t)q[3];
+    }
+    uint64_t bw = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const uint64_t t = (uint64_t)w[i] - ORDER_R[i] - bw; bw = (t >> 32) & 1; }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) out32[i] = b48[16 + i];
+    return hi == 0 && bw == 1;                         // value < r
+}
+__global__ void __launch_bounds__(BLOCK, 2) bbs_wire_prep_kernel(size_t n, size_t msg_len, size_t nblk, const uint8_t* sig145, const uint8_t* msgs,
+                                                              uint8_t* a49, uint8_t* x32, uint8_t* r32, uint8_t* m32, uint8_t* status) {
+    const size_t j = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= n) return;
+    const uint8_t* s = sig145 + 145 * j;
+#pragma unroll 1
+    for (int i = 0; i < 49; ++i) a49[49 * j + i] = s[i];
+    const bool okx = wire_zp(x32 + 32 * j, s + 49);
+    const bool okr = wire_zp(r32 + 32 * j, s + 97);
+    status[j] = (okx && okr) ? 1 : 0;
+    const uint8_t* msg = msgs + msg_len * j;
+#pragma unroll 1
+    for (size_t i = 0; i < nblk; ++i) {
+        uint8_t* o = m32 + 32 * (i * n + j);
+        const size_t len = (i + 1) * 31 <= msg_len ? 31 : msg_len - i * 31;
+        o[0] = 1;
+#pragma unroll 1
+        for (size_t b = 0; b < 31; ++b) o[1 + b] = b < len ? msg[31 * i + b] : 0;
+    }
+}
+// ok[j] <- 0xff where the reference would have thrown: malformed x / r, A not decodable, or public material not decodable
+__global__ void __launch_bounds__(BLOCK, 2) bbs_wire_finish_kernel(size_t n, size_t npub1, const uint8_t* st_sig, const uint8_t* st_a, const uint8_t* st_pub1,
+                                                                const uint8_t* st_pub2, uint8_t* ok, int* bad_flag) {
+    const size_t j = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= n) return;
+    bool pub = st_pub2[0] != 0 && st_pub2[1] != 0;
+#pragma unroll 1
+    for (size_t i = 0; i < npub1; ++i) pub = pub && st_pub1[i] != 0;
+    if (!pub) { ok[j] = 0xff; if (j == 0) *bad_flag = 1; }
+    else if (!st_sig[j] || !st_a[j]) ok[j] = 0xff;
+}
+
 }  // namespace c12381

@@ -147,6 +147,39 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_kernel(size_t n, const uint
     }
 }
 
+// gt[i] = prod_{j < k} e(g1[j * n + i], g2[j * n + i]),  k = 1 .. MAX_PROD: pair(a, b) * pair(c, d) [* pair(e, f)] as the headers
+// form it (liner_pair.hpp:291-303 -> pair_double_ate pair_BLS12381.cpp:508-626, then PAIR_fexp) with ONE joint Miller loop
+// (shared squarings) and ONE final exponentiation.  miller_only: stop before the final exponentiation — the value is then
+// the reference's Miller value (the product of the single-loop values; a G1 argument at infinity contributes 1, :532-541).
+__global__ void __launch_bounds__(BLOCK, 2) pair3_prod_kernel(size_t n, int k, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag, int miller_only) {
+    if ((((size_t)blockIdx.x * BLOCK + threadIdx.x) >> 6) * TRI_PER_WAVE >= n) return;      // whole wavefront idle
+    tri t; size_t i; bool active;
+    tri_setup(t, i, active, n);
+    __shared__ fp4_slot slots[BLOCK];
+    fp4& H = slots[threadIdx.x].v;
+    miller3_pair pr[MAX_PROD];
+    bool ok = true;
+#pragma unroll 1
+    for (int j = 0; j < k; ++j) {
+        fp2 qx, qy; bool pinf, qinf, okj;
+        pair_inputs(pr[j].px, pr[j].py, pinf, qx, qy, qinf, okj, g1 + 96 * ((size_t)j * n + i), g2 + 192 * ((size_t)j * n + i));
+        if (!okj) { pinf = true; qinf = true; }
+        ok = ok && okj;
+        pr[j].skip = pinf;
+        miller3_q(pr[j].Q, qx, qy, qinf);
+        miller3_tc(pr[j].tc, pr[j].Q, t);
+    }
+    f12t_one(H, t);
+    miller3_rangeK(H, pr, k, 64, 1, t);
+    f12t_conj(H, H, t);
+    fp4 F = H;
+    if (!miller_only) f12t_final_exp_ws(F, H, t);
+    if (active) {
+        if (!ok) { *bad_flag = 1; gt_poison(gt + 576 * i, t.role); }
+        else gt_store_coeff(gt + 576 * i, F, t.role);
+    }
+}
+
 // ------------------------------------------------------------------ work-queue kernels
 // A pairing is ~3.4 M instructions per wavefront and every wavefront task is equally long, so a plain grid finishes in
 // whole "rounds": 3121 wavefronts (2^16 pairings) on 2048 resident slots take two full double rounds although they

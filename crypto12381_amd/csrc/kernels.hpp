@@ -33,6 +33,7 @@ __global__ void __launch_bounds__(BLOCK, 2) g1_rsub_kernel(size_t n, int32_t* ac
 __global__ void __launch_bounds__(BLOCK, 2) g1_add_kernel(size_t n, const uint8_t* a, const uint8_t* b, int32_t* proj, size_t proj_stride, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) g1_finish_kernel(size_t n, const int32_t* proj, size_t stride, int32_t* pref, uint8_t* out, int fmt, size_t T);
 __global__ void __launch_bounds__(BLOCK, 2) g1_reduce_kernel(size_t n, const int32_t* in, size_t in_stride, size_t m, int32_t* outp, size_t out_stride);
+__global__ void __launch_bounds__(BLOCK, 2) g1_mul_plain_kernel(size_t n, const uint8_t* pts, const uint8_t* scalars, int32_t* proj, size_t proj_stride, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) g1_add_const_kernel(size_t n, int32_t* proj, size_t stride, const uint8_t* pt96, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) msm_prep_kernel(size_t n, const uint8_t* pts, const uint8_t* scalars, int c, int W, int32_t* pts2, uint32_t* keys, uint32_t* vals, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) msm_ranges_kernel(size_t E, const uint32_t* keys, uint32_t* lo, uint32_t* hi);
@@ -45,9 +46,11 @@ __global__ void __launch_bounds__(BLOCK, 2) g1_decompress_kernel(size_t n, const
 __global__ void __launch_bounds__(64, 1) msm_horner_kernel(const int32_t* rw, size_t stride, int W, int c, int32_t* out, size_t out_stride, const int32_t* term_in);
 __global__ void __launch_bounds__(BLOCK, 2) g1_wave_reduce_kernel(size_t groups, int W, const int32_t* in, size_t in_stride, int32_t* outp, size_t out_stride);
 __global__ void __launch_bounds__(BLOCK, 2) msm_small_term_kernel(const int32_t* sbucket, int32_t* term_out);
-__global__ void __launch_bounds__(BLOCK, 2) g2_mul_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab, size_t tab_stride, uint8_t* out, int fmt, int* bad_flag, const int32_t* skip_if, int32_t* proj, size_t proj_stride, size_t proj_off);
-__global__ void __launch_bounds__(BLOCK, 2) g2_mul2_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab, int* bad_flag, const int32_t* skip_if, int32_t* proj, size_t proj_stride, size_t proj_off);
+__global__ void __launch_bounds__(BLOCK, 2) g2_mul_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab, size_t tab_stride, uint8_t* out, int fmt, int* bad_flag, const int32_t* skip_if, int32_t* proj, size_t proj_stride, size_t proj_off, int in_g2);
+__global__ void __launch_bounds__(BLOCK, 2) g2_mul2_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab, int* bad_flag, const int32_t* skip_if, int32_t* proj, size_t proj_stride, size_t proj_off, int in_g2);
 __global__ void __launch_bounds__(BLOCK, 2) g2_finish_kernel(size_t n, const int32_t* proj, size_t stride, int32_t* pref, uint8_t* out, int fmt, size_t T);
+__global__ void __launch_bounds__(BLOCK, 2) g2_lift_kernel(size_t n, const uint8_t* pts, int32_t* proj, size_t stride, int* bad_flag);
+__global__ void __launch_bounds__(BLOCK, 2) g2_reduce_kernel(size_t n, const int32_t* in, size_t in_stride, size_t m, int32_t* outp, size_t out_stride);
 __global__ void __launch_bounds__(BLOCK, 2) g2_add_kernel(size_t n, const uint8_t* a, size_t a_stride, const uint8_t* b, uint8_t* out, int fmt, int* bad_flag, const int32_t* skip_if);
 __global__ void __launch_bounds__(BLOCK, 2) pair_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) pair_eq_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, size_t b2_stride, uint8_t* out, int* bad_flag);
@@ -56,6 +59,7 @@ __global__ void __launch_bounds__(BLOCK, 2) miller_kernel(size_t n, const uint8_
 __global__ void __launch_bounds__(BLOCK, 2) gt_op_kernel(int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out);
 __global__ void __launch_bounds__(BLOCK, 2) gt_is_unity_kernel(size_t n, const uint8_t* a, uint8_t* out);
 __global__ void __launch_bounds__(BLOCK, 2) pair3_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag);
+__global__ void __launch_bounds__(BLOCK, 2) pair3_prod_kernel(size_t n, int k, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag, int miller_only);
 __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, size_t b2_stride, uint8_t* out, int* bad_flag, const int32_t* skip_if);
 __global__ void __launch_bounds__(BLOCK, 2) pair3_queue_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit);
 __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_queue_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, size_t b2_stride, uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, const int32_t* skip_if, int spin_limit);
@@ -70,6 +74,9 @@ constexpr int PAIR_QUEUE_STATE_ROWS = 42;        // 16-byte rows x 64 lanes per 
 __global__ void __launch_bounds__(BLOCK, 2) g1_from_hash_kernel(size_t n, const uint8_t* in, int mode, int32_t* proj, size_t proj_stride, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) zp_op_kernel(int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out);
 __global__ void __launch_bounds__(BLOCK, 2) zp_fold_cols_kernel(size_t n, const uint8_t* a, size_t a_col_stride, const uint8_t* r32, const uint8_t* m32, int first, size_t T, uint8_t* out);
+__global__ void __launch_bounds__(BLOCK, 2) bbs_wire_pub_kernel(size_t nblk, const uint8_t* g1_g2_h0, const uint8_t* h49, const uint8_t* pk97, uint8_t* g1s49, uint8_t* g2s97);
+__global__ void __launch_bounds__(BLOCK, 2) bbs_wire_prep_kernel(size_t n, size_t msg_len, size_t nblk, const uint8_t* sig145, const uint8_t* msgs, uint8_t* a49, uint8_t* x32, uint8_t* r32, uint8_t* m32, uint8_t* status);
+__global__ void __launch_bounds__(BLOCK, 2) bbs_wire_finish_kernel(size_t n, size_t npub1, const uint8_t* st_sig, const uint8_t* st_a, const uint8_t* st_pub1, const uint8_t* st_pub2, uint8_t* ok, int* bad_flag);
 constexpr int ZP_INV_RUN = 16;
 __global__ void __launch_bounds__(BLOCK, 2) zp_batch_inv_kernel(size_t n, size_t T, const uint8_t* x, const uint8_t* gamma, uint8_t* out, uint32_t* pref);
 __global__ void __launch_bounds__(BLOCK, 2) zp_from_hash_kernel(size_t n, const uint8_t* digests, uint8_t* out);

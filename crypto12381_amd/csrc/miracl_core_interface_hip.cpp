@@ -183,13 +183,13 @@ void double_multiply(point1& p1, point1& p2, big& v1, big& v2) noexcept {       
     uint8_t pts[192], ks[64];
     std::memcpy(pts, raw(p1), 96); std::memcpy(pts + 96, raw(p2), 96);
     scalar32(ks, v1); scalar32(ks + 32, v2);
-    ck(c12381_g1_msm(ctx(), 2, pts, ks, raw(p1), 96));
+    ck(c12381_g1_sum_of_products(ctx(), 2, pts, ks, raw(p1), 96));      // ECP_mul2: true multiples, no endomorphism
 }
 void sum_of_products(point1& result, int n, point1* points, const big* numbers) noexcept {    // was ECP_muln
     std::vector<uint8_t> p((size_t)96 * n), k((size_t)32 * n);
     for (int i = 0; i < n; ++i) { std::memcpy(&p[(size_t)96 * i], raw(points[i]), 96); scalar32(&k[(size_t)32 * i], numbers[i]); }
     std::memset(&result, 0, sizeof result);
-    ck(c12381_g1_msm(ctx(), (size_t)n, p.data(), k.data(), raw(result), 96));
+    ck(c12381_g1_sum_of_products(ctx(), (size_t)n, p.data(), k.data(), raw(result), 96));   // ECP_muln: true multiples
 }
 
 // ------------------------------------------------------------------ G2  (src/miracl_core_interface.cpp:187-236)
@@ -258,12 +258,12 @@ void pair_ate(fp12& result, point2& p2, point1& p1) noexcept {                  
 }
 void pair_final_exponentiation(fp12& object) noexcept { ck(c12381_fexp_batch(ctx(), 1, raw(object), raw(object))); }   // was PAIR_fexp
 void pair_double_ate(fp12& result, point2& p2, point1& p1, point2& q2, point1& q1) noexcept {   // was PAIR_double_ate
-    uint8_t g1[192], g2[384], m[1152];
+    // one joint Miller loop with shared squarings (c12381_pair_product_batch, k = 2), stopped before the final exponentiation
+    uint8_t g1[192], g2[384];
     std::memcpy(g1, raw(p1), 96); std::memcpy(g1 + 96, raw(q1), 96);
     std::memcpy(g2, raw(p2), 192); std::memcpy(g2 + 192, raw(q2), 192);
-    ck(c12381_miller_batch(ctx(), 2, g1, g2, m));
     std::memset(&result, 0, sizeof result);
-    ck(c12381_gt_op_batch(ctx(), 0, 1, m, m + 576, raw(result)));
+    ck(c12381_pair_product_batch(ctx(), 1, 2, g1, g2, raw(result), C12381_F_MILLER_ONLY));
 }
 
 }  // namespace crypto12381::detail::miracl_core

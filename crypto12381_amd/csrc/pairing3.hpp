@@ -409,6 +409,21 @@ C12381_HDN void miller3_range2(fp4& F, fp2& tc1, const fp& px1, const fp& py1, b
 }
 C12381_HD void miller3_q(g2p& Q, const fp2& qx, const fp2& qy, bool q_inf);
 
+// iterations hi .. lo of the joint loop of K <= MAX_PROD pairs sharing the squarings (PAIR_double_ate pair_BLS12381.cpp:508-626
+// generalised: f <- f^2 * l_1 * ... * l_K per iteration, so the value is the product of the K single-loop values as a field
+// element).  The per-pair operands live in arrays: K is a run-time argument of the product kernels.
+constexpr int MAX_PROD = 3;
+struct miller3_pair { fp px, py; fp2 tc; g2p Q; bool skip; };
+C12381_HDN void miller3_rangeK(fp4& F, miller3_pair* pr, int K, int hi, int lo, const tri& t) {
+#pragma unroll 1
+    for (int i = hi; i >= lo; --i) {
+        f12t_sqr(F, F, t);
+#pragma unroll 1
+        for (int j = 0; j < K; ++j) miller3_pair_step(F, pr[j].tc, pr[j].px, pr[j].py, pr[j].skip, pr[j].Q, i, t);
+    }
+}
+
+
 // ------------------------------------------------------------------ fixed G2 argument: precomputed lines
 // The running point T and the coefficients of every line depend on Q only:  l0 = c0 * py,  l1 = c1,  l2 = c2 * px
 // (miller_dbl_step / miller_add_step, pairing.hpp).  When a whole batch pairs against ONE Q (the public w and g2 of

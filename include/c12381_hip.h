@@ -82,12 +82,30 @@ int c12381_fp_mulchain_dev(c12381_ctx* ctx, size_t n, int iters, const uint8_t* 
  * to_bytes(bytes_view&, point1&, compressed) (:113-116 -> ECP_toOctet).  out_fmt = 49 or 96. */
 int c12381_g1_mul_batch(c12381_ctx* ctx, size_t n, const uint8_t* pts96, const uint8_t* scalars32, uint8_t* out, int out_fmt);
 int c12381_g1_mul_batch_dev(c12381_ctx* ctx, size_t n, const uint8_t* pts96, const uint8_t* scalars32, uint8_t* out, int out_fmt);
+/* The same with caller assertions.  C12381_F_IN_SUBGROUP: every input point lies in the order-r subgroup (G1 / G2).
+ * Why it exists: the reference never checks membership and its multiply() (PAIR_G1mul pair_BLS12381.cpp:876-924 after
+ * glv() :793-805; PAIR_G2mul :927-983 after gs() :814-873) adds [r]phi(P) to the result when k mod r < x^2 (any scalar of
+ * at most 127 bits) and [r]psi^i(Q) for a zero odd base-|x| digit; those terms vanish on the subgroup and are cofactor
+ * points elsewhere.  The default entry points reproduce them for EVERY curve point, which costs each such lane a
+ * membership test as long as a scalar multiplication (2^20 G1 multiplications with 64-bit scalars: 40 ms instead of 28 ms).
+ * With the flag the test is skipped: results are identical on subgroup points (tests/test_gpu_g1.py) and are plain
+ * [k mod x^2]P - [k div x^2]phi(P) off it. */
+#define C12381_F_IN_SUBGROUP 1u
+int c12381_g1_mul_batch_flags(c12381_ctx* ctx, size_t n, const uint8_t* pts96, const uint8_t* scalars32, uint8_t* out, int out_fmt, unsigned flags);
+int c12381_g1_mul_batch_flags_dev(c12381_ctx* ctx, size_t n, const uint8_t* pts96, const uint8_t* scalars32, uint8_t* out, int out_fmt, unsigned flags);
 /* out[i] = a[i] + b[i].  Batched add(point1&, point1&) (:129-132 -> ECP_add). */
 int c12381_g1_add_batch(c12381_ctx* ctx, size_t n, const uint8_t* a96, const uint8_t* b96, uint8_t* out, int out_fmt);
 /* out = sum_i scalars[i] * pts[i]  (the reference's Π[n](g[i]^x[i]), g1_point.hpp:371-404, and
  * sum_of_products(point1&, int, point1*, const big*) :134-137 -> ECP_muln). */
 int c12381_g1_msm(c12381_ctx* ctx, size_t n, const uint8_t* pts96, const uint8_t* scalars32, uint8_t* out, int out_fmt);
 int c12381_g1_msm_dev(c12381_ctx* ctx, size_t n, const uint8_t* pts96, const uint8_t* scalars32, uint8_t* out, int out_fmt);
+/* The boundary function sum_of_products(point1&, int, point1*, const big*) with the reference's value for EVERY input
+ * (src/miracl_core_interface.cpp:134-137 -> ECP_muln ecp_BLS12381.cpp:1112-1148, a plain Pippenger): the sum of the true multiples
+ * [k_i mod r]P_i.  For points of G1 this equals c12381_g1_msm, which is the fast path; off the subgroup the two differ because the
+ * header-level Π — what c12381_g1_msm reproduces — goes through multiply()'s GLV form (tests/golden/g1.json
+ * offsubgroup_msm49 vs offsubgroup_sum_of_products49). */
+int c12381_g1_sum_of_products(c12381_ctx* ctx, size_t n, const uint8_t* pts96, const uint8_t* scalars32, uint8_t* out, int out_fmt);
+int c12381_g1_sum_of_products_dev(c12381_ctx* ctx, size_t n, const uint8_t* pts96, const uint8_t* scalars32, uint8_t* out, int out_fmt);
 /* the same product over several GPUs driven by ONE host process: terms split contiguously over ctxs[0..ngpu-1] (one
  * context per device, created by the caller), local MSMs run concurrently, the ngpu partial points are summed on
  * ctxs[0] (the combine is an elliptic-curve addition, 96 B per GPU). */
@@ -99,6 +117,14 @@ int c12381_g1_msm_multi(c12381_ctx** ctxs, int ngpu, size_t n, const uint8_t* po
  * (:192-195 -> ECP2_toOctet).  out_fmt = 97 or 192. */
 int c12381_g2_mul_batch(c12381_ctx* ctx, size_t n, const uint8_t* pts192, const uint8_t* scalars32, uint8_t* out, int out_fmt);
 int c12381_g2_mul_batch_dev(c12381_ctx* ctx, size_t n, const uint8_t* pts192, const uint8_t* scalars32, uint8_t* out, int out_fmt);
+/* with caller assertions (C12381_F_IN_SUBGROUP, see c12381_g1_mul_batch_flags) */
+int c12381_g2_mul_batch_flags(c12381_ctx* ctx, size_t n, const uint8_t* pts192, const uint8_t* scalars32, uint8_t* out, int out_fmt, unsigned flags);
+int c12381_g2_mul_batch_flags_dev(c12381_ctx* ctx, size_t n, const uint8_t* pts192, const uint8_t* scalars32, uint8_t* out, int out_fmt, unsigned flags);
+/* out = sum_i scalars[i] * pts[i] in G2; scalars == NULL: the plain sum of the points — product(type_identity<G2Point>, r)
+ * (g2_point.hpp:225-236: get_infinity + a chain of add(point2&, point2&)); with scalars it is what the header layer evaluates
+ * for Π[n](q[i]^x[i]) (eager multiply(point2&, big) :202-217, then that chain).  n = 0 gives infinity. */
+int c12381_g2_msm(c12381_ctx* ctx, size_t n, const uint8_t* pts192, const uint8_t* scalars32, uint8_t* out, int out_fmt);
+int c12381_g2_msm_dev(c12381_ctx* ctx, size_t n, const uint8_t* pts192, const uint8_t* scalars32, uint8_t* out, int out_fmt);
 /* out[i] = a[i] + b[i].  Batched add(point2&, point2&) (:212-215 -> ECP2_add). */
 int c12381_g2_add_batch(c12381_ctx* ctx, size_t n, const uint8_t* a192, const uint8_t* b192, uint8_t* out, int out_fmt);
 
@@ -108,6 +134,17 @@ int c12381_g2_add_batch(c12381_ctx* ctx, size_t n, const uint8_t* a192, const ui
  * 276-284, 246-249 -> PAIR_ate, PAIR_fexp, FP12_toOctet). */
 int c12381_pair_batch(c12381_ctx* ctx, size_t n, const uint8_t* g1_96, const uint8_t* g2_192, uint8_t* gt576);
 int c12381_pair_batch_dev(c12381_ctx* ctx, size_t n, const uint8_t* g1_96, const uint8_t* g2_192, uint8_t* gt576);
+/* gt[i] = prod_{j < k} e(g1s[j * n + i], g2s[j * n + i]) for k = 1, 2 or 3 (argument-major arrays of k * n points):
+ * pair(a, b) * pair(c, d) as the header layer forms it (liner_pair.hpp:291-303) ->
+ * pair_double_ate(fp12&, point2&, point1&, point2&, point1&) (miracl_core_interface.hpp:203-204,
+ * src/miracl_core_interface.cpp:286-289 -> PAIR_double_ate pair_BLS12381.cpp:508-626) + pair_final_exponentiation: ONE
+ * joint Miller loop with shared Fp12 squarings and ONE final exponentiation per element (k = 3: the triple products of
+ * the PS / bbs04 / AC-* examples).  A G1 argument at infinity contributes 1 (:532-541).
+ * flags: C12381_F_MILLER_ONLY stops before the final exponentiation — the output is the reference's Miller value
+ * (FP12_toOctet bytes of the product of the k single-loop values), what pair_double_ate itself returns. */
+#define C12381_F_MILLER_ONLY 2u
+int c12381_pair_product_batch(c12381_ctx* ctx, size_t n, int k, const uint8_t* g1s_96, const uint8_t* g2s_192, uint8_t* gt576, unsigned flags);
+int c12381_pair_product_batch_dev(c12381_ctx* ctx, size_t n, int k, const uint8_t* g1s_96, const uint8_t* g2s_192, uint8_t* gt576, unsigned flags);
 /* ok[i] = (e(a1[i], a2[i]) == e(b1[i], b2[i])) as the reference's header evaluates it
  * (liner_pair.hpp:339-350): two pair_ate, conjugate, multiply, ONE pair_final_exponentiation, is_unity.
  * ok[i] is 1 / 0, or 0xff when an input point of lane i is not on its curve. */
@@ -221,6 +258,18 @@ int c12381_zp_from_hash_batch(c12381_ctx* ctx, size_t n, const uint8_t* digests6
 int c12381_zp_inner_product(c12381_ctx* ctx, size_t n, const uint8_t* a32, const uint8_t* b32, uint8_t out32[32]);
 int c12381_zp_inner_product_dev(c12381_ctx* ctx, size_t n, const uint8_t* a32, const uint8_t* b32, uint8_t* out32);
 
+/* BBS+ verification from the WIRE formats of the reference's example (bbs+.cpp:57-73 as a whole): pp.g1_g2_h0 = serialize(g1, g2, h0)
+ * (49 + 97 + 49 bytes, set.hpp:235-293), pp.h (nh entries of 49 bytes), pk = serialize(w) (97 bytes), signatures =
+ * serialize(A, x, r) (49 + 48 + 48 bytes) and raw message bytes — msg_len bytes per message, encoded by encode_to<Zp>
+ * (zp_number.hpp:1011-1037) into ceil(msg_len / 31) scalars.  Decoding (ECP_fromOctet / ECP2_fromOctet with the header layer's
+ * "leading 0x00 = infinity", g1_point.hpp:87-111; parse<Zp> range check zp_number.hpp:226-236), encoding and verification run
+ * on the context's stream.  ok[j] = 1 / 0 = what verify() returns, 0xff = the reference would throw for signature j (malformed
+ * A, x or r); public material that does not decode poisons every lane and returns C12381_E_POINT; more message units than
+ * h entries ("message is too long") is C12381_E_ARG. */
+int c12381_bbs_plus_verify_wire_batch(c12381_ctx* ctx, size_t n, size_t nh, size_t msg_len, const uint8_t* g1_g2_h0_195, const uint8_t* h_49,
+                                      const uint8_t* pk_97, const uint8_t* sig_145, const uint8_t* msgs, uint8_t* ok);
+int c12381_bbs_plus_verify_wire_batch_dev(c12381_ctx* ctx, size_t n, size_t nh, size_t msg_len, const uint8_t* g1_g2_h0_195, const uint8_t* h_49,
+                                          const uint8_t* pk_97, const uint8_t* sig_145, const uint8_t* msgs, uint8_t* ok);
 /* BBS+ signing for a batch (examples/bbs-plus/src/bbs+.cpp:38-55): A[j] = (g1 * h0^r[j] * prod_i h_i^m[i*n + j])^(1/(gamma + x[j]))
  * — `^` is multiply (:122), `inverse` is mod_inverse (:59; inverse(0) = 0, so A is then the point at infinity), Π the
  * sum of the columns.  x and r are the caller's random scalars (the reference draws them inside sign()); gamma is the

@@ -107,6 +107,13 @@ class Oracle:
         self._ck(self._f("g1_msm")(_sz(n), pts, scalars, o, fmt, nthreads), "g1_msm")
         return o.raw[:fmt]
 
+    def g1_sum_of_products(self, pts: bytes, scalars: bytes, fmt: int = 49) -> bytes:
+        """sum_of_products -> ECP_muln: the true multiples sum [k_i mod r] P_i on any curve points"""
+        n = len(pts) // 96
+        o = self._buf(fmt)
+        self._ck(self._f("g1_sum_of_products")(n, pts, scalars, o, fmt), "g1_sum_of_products")
+        return o.raw[:fmt]
+
     # ---- G2
     def g2_mul(self, pts: bytes, scalars: bytes, fmt: int = 97, nthreads: int = 1) -> bytes:
         n = len(pts) // 192

@@ -797,6 +797,23 @@ int orc_g1_msm(size_t n, const uint8_t* pts96, const uint8_t* scalars32, uint8_t
     return m.bad ? -2 : 0;
 }
 
+/* sum_of_products(point1&, n, point1*, const big*) src/miracl_core_interface.cpp:134-137 -> ECP_muln ecp_BLS12381.cpp:1112-1148: a plain
+ * Pippenger over the scalars as given — the true multiples sum [k_i]P_i for ANY curve points (no endomorphism), unlike multiply().
+ * Scalars are reduced mod r first, as the header layer's Zp values are (ref_wrap.cpp does the same before ECP_muln). */
+int orc_g1_sum_of_products(int n, const uint8_t* pts96, const uint8_t* scalars32, uint8_t* out, int out_fmt) {
+    INIT();
+    g1p acc; g1_inf(&acc);
+    for (int i = 0; i < n; i++) {
+        g1p P; uint64_t k[4];
+        if (!g1_load96(&P, pts96 + 96 * (size_t)i)) return -2;
+        scalar_load(k, scalars32 + 32 * (size_t)i);
+        g1_mul_plain(&P, k, 4);
+        g1_add(&acc, &P);
+    }
+    g1_store(out, &acc, out_fmt);
+    return 0;
+}
+
 static void g2_mul_range(size_t lo, size_t hi, void* c) {
     mul_ctx* m = (mul_ctx*)c;
     for (size_t i = lo; i < hi; i++) {

@@ -107,6 +107,9 @@ def main():
     g1j["offsubgroup_points"], g1j["offsubgroup_scalars"] = hx(off, 96), hx(off_sc, 32)
     g1j["offsubgroup_mul96"] = hx(ref.g1_mul(off, off_sc, 96), 96)
     g1j["offsubgroup_msm49"] = ref.g1_msm(off, off_sc, 49, 2).hex()
+    # the boundary's OTHER product: sum_of_products -> ECP_muln (plain Pippenger, true multiples) differs from the chain above off the subgroup
+    g1j["offsubgroup_sum_of_products49"] = ref.g1_sum_of_products(off, off_sc, 49).hex()
+    g1j["sum_of_products49"] = ref.g1_sum_of_products(pts_e, sc, 49).hex()
     # ... and scalars below x^2: glv() leaves u1 = r there, so the reference adds [r]phi(P) (pair_BLS12381.cpp:793-805, :899-906)
     X2 = 0xd201000000010000 ** 2
     small = [0, 1, 2, 0xd201000000010001, X2 - 1, X2, X2 + 1, R - 1, R, R + 1, 3 * X2, (1 << 127), 12345, R + 7]

@@ -222,3 +222,59 @@ def test_bbs_plus_verify_aggregate(oracle_port):
     Xbad = bytearray(Xb); Xbad[32 * 4100 + 31] ^= 1
     assert ctx.bbs_plus_verify_aggregate(G1p, G2p, h0, h, w, Ab, bytes(Xbad), Rb, Mb, rhob) is False
     ctx.close()
+
+
+def test_bbs_plus_verify_from_wire_formats(oracle_port):
+    """c12381_bbs_plus_verify_wire_batch: the whole of examples/bbs-plus/src/bbs+.cpp:57-73 from serialized parameters, key,
+    signatures (49 + 48 + 48 B) and raw message bytes; verdicts (incl. 0xff where the reference throws) against the oracle
+    driving the reference's own from_bytes / multiply / add / pair_ate sequence on the same bytes."""
+    from crypto12381_amd import Context
+    from oracle.bindings import Oracle, have_reference
+    orc = oracle_port
+    checkers = [orc] + ([Oracle("reference")] if have_reference() else [])
+    ctx = Context(0)
+    for msg_len, n in ((12, 70), (45, 33), (62, 9)):
+        nblk = (msg_len + 30) // 31
+        nh = nblk + 1                                             # one unused h entry, as setup(16) leaves many
+        G1p, G2p, h0, h, gamma, w = _setup(orc, nh)
+        pp = orc.g1_compress(G1p) + orc.g2_compress(G2p) + orc.g1_compress(h0)
+        h49 = orc.g1_compress(h)
+        pk = orc.g2_compress(w)
+        assert len(pp) == 195 and len(h49) == 49 * nh and len(pk) == 97
+        sigs, msgs = b"", b""
+        for j in range(n):
+            msg = bytes((prng(740, j * 64 + b, 1)) for b in range(msg_len)) if j else (b"Hello, BBS+!" + bytes(msg_len))[:msg_len]
+            units = orc.encode_to_zp(msg)
+            ms = [int.from_bytes(units[32 * i:32 * i + 32], "big") for i in range(nblk)]
+            assert all(m >> 248 == 1 for m in ms)
+            x, r = prng(741, j) % R, prng(742, j) % R
+            a = _sign(orc, G1p, h0, h, gamma, ms, x, r)
+            sig = bytearray(orc.g1_compress(a) + bytes(16) + x.to_bytes(32, "big") + bytes(16) + r.to_bytes(32, "big"))
+            kind = j % 9
+            if kind == 1:
+                msg = bytes([msg[0] ^ 1]) + msg[1:]               # another message: verify() returns false
+            elif kind == 2:
+                sig[49 + 16:49 + 48] = (R + 5).to_bytes(32, "big")   # x >= r: parse<Zp> throws
+            elif kind == 3:
+                sig[0] = 0x05                                     # unknown tag: from_bytes fails
+            elif kind == 4:
+                sig[0:49] = bytes(49)                             # A = infinity: parses, does not verify
+            elif kind == 5:
+                sig[97] = 1                                       # r >= 2^256
+            elif kind == 6:
+                sig[1:49] = (prng(743, j, 48) % (1 << 380)).to_bytes(48, "big")   # random x: about half are not on the curve
+            sigs += bytes(sig); msgs += msg
+        got = ctx.bbs_plus_verify_wire(pp, h49, pk, sigs, msgs, msg_len)
+        for ck in checkers:
+            assert got == ck.bbs_plus_verify_wire(pp, h49, pk, sigs, msgs, msg_len, 8), (msg_len, ck.kind)
+        assert got[0] == 1 and got[1] == 0 and got[2] == 0xff and got[3] == 0xff and got[4] == 0 and got[5] == 0xff
+    # message longer than the h entries allow: the reference throws "message is too long" before anything else
+    from crypto12381_amd.capi import C12381Error, E_ARG
+    with pytest.raises(C12381Error) as ei:
+        ctx.bbs_plus_verify_wire(pp, h49[:49], pk, sigs, msgs, msg_len)
+    assert ei.value.code == E_ARG
+    # public material that does not decode poisons every lane
+    bad_pp = bytes([5]) + pp[1:]
+    out = ctx.bbs_plus_verify_wire(bad_pp, h49, pk, sigs, msgs, msg_len, strict=False)
+    assert out == b"\xff" * (len(sigs) // 145)
+    ctx.close()

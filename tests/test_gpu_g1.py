@@ -203,3 +203,79 @@ def test_fixed_base_entry_points(ctx, oracle_port):
     assert ctx.g2_mul_fixed(gen2, sc2[:32 * 12], 192) == oracle_port.g2_mul(gen2 * 12, sc2[:32 * 12], 192, 4)
     off2 = cat(g["offsubgroup_points"])[:192]
     assert ctx.g2_mul_fixed(off2, sc2[-32 * 14:], 192) == oracle_port.g2_mul(off2 * 14, sc2[-32 * 14:], 192)
+
+
+def test_in_subgroup_flag(ctx, oracle_port):
+    """C12381_F_IN_SUBGROUP skips the [r]phi(P) / [r]psi^i(Q) side paths (pair_BLS12381.cpp:793-805, 896-914, 868-871):
+    identical results on subgroup points for short scalars, the default entry stays exact off the subgroup, and the
+    flagged entry returns the plain endomorphism combination there (documented divergence)."""
+    from crypto12381_amd.capi import F_IN_SUBGROUP, E_ARG
+    g = golden("g1")
+    g1 = bytes.fromhex(g["generator"])
+    n = 300
+    pts = ctx.g1_mul(g1 * n, scalars(3101, n), 96)
+    short = b"".join((prng(3102, i) % (1 << (8 * (1 + i % 16)))).to_bytes(32, "big") for i in range(n))      # 8 .. 128-bit scalars
+    exp = oracle_port.g1_mul(pts, short, 96, 8)
+    assert ctx.g1_mul(pts, short, 96) == exp
+    assert ctx.g1_mul_flags(pts, short, 96, F_IN_SUBGROUP) == exp
+    assert ctx.g1_mul_flags(pts, short, 49, F_IN_SUBGROUP) == oracle_port.g1_mul(pts, short, 49, 8)
+    full = scalars(3103, n)
+    assert ctx.g1_mul_flags(pts, full, 96, F_IN_SUBGROUP) == oracle_port.g1_mul(pts, full, 96, 8)
+    g2g = golden("g2")
+    g2 = bytes.fromhex(g2g["generator"])
+    m = 120
+    q = ctx.g2_mul(g2 * m, scalars(3104, m), 192)
+    short2 = short[:32 * m]
+    e2 = oracle_port.g2_mul(q, short2, 192, 8)
+    assert ctx.g2_mul(q, short2, 192) == e2 and ctx.g2_mul_flags(q, short2, 192, F_IN_SUBGROUP) == e2
+    assert ctx.g2_mul_flags(q, short2, 97, F_IN_SUBGROUP) == oracle_port.g2_mul(q, short2, 97, 8)
+    # off the subgroup: the default entry equals the reference (golden), the flagged one drops exactly the [r]-terms
+    op, osc = cat(g["offsubgroup_small_points"]), cat(g["offsubgroup_small_scalars"])
+    assert ctx.g1_mul(op, osc, 96) == cat(g["offsubgroup_small_mul96"])
+    assert ctx.g1_mul_flags(op, osc, 96, F_IN_SUBGROUP) != cat(g["offsubgroup_small_mul96"])
+    # unknown flag bits are argument errors
+    import ctypes
+    from crypto12381_amd.capi import _p
+    out = ctypes.create_string_buffer(96)
+    assert ctx.lib.c12381_g1_mul_batch_flags(ctx.h, 1, _p(pts[:96]), _p(short[:32]), _p(out), 96, 2) == E_ARG
+
+
+def test_sum_of_products_is_ecp_muln_on_every_point(ctx, oracle_port):
+    """The seam's sum_of_products (-> ECP_muln ecp_BLS12381.cpp:1112-1148) sums TRUE multiples; the header-level product
+    (c12381_g1_msm) goes through multiply()'s GLV form.  Equal on G1, different off it — both pinned by reference vectors."""
+    g = golden("g1")
+    pts, sc = cat(g["points"]), cat(g["scalars"])
+    n = g["msm_n"]
+    assert ctx.g1_sum_of_products(pts[:96 * n], sc[:32 * n], 49).hex() == g["sum_of_products49"] == g["msm49"]
+    off, osc = cat(g["offsubgroup_points"]), cat(g["offsubgroup_scalars"])
+    assert ctx.g1_sum_of_products(off, osc, 49).hex() == g["offsubgroup_sum_of_products49"]
+    assert ctx.g1_msm(off, osc, 49).hex() == g["offsubgroup_msm49"] != g["offsubgroup_sum_of_products49"]
+    assert ctx.g1_sum_of_products(off, osc, 96) == oracle_port.g1_sum_of_products(off, osc, 96)
+    # sizes across the tree-sum levels, infinity terms, zero scalars
+    m = 150
+    g1 = bytes.fromhex(g["generator"])
+    P = bytearray(ctx.g1_mul(g1 * m, scalars(3201, m), 96)); P[96 * 3:96 * 4] = bytes(96)
+    K = bytearray(scalars(3202, m)); K[32 * 5:32 * 6] = bytes(32)
+    assert ctx.g1_sum_of_products(bytes(P), bytes(K), 49) == oracle_port.g1_msm(bytes(P), bytes(K), 49, 8)
+    assert ctx.g1_sum_of_products(b"", b"", 49) == bytes(49)
+
+
+def test_g2_product(ctx, oracle_port):
+    """c12381_g2_msm: the header's product over G2 points (g2_point.hpp:225-236, a chain of add) and Π q_i^{x_i}."""
+    g2 = bytes.fromhex(golden("g2")["generator"])
+    m = 131
+    Q = bytearray(ctx.g2_mul(g2 * m, scalars(3301, m), 192)); Q[192 * 2:192 * 3] = bytes(192)
+    Q = bytes(Q)
+    acc = bytes(192)
+    for i in range(m):
+        acc = oracle_port.g2_add(acc, Q[192 * i:192 * i + 192], 192)
+    assert ctx.g2_msm(Q, None, 192) == acc
+    assert ctx.g2_msm(Q, None, 97) == oracle_port.g2_compress(acc)
+    K = scalars(3302, m)
+    T = oracle_port.g2_mul(Q, K, 192, 8)
+    acc = bytes(192)
+    for i in range(m):
+        acc = oracle_port.g2_add(acc, T[192 * i:192 * i + 192], 192)
+    assert ctx.g2_msm(Q, K, 192) == acc
+    assert ctx.g2_msm(b"", None, 97) == bytes(97)
+    assert ctx.g2_msm(Q[:192], K[:32], 192) == T[:192]

@@ -159,3 +159,37 @@ def test_pair_fixed_g2(ctx, oracle_port):
     bad = g2s[:191] + bytes([g2s[191] ^ 1])
     assert ctx.pair_fixed_g2(g1s, bad, strict=False) == b"\xff" * (576 * n)
     assert ctx.pair_fixed_g2(b"", g2s[:192]) == b""
+
+
+def test_pair_product_batch(ctx, oracle_port):
+    """c12381_pair_product_batch: pair(a,b) * pair(c,d) [* pair(e,f)] with one joint Miller loop and one final exponentiation
+    (liner_pair.hpp:291-303 -> pair_double_ate pair_BLS12381.cpp:508-626): equals the reference's pair2 golden, the product of
+    single pairings through gt_op, and the reference's law tests (unit-tests/liner_pair.cpp:66-79, 92-103)."""
+    from crypto12381_amd.capi import F_MILLER_ONLY
+    g = golden("pairing")
+    a1, a2, b1, b2 = cat(g["eq_a1"]), cat(g["eq_a2"]), cat(g["eq_b1"]), cat(g["eq_b2"])
+    n = len(a1) // 96
+    got = ctx.pair_product(a1 + b1, a2 + b2, 2)
+    assert got == oracle_port.pair2(a1, a2, b1, b2)
+    assert got == ctx.gt_op("mul", ctx.pair(a1, a2), ctx.pair(b1, b2))
+    if "pair2" in g and len(cat(g["pair2"])) == 576 * n:
+        assert got == cat(g["pair2"])
+    # Miller-only form: the reference's pair_double_ate value (product of the two Miller values), then fexp gives the same GT
+    m2 = ctx.pair_product(a1 + b1, a2 + b2, 2, F_MILLER_ONLY)
+    assert m2 == ctx.gt_op("mul", ctx.miller(a1, a2), ctx.miller(b1, b2))
+    assert ctx.fexp(m2) == got
+    # k = 1 degenerates to the plain pairing, k = 3 is the triple product
+    assert ctx.pair_product(a1, a2, 1) == ctx.pair(a1, a2)
+    c1, c2 = cat(g["g1"])[:96 * n] if len(cat(g["g1"])) >= 96 * n else (cat(g["g1"]) * n)[:96 * n], (cat(g["g2"]) * n)[:192 * n]
+    tri = ctx.pair_product(a1 + b1 + c1, a2 + b2 + c2, 3)
+    assert tri == ctx.gt_op("mul", got, ctx.pair(c1, c2))
+    # infinity arguments contribute 1 (pair_BLS12381.cpp:532-541; G2 infinity: unit-tests/liner_pair.cpp:28-40)
+    z1, z2 = bytes(96 * n), bytes(192 * n)
+    assert ctx.pair_product(a1 + z1, a2 + b2, 2) == ctx.pair(a1, a2)
+    assert ctx.pair_product(a1 + b1, a2 + z2, 2) == ctx.pair(a1, a2)
+    # a ragged batch across wavefront groups against the oracle
+    m = 47
+    g1 = bytes.fromhex(golden("g1")["generator"]); g2 = bytes.fromhex(golden("g2")["generator"])
+    P = ctx.g1_mul(g1 * (2 * m), scalars(4401, 2 * m), 96)
+    Q = ctx.g2_mul(g2 * (2 * m), scalars(4402, 2 * m), 192)
+    assert ctx.pair_product(P, Q, 2) == oracle_port.pair2(P[:96 * m], Q[:192 * m], P[96 * m:], Q[192 * m:])

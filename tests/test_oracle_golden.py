@@ -177,3 +177,41 @@ def test_zp_golden_against_python_ints():
         assert int(g["zp_inv"][i], 16) == pow(x, R - 2, R)
     for dg, z in zip(g["digests"], g["zp_from_hash"]):
         assert int(z, 16) == int(dg, 16) % R
+
+
+def test_bbs_wire_restatement_matches_reference(oracle_ref, oracle_port):
+    """encode_to<Zp> (zp_number.hpp:1011-1037) and the wire-format BBS+ verification: the C restatement against the compiled
+    reference on valid, forged and malformed signatures (CPU only)."""
+    from util import R, golden, prng, scalars
+    g1 = bytes.fromhex(golden("g1")["generator"]); g2 = bytes.fromhex(golden("g2")["generator"])
+    for msg in (b"", b"a", b"Hello, BBS+!", bytes(range(31)), bytes(range(32)), bytes(range(100))):
+        assert oracle_ref.encode_to_zp(msg) == oracle_port.encode_to_zp(msg)
+    assert oracle_port.encode_to_zp(b"Hello, BBS+!").hex() == "01" + b"Hello, BBS+!".hex() + "00" * 19
+    gs = oracle_ref.g1_mul(g1 * 4, scalars(801, 4), 96)
+    G1p, h0, h = gs[:96], gs[96:192], gs[192:]
+    G2p = oracle_ref.g2_mul(g2, scalars(802, 1), 192)
+    gamma = prng(803, 0) % R
+    w = oracle_ref.g2_mul(G2p, gamma.to_bytes(32, "big"), 192)
+    pp = oracle_ref.g1_compress(G1p) + oracle_ref.g2_compress(G2p) + oracle_ref.g1_compress(h0)
+    h49, pk = oracle_ref.g1_compress(h), oracle_ref.g2_compress(w)
+    msg_len, n = 40, 8
+    sigs, msgs = b"", b""
+    for j in range(n):
+        msg = bytes(prng(804, j * 64 + b, 1) for b in range(msg_len))
+        u = oracle_ref.encode_to_zp(msg)
+        x, r = prng(805, j) % R, prng(806, j) % R
+        B = oracle_ref.g1_msm(G1p + h0 + h, (1).to_bytes(32, "big") + r.to_bytes(32, "big") + u, 96, 1)
+        a = oracle_ref.g1_mul(B, pow((gamma + x) % R, -1, R).to_bytes(32, "big"), 96)
+        sig = bytearray(oracle_ref.g1_compress(a) + bytes(16) + x.to_bytes(32, "big") + bytes(16) + r.to_bytes(32, "big"))
+        if j == 2:
+            msg = bytes([msg[0] ^ 0x80]) + msg[1:]
+        if j == 3:
+            sig[49 + 16:49 + 48] = R.to_bytes(32, "big")
+        if j == 4:
+            sig[0] = 0x07
+        if j == 5:
+            sig[:49] = bytes(49)
+        sigs += bytes(sig); msgs += msg
+    a = oracle_ref.bbs_plus_verify_wire(pp, h49, pk, sigs, msgs, msg_len, 4)
+    b = oracle_port.bbs_plus_verify_wire(pp, h49, pk, sigs, msgs, msg_len, 4)
+    assert a == b and list(a) == [1, 1, 0, 0xff, 0xff, 0, 1, 1]
