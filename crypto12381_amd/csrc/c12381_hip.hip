@@ -345,9 +345,12 @@ int c12381_set_stream(c12381_ctx* c, void* hip_stream) {
     return 0;
 }
 
+static void pair_stamps_dump(c12381_ctx* c);
 int c12381_sync(c12381_ctx* c) {
     int rc = bind(c); if (rc) return rc;
-    return read_flag(c);
+    rc = read_flag(c);
+    pair_stamps_dump(c);
+    return rc;
 }
 
 int c12381_profile(c12381_ctx* c, int enable) {
@@ -691,6 +694,32 @@ static int pair_spin_limit() {
     static const int v = [] { const char* e = std::getenv("C12381_PAIR_SPIN_LIMIT"); return e ? std::atoi(e) : (1 << 20); }();
     return v;
 }
+// Diagnostic: C12381_PAIR_STAMPS=<file> makes every task of pair3_queue_kernel record its claim / start / end times (s_memtime)
+// into a device buffer that c12381_sync() writes to the file — per-phase durations and hand-over waits (tools/queue_phase_times.py).
+static const char* pair_stamps_path() {
+    static const char* p = std::getenv("C12381_PAIR_STAMPS");
+    return p;
+}
+static unsigned long long* g_stamps = nullptr;
+static size_t g_stamps_tasks = 0;
+static unsigned long long* pair_stamps(c12381_ctx* c, size_t n) {
+    if (!pair_stamps_path()) return nullptr;
+    const size_t tasks = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE * 10;
+    if (g_stamps_tasks < tasks) {
+        if (g_stamps) (void)hipFree(g_stamps);
+        if (hipMalloc((void**)&g_stamps, tasks * 32) != hipSuccess) { g_stamps = nullptr; g_stamps_tasks = 0; return nullptr; }
+        g_stamps_tasks = tasks;
+    }
+    (void)hipMemsetAsync(g_stamps, 0, tasks * 32, c->stream);
+    return g_stamps;
+}
+static void pair_stamps_dump(c12381_ctx* c) {
+    if (!pair_stamps_path() || !g_stamps) return;
+    std::vector<unsigned long long> h(g_stamps_tasks * 4);
+    if (hipMemcpy(h.data(), g_stamps, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+    if (FILE* f = std::fopen(pair_stamps_path(), "wb")) { std::fwrite(h.data(), 8, h.size(), f); std::fclose(f); }
+    (void)c;
+}
 static bool pair_use_queue(size_t n) {
     const int m = pair_queue_mode();
     if (m >= 0) return m == 1;
@@ -716,7 +745,7 @@ static int launch_pair(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8_t
     else if (pair_use_queue(n)) {
         uint4* st; unsigned int *fl, *ct; unsigned blocks; int rc;
         if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
-        hipLaunchKernelGGL(pair3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag, st, fl, ct, pair_spin_limit());
+        hipLaunchKernelGGL(pair3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag, st, fl, ct, pair_spin_limit(), pair_stamps(c, n));
     } else hipLaunchKernelGGL(pair3_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag);
     HIPCK(c, hipGetLastError());
     return 0;
@@ -740,7 +769,7 @@ int c12381_pair_batch_dev(c12381_ctx* c, size_t n, const uint8_t* g1, const uint
         uint4* st; unsigned int *fl, *ct; unsigned blocks;
         if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
         timed tm(c, 3);
-        hipLaunchKernelGGL(pair3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag, st, fl, ct, pair_spin_limit());
+        hipLaunchKernelGGL(pair3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag, st, fl, ct, pair_spin_limit(), pair_stamps(c, n));
         HIPCK(c, hipGetLastError());
         return 0;
     }

@@ -105,7 +105,8 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_kernel(size_t n, const uint8_t
     __shared__ fp4_slot slots[BLOCK];
     fp4& H = slots[threadIdx.x].v;
     miller3_loop(H, px, py, pinf, qx, qy, qinf, t);
-    fp4 F = H;
+    fp4 F;
+    slot_load(F, H);
     f12t_final_exp_ws(F, H, t);
     if (active) {
         if (!ok) { uint4* q = reinterpret_cast<uint4*>(gt + 576 * i + (t.role == 0 ? 384 : (t.role == 1 ? 192 : 0))); for (int j = 0; j < 12; ++j) q[j] = make_uint4(~0u, ~0u, ~0u, ~0u); }
@@ -137,7 +138,8 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_kernel(size_t n, const uint
         fp_norm1(py2, ny);
     }
     miller3_loop2(H, px, py, pinf, qx, qy, qinf, px2, py2, pinf2, qx2, qy2, qinf2, t);
-    fp4 F = H;
+    fp4 F;
+    slot_load(F, H);
     f12t_final_exp_ws(F, H, t);
     const bool one = f12t_is_one(F, t);
     const bool valid = ok && okb;
@@ -169,10 +171,11 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_prod_kernel(size_t n, int k, c
         miller3_q(pr[j].Q, qx, qy, qinf);
         miller3_tc(pr[j].tc, pr[j].Q, t);
     }
-    f12t_one(H, t);
+    { fp4 one; f12t_one(one, t); slot_store(H, one); }
     miller3_rangeK(H, pr, k, 64, 1, t);
-    f12t_conj(H, H, t);
-    fp4 F = H;
+    f12t_conj_h(H, t);
+    fp4 F;
+    slot_load(F, H);
     if (!miller_only) f12t_final_exp_ws(F, H, t);
     if (active) {
         if (!ok) { *bad_flag = 1; gt_poison(gt + 576 * i, t.role); }
@@ -191,7 +194,8 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_prod_kernel(size_t n, int k, c
 // (queue_wait above: a time-out poisons the group instead of letting it run on stale state).
 template <bool EQ>
 __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, size_t b2_stride,
-                                                 uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit, fp4& H) {
+                                                 uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit, fp4& H,
+                                                 unsigned long long* stamps = nullptr) {
     const unsigned lane = threadIdx.x & 63u;
     const unsigned trip = lane / 3u;
     tri t;
@@ -214,7 +218,11 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
         const size_t e = g * TRI_PER_WAVE + (lane == 63u ? TRI_PER_WAVE - 1 : trip);
         const bool active = lane < 63u && e < n;
         const size_t i = e < n ? e : n - 1;          // inactive lanes shadow the last element: same instruction stream
+        // diagnostic time stamps (C12381_PAIR_STAMPS, tools/queue_phase_times.py): claim, start after the wait, end — per task
+        unsigned long long ts_claim = 0, ts_start = 0;
+        if (stamps) ts_claim = __builtin_amdgcn_s_memtime();
         const bool poisoned = queue_wait(flags, g, p, spin_limit);
+        if (stamps) ts_start = __builtin_amdgcn_s_memtime();
         uint4* st = state + g * (size_t)ROWS * 64;
         if (poisoned) {
             if (p == TASKS - 1 && active) {
@@ -239,17 +247,25 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
             if (p == 0) {
                 miller3_tc(tc, Q, t);
                 if (EQ) miller3_tc(tc2, Q2, t);
-                f12t_one(H, t);
+                fp4 one;
+                f12t_one(one, t);
+                slot_store(H, one);
             } else {
-                st_load<fp4, ST_ROWS_F>(H, st + ST_F * 64, lane);
+                fp4 f;
+                st_load<fp4, ST_ROWS_F>(f, st + ST_F * 64, lane);
+                slot_store(H, f);
                 st_load<fp2, ST_ROWS_TC>(tc, st + ST_TC1 * 64, lane);
                 if (EQ) st_load<fp2, ST_ROWS_TC>(tc2, st + ST_TC2 * 64, lane);
             }
             const int hi = 64 - 16 * (int)p, lo = hi - 15;
             if (EQ) miller3_range2(H, tc, px, py, pinf, Q, tc2, px2, py2, pinf2, Q2, hi, lo, t);
             else miller3_range(H, tc, px, py, pinf, Q, hi, lo, t);
-            if (p == MILLER_TASKS - 1) f12t_conj(H, H, t);
-            st_store<fp4, ST_ROWS_F>(st + ST_F * 64, lane, H);
+            if (p == MILLER_TASKS - 1) f12t_conj_h(H, t);
+            {
+                fp4 f;
+                slot_load(f, H);
+                st_store<fp4, ST_ROWS_F>(st + ST_F * 64, lane, f);
+            }
             if (p < MILLER_TASKS - 1) {
                 st_store<fp2, ST_ROWS_TC>(st + ST_TC1 * 64, lane, tc);
                 if (EQ) st_store<fp2, ST_ROWS_TC>(st + ST_TC2 * 64, lane, tc2);
@@ -289,13 +305,18 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
             }
         }
         queue_publish(flags, g, p, poisoned, lane);
+        if (stamps && lane == 0) {
+            unsigned long long* o = stamps + 4 * (size_t)task;
+            o[0] = ts_claim; o[1] = ts_start; o[2] = __builtin_amdgcn_s_memtime();
+            o[3] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);      // HW_ID | XCC_ID
+        }
     }
 }
 
 __global__ void __launch_bounds__(BLOCK, 2) pair3_queue_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag, uint4* state,
-                                                            unsigned int* flags, unsigned int* counter, int spin_limit) {
+                                                            unsigned int* flags, unsigned int* counter, int spin_limit, unsigned long long* stamps) {
     __shared__ fp4_slot slots[BLOCK];
-    pair3_queue_body<false>(n, g1, g2, nullptr, nullptr, 0, gt, bad_flag, state, flags, counter, spin_limit, slots[threadIdx.x].v);
+    pair3_queue_body<false>(n, g1, g2, nullptr, nullptr, 0, gt, bad_flag, state, flags, counter, spin_limit, slots[threadIdx.x].v, stamps);
 }
 __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_queue_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2,
                                                                size_t b2_stride, uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags,
@@ -375,12 +396,20 @@ __device__ __forceinline__ void pair3_fixed_queue_body(size_t n, const uint8_t* 
                 if (TWO) { if (t.role == 0) out[e] = 0xff; } else gt_poison(out + 576 * e, t.role);
             }
         } else if (p < MILLER_TASKS) {
-            if (p == 0) f12t_one(H, t); else st_load<fp4, ST_ROWS_F>(H, st + ST_F * 64, lane);
+            {
+                fp4 f;
+                if (p == 0) f12t_one(f, t); else st_load<fp4, ST_ROWS_F>(f, st + ST_F * 64, lane);
+                slot_store(H, f);
+            }
             const int hi = 64 - 16 * (int)p, lo = hi - 15;
             if (TWO) miller3_range2_fixed(H, ax, ay, ainf, tabw, cx, cy, cinf, tabg, hi, lo, t);
             else miller3_range_fixed(H, ax, ay, ainf, tabw, hi, lo, t);
-            if (p == MILLER_TASKS - 1) f12t_conj(H, H, t);
-            st_store<fp4, ST_ROWS_F>(st + ST_F * 64, lane, H);
+            if (p == MILLER_TASKS - 1) f12t_conj_h(H, t);
+            {
+                fp4 f;
+                slot_load(f, H);
+                st_store<fp4, ST_ROWS_F>(st + ST_F * 64, lane, f);
+            }
         } else {
             const int step = (int)(p - MILLER_TASKS);
             fp4 r, y1, aux;
@@ -440,7 +469,7 @@ __global__ void __launch_bounds__(BLOCK, 2) miller3_kernel(size_t n, const uint8
     miller3_loop(H, px, py, pinf, qx, qy, qinf, t);
     if (active) {
         if (!ok) { uint4* q = reinterpret_cast<uint4*>(out + 576 * i + (t.role == 0 ? 384 : (t.role == 1 ? 192 : 0))); for (int j = 0; j < 12; ++j) q[j] = make_uint4(~0u, ~0u, ~0u, ~0u); }
-        else { fp4 F = H; gt_store_coeff(out + 576 * i, F, t.role); }
+        else { fp4 F; slot_load(F, H); gt_store_coeff(out + 576 * i, F, t.role); }
     }
 }
 // op 0: a*b (FP12_mul), 1: conj(a), 2: a^e (FP12_pow, e = 32-byte exponent used as given), 3: final exponentiation

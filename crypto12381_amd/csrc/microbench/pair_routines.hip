@@ -50,28 +50,32 @@ __global__ void __launch_bounds__(BLOCK, PR_WAVES) routine_kernel(int iters, con
     const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const int32_t* sp = seed + (gid % 4096) * 8 * NL;
     fp4 a; fp2 tc; fp px, py;
-    load_fp4(a, sp); load_fp4(H, sp + 4 * NL);
+    load_fp4(a, sp);
+    { fp4 h0; load_fp4(h0, sp + 4 * NL); slot_store(H, h0); }
     tc = a.b; px = a.a.a; py = a.a.b;
     uint64_t t0 = 0, r0 = 0;
     if (threadIdx.x == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
 #pragma unroll 1
     for (int it = 0; it < iters; ++it) {
-        if constexpr (KIND == 0) f12t_sqr(H, H, t);
+        if constexpr (KIND == 0) f12t_sqr_h(H, t);
         else if constexpr (KIND == 1) miller3_dbl_line(H, tc, px, py, false, t);
-        else if constexpr (KIND == 2) f12t_usqr(H, H, (it & 1) == 0, t);
-        else if constexpr (KIND == 3) f12t_mul(H, H, a, t);
-        else if constexpr (KIND == 4) f12t_mul_line(H, tc, a.a, a.b, t);
-        else if constexpr (KIND == 5) { fp4 w; fp4_mul_call(w, a, H); H = w; }
-        else if constexpr (KIND == 6) { fp4 w; f12t_frob(w, H, t); H = w; }
+        else if constexpr (KIND == 2) f12t_usqr_h(H, (it & 1) == 0, t);
+        else if constexpr (KIND == 3) f12t_mul_h(H, a, t);
+        else if constexpr (KIND == 10) { fp4 w; f12t_mul(w, a, a, t); a = w; }
+        else if constexpr (KIND == 4) f12t_mul_line_h(H, tc, a.a, a.b, t);
+        else if constexpr (KIND == 5) { fp4 w; fp4_mul_call(w, a, a); a = w; }
+        else if constexpr (KIND == 6) { fp4 w; f12t_frob(w, a, t); a = w; }
         else if constexpr (KIND == 7) { fp r; fp_mul(r, px, py); fp_mul(px, r, py); }          // two dependent Fp products, registers only
         else if constexpr (KIND == 8) { fp2 r; fp2_mul(r, tc, a.a); fp2_mul(tc, r, a.a); }      // two dependent Fp2 products
-        else if constexpr (KIND == 9) { f12t_sqr(H, H, t); miller3_dbl_line(H, tc, px, py, false, t); }   // one Miller iteration without addition step
+        else if constexpr (KIND == 9) { f12t_sqr_h(H, t); miller3_dbl_line(H, tc, px, py, false, t); }   // one Miller iteration without addition step
     }
     if (threadIdx.x == 0) {
         const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
         stamps[2 * blockIdx.x] = t1 - t0; stamps[2 * blockIdx.x + 1] = r1 - r0;
     }
-    fp4 o = H;
+    fp4 o;
+    slot_load(o, H);
+    fp4_add(o, o, a);
     fp_add(o.a.a, o.a.a, px); fp_add(o.a.b, o.a.b, py); fp_add(o.b.a, o.b.a, tc.a); fp_add(o.b.b, o.b.b, tc.b);
     store_fp4(sink + gid * 4 * NL, o);
 }
@@ -120,12 +124,13 @@ int main(int argc, char** argv) {
     if (run<7>("2x fp_mul (regs)", iters * 20, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
     if (run<8>("2x fp2_mul (regs)", iters * 8, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
     if (run<5>("fp4_mul_call", iters * 2, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
-    if (run<0>("f12t_sqr", iters, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
+    if (run<0>("f12t_sqr_h", iters, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
     if (run<1>("miller3_dbl_line", iters, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
     if (run<9>("sqr + dbl_line", iters, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
-    if (run<2>("f12t_usqr", iters * 2, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
-    if (run<3>("f12t_mul", iters, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
-    if (run<4>("f12t_mul_line", iters, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
+    if (run<2>("f12t_usqr_h", iters * 2, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
+    if (run<3>("f12t_mul_h (LDS)", iters, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
+    if (run<10>("f12t_mul (private)", iters, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
+    if (run<4>("f12t_mul_line_h", iters, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
     if (run<6>("f12t_frob", iters * 2, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
     return 0;
 }

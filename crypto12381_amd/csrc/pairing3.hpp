@@ -44,6 +44,47 @@ C12381_HD void tri_fetch_fp4(fp4& out, const fp4& v, int s, const tri& t) { tri_
 C12381_HD int tri_next(const tri& t) { return t.role == 2 ? 0 : t.role + 1; }
 C12381_HD int tri_prev(const tri& t) { return t.role == 0 ? 2 : t.role - 1; }
 
+// ------------------------------------------------------------------ the per-lane LDS slot
+// The running Fp12 coefficient of the Miller loop and of the exponentiations lives in one 224-byte LDS slot per lane (k_pair3.hip).
+// The out-of-line routines below that end in _h take THAT slot: they move it with explicit LDS instructions (ds_read_b128 /
+// ds_write_b128 through an address-space-3 pointer).  Through a plain reference the same accesses compile to flat_load / flat_store,
+// which the hardware completes out of order — every wait on one of them is a full vmcnt(0) + lgkmcnt(0) drain that also waits
+// for the wavefront's pending private-memory stores (MI355X_MICROARCH.md, s_waitcnt).
+// slot_park / slot_unpark are the volatile forms: a value parked in the slot is really written and really read back instead of
+// being kept alive in 56 registers across an Fp4 product (f12t_mul_h).
+// C12381_PHASE(): a scheduling fence.  The build schedules for instruction-level parallelism (build.py), and two independent Fp4
+// products in one routine are exactly what such a scheduler interleaves — doubling the live registers and spilling hundreds of
+// dwords.  The fence keeps the phases of a routine apart (no instruction crosses it), as a call boundary used to.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define C12381_PHASE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define C12381_PHASE() do { } while (0)
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef int32_t c12381_v4i __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) c12381_v4i c12381_lds_v4i;
+static_assert(sizeof(fp4) == 14 * 16, "fp4 is 14 rows of 16 bytes on the device");
+template <class P> C12381_HD void slot_rd(fp4& r, P p) {
+    int32_t* w = reinterpret_cast<int32_t*>(&r);
+#pragma unroll
+    for (int i = 0; i < 14; ++i) { const c12381_v4i v = p[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
+}
+template <class P> C12381_HD void slot_wr(P p, const fp4& r) {
+    const int32_t* w = reinterpret_cast<const int32_t*>(&r);
+#pragma unroll
+    for (int i = 0; i < 14; ++i) { c12381_v4i v; v.x = w[4 * i]; v.y = w[4 * i + 1]; v.z = w[4 * i + 2]; v.w = w[4 * i + 3]; p[i] = v; }
+}
+C12381_HD void slot_load(fp4& r, const fp4& slot) { slot_rd(r, (const c12381_lds_v4i*)(&slot)); }
+C12381_HD void slot_store(fp4& slot, const fp4& r) { slot_wr((c12381_lds_v4i*)(&slot), r); }
+C12381_HD void slot_unpark(fp4& r, const fp4& slot) { slot_rd(r, (const volatile c12381_lds_v4i*)(&slot)); }
+C12381_HD void slot_park(fp4& slot, const fp4& r) { slot_wr((volatile c12381_lds_v4i*)(&slot), r); }
+#else
+C12381_HD void slot_load(fp4& r, const fp4& slot) { r = slot; }
+C12381_HD void slot_store(fp4& slot, const fp4& r) { slot = r; }
+C12381_HD void slot_unpark(fp4& r, const fp4& slot) { r = slot; }
+C12381_HD void slot_park(fp4& slot, const fp4& r) { slot = r; }
+#endif
+
 // ------------------------------------------------------------------ inlined Fp4 cores (operands stay in registers)
 C12381_HD void fp4_mul_core(fp4& w, const fp4& x, const fp4& y) {
     fp2 t1, t2, t3, t4;
@@ -96,8 +137,49 @@ C12381_HDN void f12t_mul(fp4& w, const fp4& x, const fp4& y, const tri& t) {
     fp4_sub(e, zc, z); fp4_sub(e, e, zn); fp4_norm1(e, e);
     f12t_combine(w, z, zn, e, t);
 }
-// w = x^2 (FP12_sqr :190-238 as six squarings: z_r = x_r^2, (x_r + x_{r+1})^2).  w may alias x.
-C12381_HDN void f12t_sqr(fp4& w, const fp4& x, const tri& t) {
+// H <- H * y for the value in this lane's LDS slot (y: any memory, read only).  Same Karatsuba as f12t_mul, scheduled so that
+// NOTHING is stored to private memory: (x + x')(y + y') is formed first and parked in the slot while x y takes the whole register
+// budget (x has been read back from the slot by then), and read back for the combination.  f12t_mul exchanges
+// its operands and both products with the out-of-line fp4_mul_call through private memory — four dependent store -> load round
+// trips to HBM per product (measured: 64.7 K cycles per call against 37.7 K of issue, profiles/r02_pair_routines_2waves.txt).
+C12381_HDN void f12t_mul_h(fp4& H, const fp4& y, const tri& t) {
+    fp4 z, zc, zn, e, w;
+    {   // (x + x')(y + y') first: its operands are sums, so x and y need not stay in registers while it runs
+        fp4 sx, sy;
+        {
+            fp4 x, yv, xn, yn;
+            slot_load(x, H);
+            yv = y;
+            tri_fetch_fp4(xn, x, tri_next(t), t);
+            tri_fetch_fp4(yn, yv, tri_next(t), t);
+            fp4_addn(sx, x, xn); fp4_addn(sy, yv, yn);
+        }
+        C12381_PHASE();
+        fp4_mul_core(zc, sx, sy);
+        C12381_PHASE();
+    }
+    {   // x y: x comes back from the slot, which then takes zc; y is read again through a pointer the compiler cannot match
+        // with the first read (it would otherwise keep all of y alive across the first product)
+        fp4 x, yv;
+        slot_unpark(x, H);
+        slot_park(H, zc);
+        const fp4* yp = &y;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(yp));
+#endif
+        yv = *yp;
+        C12381_PHASE();
+        fp4_mul_core(z, x, yv);
+        C12381_PHASE();
+    }
+    slot_unpark(zc, H);
+    tri_fetch_fp4(zn, z, tri_next(t), t);
+    fp4_sub(e, zc, z); fp4_sub(e, e, zn); fp4_norm1(e, e);
+    f12t_combine(w, z, zn, e, t);
+    slot_store(H, w);
+}
+// w = x^2 (FP12_sqr :190-238 as six squarings: z_r = x_r^2, (x_r + x_{r+1})^2).
+C12381_HD void f12t_sqr_body(fp4& w, const fp4& x, const tri& t) {
     fp4 xn, z, zc, zn, e, sx;
     tri_fetch_fp4(xn, x, tri_next(t), t);
     fp4_sqr_core(z, x);
@@ -107,9 +189,11 @@ C12381_HDN void f12t_sqr(fp4& w, const fp4& x, const tri& t) {
     fp4_sub(e, zc, z); fp4_sub(e, e, zn); fp4_norm1(e, e);
     f12t_combine(w, z, zn, e, t);
 }
+C12381_HDN void f12t_sqr(fp4& w, const fp4& x, const tri& t) { fp4 xv = x, r; f12t_sqr_body(r, xv, t); w = r; }      // w may alias x
+C12381_HDN void f12t_sqr_h(fp4& H, const tri& t) { fp4 x, r; slot_load(x, H); f12t_sqr_body(r, x, t); slot_store(H, r); }
 // Granger-Scott unitary squaring (FP12_usqr :147-186): one Fp4 squaring per lane.
 //   w_a = 3 xa^2 - 2 conj(xa),  w_b = 3 s xc^2 + 2 conj(xb),  w_c = 3 xb^2 - 2 conj(xc)
-C12381_HDN void f12t_usqr(fp4& w, const fp4& x, bool reduce, const tri& t) {
+C12381_HD void f12t_usqr_body(fp4& w, const fp4& x, bool reduce, const tri& t) {
     fp4 q, qq, sq, three, lin, c1, c2, r;
     fp4_sqr_core_raw(q, x);                                // un-normalised: one carry round after the select below
     const int src = t.role == 0 ? t.role : (t.role == 1 ? tri_next(t) : tri_prev(t));
@@ -124,12 +208,15 @@ C12381_HDN void f12t_usqr(fp4& w, const fp4& x, bool reduce, const tri& t) {
     fp4_add(r, three, lin);
     if (reduce) fp4_weak_reduce(w, r); else fp4_norm1(w, r);
 }
+C12381_HDN void f12t_usqr(fp4& w, const fp4& x, bool reduce, const tri& t) { fp4 xv = x, r; f12t_usqr_body(r, xv, reduce, t); w = r; }
+C12381_HDN void f12t_usqr_h(fp4& H, bool reduce, const tri& t) { fp4 x, r; slot_load(x, H); f12t_usqr_body(r, x, reduce, t); slot_store(H, r); }
 // FP12_conj :117-123
 C12381_HD void f12t_conj(fp4& w, const fp4& x, const tri& t) {
     fp4 c1, c2;
     fp4_conj(c1, x); fp4_nconj(c2, x);
     fp4_select(w, t.role == 1, c2, c1);
 }
+C12381_HD void f12t_conj_h(fp4& H, const tri& t) { fp4 x, r; slot_load(x, H); f12t_conj(r, x, t); slot_store(H, r); }
 // FP12_frob :867-880
 C12381_HDN void f12t_frob(fp4& w, const fp4& x, const tri& t) {
     fp2 f, f2, f3, m;
@@ -198,43 +285,57 @@ C12381_HD void f12t_mul_line_core(fp4& x, const fp2& l0, const fp2& l1, const fp
     fp4_norm1(x, p);
 }
 C12381_HDN void f12t_mul_line(fp4& x, const fp2& l0, const fp2& l1, const fp2& l2, const tri& t) { f12t_mul_line_core(x, l0, l1, l2, t); }
-// w <- a^x for unitary a, x < 0, computed IN w (w must not alias a): the running value never leaves `w`, which the
-// kernels place in LDS — the 63 squarings then exchange their operand at LDS latency instead of through private memory
-C12381_HDN void f12t_pow_x(fp4& w, const fp4& a, const tri& t) {
-    w = a;
+C12381_HDN void f12t_mul_line_h(fp4& H, const fp2& l0, const fp2& l1, const fp2& l2, const tri& t) {
+    fp4 x;
+    slot_load(x, H);
+    f12t_mul_line_core(x, l0, l1, l2, t);
+    slot_store(H, x);
+}
+// h <- a^x for unitary a, x < 0, computed IN the LDS slot h: the 63 squarings and 5 products move the running value with LDS
+// instructions only; `a` is read from wherever it lives (private memory in the kernels), never written.
+C12381_HDN void f12t_pow_x(fp4& h, const fp4& a, const tri& t) {
+    {
+        fp4 av = a;
+        slot_store(h, av);
+    }
 #pragma unroll 1
     for (int i = 62; i >= 0; --i) {
-        f12t_usqr(w, w, (i & 1) == 0, t);
-        if ((BLS_X >> i) & 1ull) f12t_mul(w, w, a, t);
+        f12t_usqr_h(h, (i & 1) == 0, t);
+        if ((BLS_X >> i) & 1ull) f12t_mul_h(h, a, t);
     }
-    f12t_conj(w, w, t);
+    f12t_conj_h(h, t);
 }
 // PAIR_fexp :629-755 as six steps (the work-queue kernels schedule them as separate tasks; state between steps: r, y1
-// and — after step 4 — aux).  `h` is working storage for the exponentiation by x (kernels: an LDS slot).
+// and — after step 4 — aux).  `h` is this lane's LDS slot: every product is h <- h * (operand in private memory).
 //   0: easy part, y1 = r^3      1, 2: r <- r^(x-1)      3: r <- r^(x+p)      4: aux = r^x      5: r <- aux^x r^(p^2-1) y1
 C12381_HDN void f12t_final_exp_step(int step, fp4& r, fp4& y1, fp4& aux, fp4& h, const tri& t) {
     fp4 t0;
     if (step == 0) {
         f12t_inv(t0, r, t);
-        f12t_conj(r, r, t);
-        f12t_mul(r, r, t0, t);
+        { fp4 c; f12t_conj(c, r, t); slot_store(h, c); }
+        f12t_mul_h(h, t0, t);                                                 // conj(r) / r
+        slot_load(r, h);
         f12t_frob(t0, r, t); f12t_frob(t0, t0, t);
-        f12t_mul(r, t0, r, t);
-        f12t_usqr(y1, r, false, t); f12t_mul(y1, y1, r, t);                   // r^3
+        f12t_mul_h(h, t0, t);                                                 // ^(p^2 + 1)
+        slot_load(r, h);
+        f12t_usqr_h(h, false, t); f12t_mul_h(h, r, t);                        // r^3
+        slot_load(y1, h);
     } else if (step <= 3) {
         f12t_pow_x(h, r, t);
         if (step == 3) f12t_frob(t0, r, t); else f12t_conj(t0, r, t);
-        f12t_mul(r, h, t0, t);                                                // r^(x-1) twice, then r^(x+p)
+        f12t_mul_h(h, t0, t);                                                 // r^(x-1) twice, then r^(x+p)
+        slot_load(r, h);
     } else if (step == 4) {
         f12t_pow_x(h, r, t);
-        aux = h;                                                              // r^x
+        slot_load(aux, h);                                                    // r^x
     } else {
         f12t_pow_x(h, aux, t);                                                // r^(x^2)
         f12t_frob(t0, r, t); f12t_frob(t0, t0, t);                            // r^(p^2)
-        f12t_mul(h, h, t0, t);
+        f12t_mul_h(h, t0, t);
         f12t_conj(t0, r, t);
-        f12t_mul(r, h, t0, t);                                                // ^(x^2+p^2-1)
-        f12t_mul(r, r, y1, t);
+        f12t_mul_h(h, t0, t);                                                 // ^(x^2+p^2-1)
+        f12t_mul_h(h, y1, t);
+        slot_load(r, h);
     }
 }
 C12381_HD void f12t_final_exp_ws(fp4& r, fp4& h, const tri& t) {
@@ -242,10 +343,13 @@ C12381_HD void f12t_final_exp_ws(fp4& r, fp4& h, const tri& t) {
 #pragma unroll 1
     for (int step = 0; step < 6; ++step) f12t_final_exp_step(step, r, y1, aux, h, t);
 }
-C12381_HD void f12t_final_exp(fp4& r, const tri& t) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+// host simulation only: on the device the working slot has to be LDS (slot_load / slot_store)
+inline void f12t_final_exp(fp4& r, const tri& t) {
     fp4 h;
     f12t_final_exp_ws(r, h, t);
 }
+#endif
 C12381_HD void f12t_one(fp4& F, const tri& t);
 // FP12_pow :736-774 on a triple, exponent e < 2^256 used AS GIVEN (the three lanes of a triple hold the same e): the
 // reference's signed-digit ladder over (3e, e) with Granger-Scott squarings — a power only for unitary inputs, like
@@ -348,12 +452,16 @@ C12381_HDN void miller3_dbl_step(fp2& tc, fp2& l0, fp2& l1, fp2& l2, const fp& p
 // doubling step and the multiplication of f by its line in ONE out-of-line routine: the three line coefficients stay in
 // registers instead of crossing two call boundaries through memory (42 stores + 42 loads per iteration).
 // skip: the G1 argument of this pair is infinity — its line is replaced by 1 (PAIR_ate returns 1 for it, :448-449).
+// F is this lane's LDS slot.
 C12381_HDN void miller3_dbl_line(fp4& F, fp2& tc, const fp& px, const fp& py, bool skip, const tri& t) {
     fp2 l0, l1, l2, one2, zero2;
     miller3_dbl_step_core(tc, l0, l1, l2, px, py, t);
     fp2_one(one2); fp2_zero(zero2);
     fp2_select(l0, skip, one2, l0); fp2_select(l1, skip, zero2, l1); fp2_select(l2, skip, zero2, l2);
-    f12t_mul_line_core(F, l0, l1, l2, t);
+    fp4 x;
+    slot_load(x, F);
+    f12t_mul_line_core(x, l0, l1, l2, t);
+    slot_store(F, x);
 }
 // ------------------------------------------------------------------ Miller loop on a triple, in pieces
 // (the kernels run it either whole or as two half-ranges of a work queue, see k_pair3.hip)
@@ -387,14 +495,14 @@ C12381_HD void miller3_pair_step(fp4& F, fp2& tc, const fp& px, const fp& py, bo
         fp2_select(tc, t.role == 0, T.x, T.y); fp2_select(tc, t.role == 2, T.z, tc);
         fp2_one(one2); fp2_zero(zero2);
         fp2_select(l0, skip, one2, l0); fp2_select(l1, skip, zero2, l1); fp2_select(l2, skip, zero2, l2);
-        f12t_mul_line(F, l0, l1, l2, t);
+        f12t_mul_line_h(F, l0, l1, l2, t);
     }
 }
 // iterations hi .. lo (inclusive, 64 >= hi >= lo >= 1) of the loop for one pair / for two pairs sharing the squarings
 C12381_HDN void miller3_range(fp4& F, fp2& tc, const fp& px, const fp& py, bool skip, const g2p& Q, int hi, int lo, const tri& t) {
 #pragma unroll 1
     for (int i = hi; i >= lo; --i) {
-        f12t_sqr(F, F, t);
+        f12t_sqr_h(F, t);
         miller3_pair_step(F, tc, px, py, skip, Q, i, t);
     }
 }
@@ -402,7 +510,7 @@ C12381_HDN void miller3_range2(fp4& F, fp2& tc1, const fp& px1, const fp& py1, b
                                fp2& tc2, const fp& px2, const fp& py2, bool skip2, const g2p& Q2, int hi, int lo, const tri& t) {
 #pragma unroll 1
     for (int i = hi; i >= lo; --i) {
-        f12t_sqr(F, F, t);
+        f12t_sqr_h(F, t);
         miller3_pair_step(F, tc1, px1, py1, skip1, Q1, i, t);
         miller3_pair_step(F, tc2, px2, py2, skip2, Q2, i, t);
     }
@@ -417,7 +525,7 @@ struct miller3_pair { fp px, py; fp2 tc; g2p Q; bool skip; };
 C12381_HDN void miller3_rangeK(fp4& F, miller3_pair* pr, int K, int hi, int lo, const tri& t) {
 #pragma unroll 1
     for (int i = hi; i >= lo; --i) {
-        f12t_sqr(F, F, t);
+        f12t_sqr_h(F, t);
 #pragma unroll 1
         for (int j = 0; j < K; ++j) miller3_pair_step(F, pr[j].tc, pr[j].px, pr[j].py, pr[j].skip, pr[j].Q, i, t);
     }
@@ -488,7 +596,10 @@ C12381_HDN void miller3_fixed_line(fp4& F, const int32_t* tab, int k, const fp& 
     tri_fetch_fp2(l2, prod, 1, t);
     fp2_one(one2); fp2_zero(zero2);
     fp2_select(l0, skip, one2, l0); fp2_select(c1, skip, zero2, c1); fp2_select(l2, skip, zero2, l2);
-    f12t_mul_line_core(F, l0, c1, l2, t);
+    fp4 x;
+    slot_load(x, F);
+    f12t_mul_line_core(x, l0, c1, l2, t);
+    slot_store(F, x);
 }
 // iterations hi .. lo of the loop of one pair whose G2 argument is fixed (table tab)
 C12381_HDN void miller3_range_fixed(fp4& F, const fp& px, const fp& py, bool skip, const int32_t* tab, int hi, int lo, const tri& t) {
@@ -499,7 +610,7 @@ C12381_HDN void miller3_range_fixed(fp4& F, const fp& px, const fp& py, bool ski
     for (int j = 64; j > hi; --j) k += 1 + ((((N3 >> j) & 1) != ((N1 >> j) & 1)) ? 1 : 0);
 #pragma unroll 1
     for (int i = hi; i >= lo; --i) {
-        f12t_sqr(F, F, t);
+        f12t_sqr_h(F, t);
         miller3_fixed_line(F, tab, k++, px, py, skip, t);
         if (((N3 >> i) & 1) != ((N1 >> i) & 1)) miller3_fixed_line(F, tab, k++, px, py, skip, t);
     }
@@ -514,7 +625,7 @@ C12381_HDN void miller3_range2_fixed(fp4& F, const fp& px1, const fp& py1, bool 
     for (int j = 64; j > hi; --j) k += 1 + ((((N3 >> j) & 1) != ((N1 >> j) & 1)) ? 1 : 0);
 #pragma unroll 1
     for (int i = hi; i >= lo; --i) {
-        f12t_sqr(F, F, t);
+        f12t_sqr_h(F, t);
         miller3_fixed_line(F, tab1, k, px1, py1, skip1, t);
         miller3_fixed_line(F, tab2, k, px2, py2, skip2, t);
         ++k;
@@ -532,9 +643,9 @@ C12381_HDN void miller3_loop(fp4& F, const fp& px, const fp& py, bool p_inf, con
     fp2 tc;
     miller3_q(Q, qx, qy, q_inf);
     miller3_tc(tc, Q, t);
-    f12t_one(F, t);
+    { fp4 one; f12t_one(one, t); slot_store(F, one); }
     miller3_range(F, tc, px, py, p_inf, Q, 64, 1, t);
-    f12t_conj(F, F, t);
+    f12t_conj_h(F, t);
 }
 // Two Miller loops with SHARED squarings: F = conj(M(Q1, P1) * M(Q2, P2)) — the product the reference forms from two
 // pair_ate results (liner_pair.hpp:339-350) costs one Fp12 squaring per iteration instead of two.  As a field element
@@ -545,9 +656,9 @@ C12381_HDN void miller3_loop2(fp4& F, const fp& px1, const fp& py1, bool p_inf1,
     fp2 tc1, tc2;
     miller3_q(Q1, qx1, qy1, q_inf1); miller3_q(Q2, qx2, qy2, q_inf2);
     miller3_tc(tc1, Q1, t); miller3_tc(tc2, Q2, t);
-    f12t_one(F, t);
+    { fp4 one; f12t_one(one, t); slot_store(F, one); }
     miller3_range2(F, tc1, px1, py1, p_inf1, Q1, tc2, px2, py2, p_inf2, Q2, 64, 1, t);
-    f12t_conj(F, F, t);
+    f12t_conj_h(F, t);
 }
 
 }  // namespace c12381

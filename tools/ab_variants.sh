@@ -5,7 +5,7 @@ VARIANTS=${1:-"base"}
 shift
 for v in $VARIANTS; do
   if [ $v = base ]; then unset C12381_LIB; else export C12381_LIB=$GRAFT_REPO_ROOT/crypto12381_amd/lib/exp/lib$v.so; fi
-  python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > gpurun_out/ab_$v.json 2>gpurun_out/ab_$v.err || { tail -3 gpurun_out/ab_$v.err; continue; }
+  python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-msm --no-bbs "$@" > gpurun_out/ab_$v.json 2>gpurun_out/ab_$v.err || { tail -3 gpurun_out/ab_$v.err; continue; }
   python - <<PY
 import json
 d=json.load(open("gpurun_out/ab_$v.json"))
