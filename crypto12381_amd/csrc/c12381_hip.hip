@@ -725,17 +725,17 @@ static bool pair_use_queue(size_t n) {
     if (m >= 0) return m == 1;
     return (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE > PAIR_QUEUE_WAVES;
 }
-// state slab: [flags: one word per group][counter][pad to 256 B][42 x 1 KiB per group]
+// state slab: [flags: one word per group][task counter][whole-group counter][pad to 256 B][42 x 1 KiB per group]
 static int pair_queue_setup(c12381_ctx* c, size_t n, uint4*& state, unsigned int*& flags, unsigned int*& counter, unsigned& blocks) {
     const size_t groups = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE;
-    const size_t head = round_up((groups + 1) * 4, 256);
+    const size_t head = round_up((groups + 2) * 4, 256);          // flags | task counter | whole-group counter
     int rc;
     if ((rc = ensure(c, c12381_ctx::WS_PAIR_ST, head + groups * (size_t)PAIR_QUEUE_STATE_ROWS * 1024))) return rc;
     uint8_t* base = (uint8_t*)c->ws[c12381_ctx::WS_PAIR_ST];
     flags = (unsigned int*)base;
     counter = flags + groups;
     state = (uint4*)(base + head);
-    HIPCK(c, hipMemsetAsync(base, 0, (groups + 1) * 4, c->stream));
+    HIPCK(c, hipMemsetAsync(base, 0, (groups + 2) * 4, c->stream));
     const size_t waves = groups < PAIR_QUEUE_WAVES ? groups : PAIR_QUEUE_WAVES;
     blocks = (unsigned)((waves * 64 + BLOCK - 1) / BLOCK);
     return 0;

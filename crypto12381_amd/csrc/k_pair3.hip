@@ -95,23 +95,52 @@ __device__ __forceinline__ void gt_poison(uint8_t* o576, int role) {
 
 namespace c12381 {
 
+// One whole group of 21 pairings on this wavefront: Miller loop(s) + final exponentiation + output (lane element index i, shadow
+// lanes inactive).  EQ: e(a1, a2) == e(b1, b2)  <=>  e(a1, a2) * e(-b1, b2) == 1: one joint Miller loop (shared squarings), one
+// final exponentiation.  liner_pair.hpp:339-350 forms ate(a) * conj(ate(b)) from two separate loops; after the final
+// exponentiation both are e(a) / e(b) (conj and negating the G1 argument both invert the pairing value; the Miller values differ
+// by factors in Fp6, which the easy part kills), so the boolean is the same for all curve points, infinity arguments included.
+template <bool EQ>
+__device__ __forceinline__ void pair3_whole_group(size_t i, bool active, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2,
+                                                  size_t b2_stride, uint8_t* out, int* bad_flag, fp4& H, const tri& t) {
+    fp px, py; fp2 qx, qy; bool pinf, qinf, ok, okb = true;
+    pair_inputs(px, py, pinf, qx, qy, qinf, ok, a1 + 96 * i, a2 + 192 * i);
+    if (!ok) { pinf = true; qinf = true; }
+    if (EQ) {
+        fp px2, py2; fp2 qx2, qy2; bool pinf2, qinf2;
+        pair_inputs(px2, py2, pinf2, qx2, qy2, qinf2, okb, b1 + 96 * i, b2 + b2_stride * i);
+        if (!okb) { pinf2 = true; qinf2 = true; }
+        {
+            fp ny;
+            fp_neg(ny, py2);
+            fp_norm1(py2, ny);
+        }
+        miller3_loop2(H, px, py, pinf, qx, qy, qinf, px2, py2, pinf2, qx2, qy2, qinf2, t);
+    } else {
+        miller3_loop(H, px, py, pinf, qx, qy, qinf, t);
+    }
+    fp4 F;
+    slot_load(F, H);
+    f12t_final_exp_ws(F, H, t);
+    const bool valid = ok && okb;
+    if (EQ) {
+        const bool one = f12t_is_one(F, t);
+        if (active && t.role == 0) {
+            if (!valid) *bad_flag = 1;
+            out[i] = valid ? (one ? 1 : 0) : 0xff;
+        }
+    } else if (active) {
+        if (!valid) { *bad_flag = 1; gt_poison(out + 576 * i, t.role); }
+        else gt_store_coeff(out + 576 * i, F, t.role);
+    }
+}
+
 __global__ void __launch_bounds__(BLOCK, 2) pair3_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag) {
     if ((((size_t)blockIdx.x * BLOCK + threadIdx.x) >> 6) * TRI_PER_WAVE >= n) return;      // whole wavefront idle
     tri t; size_t i; bool active;
     tri_setup(t, i, active, n);
-    fp px, py; fp2 qx, qy; bool pinf, qinf, ok;
-    pair_inputs(px, py, pinf, qx, qy, qinf, ok, g1 + 96 * i, g2 + 192 * i);
-    if (!ok) { if (active) *bad_flag = 1; pinf = true; qinf = true; }
     __shared__ fp4_slot slots[BLOCK];
-    fp4& H = slots[threadIdx.x].v;
-    miller3_loop(H, px, py, pinf, qx, qy, qinf, t);
-    fp4 F;
-    slot_load(F, H);
-    f12t_final_exp_ws(F, H, t);
-    if (active) {
-        if (!ok) { uint4* q = reinterpret_cast<uint4*>(gt + 576 * i + (t.role == 0 ? 384 : (t.role == 1 ? 192 : 0))); for (int j = 0; j < 12; ++j) q[j] = make_uint4(~0u, ~0u, ~0u, ~0u); }
-        else gt_store_coeff(gt + 576 * i, F, t.role);
-    }
+    pair3_whole_group<false>(i, active, g1, g2, nullptr, nullptr, 0, gt, bad_flag, slots[threadIdx.x].v, t);
 }
 
 __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2,
@@ -120,33 +149,8 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_kernel(size_t n, const uint
     if ((((size_t)blockIdx.x * BLOCK + threadIdx.x) >> 6) * TRI_PER_WAVE >= n) return;
     tri t; size_t i; bool active;
     tri_setup(t, i, active, n);
-    // e(a1, a2) == e(b1, b2)  <=>  e(a1, a2) * e(-b1, b2) == 1: one joint Miller loop (shared squarings), one final
-    // exponentiation.  liner_pair.hpp:339-350 forms ate(a) * conj(ate(b)) from two separate loops; after the final
-    // exponentiation both are e(a) / e(b) (conj and negating the G1 argument both invert the pairing value; the
-    // Miller values differ by factors in Fp6, which the easy part kills), so the boolean is the same for all
-    // curve points, infinity arguments included.
-    fp px, py, px2, py2; fp2 qx, qy, qx2, qy2; bool pinf, qinf, pinf2, qinf2, ok, okb;
     __shared__ fp4_slot slots[BLOCK];
-    fp4& H = slots[threadIdx.x].v;
-    pair_inputs(px, py, pinf, qx, qy, qinf, ok, a1 + 96 * i, a2 + 192 * i);
-    if (!ok) { pinf = true; qinf = true; }
-    pair_inputs(px2, py2, pinf2, qx2, qy2, qinf2, okb, b1 + 96 * i, b2 + b2_stride * i);
-    if (!okb) { pinf2 = true; qinf2 = true; }
-    {
-        fp ny;
-        fp_neg(ny, py2);
-        fp_norm1(py2, ny);
-    }
-    miller3_loop2(H, px, py, pinf, qx, qy, qinf, px2, py2, pinf2, qx2, qy2, qinf2, t);
-    fp4 F;
-    slot_load(F, H);
-    f12t_final_exp_ws(F, H, t);
-    const bool one = f12t_is_one(F, t);
-    const bool valid = ok && okb;
-    if (active && t.role == 0) {
-        if (!valid) *bad_flag = 1;
-        out[i] = valid ? (one ? 1 : 0) : 0xff;
-    }
+    pair3_whole_group<true>(i, active, a1, a2, b1, b2, b2_stride, out, bad_flag, slots[threadIdx.x].v, t);
 }
 
 // gt[i] = prod_{j < k} e(g1[j * n + i], g2[j * n + i]),  k = 1 .. MAX_PROD: pair(a, b) * pair(c, d) [* pair(e, f)] as the headers
@@ -203,8 +207,24 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
     t.base = lane == 63u ? 63 : (int)(3u * trip);
     const size_t ngroups = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE;
     constexpr unsigned int MILLER_TASKS = 4, TASKS = MILLER_TASKS + 6;
-    const size_t ntasks = ngroups * TASKS;
     constexpr int ROWS = ST_Y1 + ST_ROWS_F;
+    // Hybrid schedule.  Wavefronts first claim WHOLE groups (counter[1]: no hand-over, no wait on a slower partner, the state stays
+    // in registers and in the LDS slot) until only the last nwaves / 2 groups are left; those go through the queue in tenth-length
+    // tasks (counter[0]), which is what evens out the end of the launch: whole groups finish up to a group-time apart (the two
+    // wavefronts of a SIMD do not share it evenly, profiles/r02_queue_phase_times.txt), ~5 small tasks per wavefront absorb that.
+    // 2^16 pairings on 2048 resident wavefronts: 2097 whole groups + 1024 queued ones (22.6 -> 20.4 ms with a static split).
+    // ndirect = 0 when the batch fits the grid (queue forced on for a small batch: tests of the queue path).
+    const size_t nwaves = (size_t)gridDim.x * (BLOCK / 64);
+    const size_t ndirect = ngroups > nwaves ? ngroups - nwaves / 2 : 0;
+    for (;;) {
+        const unsigned int gc = atomicAdd(counter + 1, lane == 0 ? 1u : 0u);
+        const size_t g = (size_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)gc);
+        if (g >= ndirect) break;
+        const size_t e = g * TRI_PER_WAVE + (lane == 63u ? TRI_PER_WAVE - 1 : trip);
+        pair3_whole_group<EQ>(e < n ? e : n - 1, lane < 63u && e < n, a1, a2, b1, b2, b2_stride, out, bad_flag, H, t);
+    }
+    const size_t nq = ngroups - ndirect;                       // queued groups: ndirect .. ngroups - 1
+    const size_t ntasks = nq * TASKS;
     for (;;) {
         // lane 0 claims a task; readfirstlane makes the number a scalar, so phase / group and every branch on them are
         // wave-uniform for the compiler too (a broadcast by shuffle leaves them "divergent": the loop was then
@@ -213,8 +233,8 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
         const unsigned int claimed = atomicAdd(counter, lane == 0 ? 1u : 0u);
         const unsigned int task = (unsigned int)__builtin_amdgcn_readfirstlane((int)claimed);
         if ((size_t)task >= ntasks) break;
-        const unsigned int p = (unsigned int)(task / ngroups);
-        const size_t g = task % ngroups;
+        const unsigned int p = (unsigned int)(task / nq);
+        const size_t g = ndirect + task % nq;
         const size_t e = g * TRI_PER_WAVE + (lane == 63u ? TRI_PER_WAVE - 1 : trip);
         const bool active = lane < 63u && e < n;
         const size_t i = e < n ? e : n - 1;          // inactive lanes shadow the last element: same instruction stream
@@ -368,14 +388,51 @@ __device__ __forceinline__ void pair3_fixed_queue_body(size_t n, const uint8_t* 
     t.base = lane == 63u ? 63 : (int)(3u * trip);
     const size_t ngroups = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE;
     constexpr unsigned int MILLER_TASKS = 4, TASKS = MILLER_TASKS + 6;
-    const size_t ntasks = ngroups * TASKS;
     constexpr int ROWS = ST_Y1 + ST_ROWS_F;
+    // whole groups first, the last nwaves / 2 groups through the queue (see pair3_queue_body)
+    const size_t nwaves = (size_t)gridDim.x * (BLOCK / 64);
+    const size_t ndirect = ngroups > nwaves ? ngroups - nwaves / 2 : 0;
+    for (;;) {
+        const unsigned int gc = atomicAdd(counter + 1, lane == 0 ? 1u : 0u);
+        const size_t g = (size_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)gc);
+        if (g >= ndirect) break;
+        const size_t e = g * TRI_PER_WAVE + (lane == 63u ? TRI_PER_WAVE - 1 : trip);
+        const bool active = lane < 63u && e < n;
+        const size_t i = e < n ? e : n - 1;
+        fp ax, ay, cx, cy; bool ainf, cinf = true, oka, okc = true;
+        g1_parse96(ax, ay, ainf, oka, a96 + 96 * i);
+        if (!oka || !table_ok) ainf = true;
+        if (TWO) {
+            g1_parse96(cx, cy, cinf, okc, c96 + 96 * i);
+            if (!okc) cinf = true;
+        }
+        { fp4 one; f12t_one(one, t); slot_store(H, one); }
+        if (TWO) miller3_range2_fixed(H, ax, ay, ainf, tabw, cx, cy, cinf, tabg, 64, 1, t);
+        else miller3_range_fixed(H, ax, ay, ainf, tabw, 64, 1, t);
+        f12t_conj_h(H, t);
+        fp4 F;
+        slot_load(F, H);
+        f12t_final_exp_ws(F, H, t);
+        if (TWO) {
+            const bool one = f12t_is_one(F, t);
+            const bool valid = oka && okc;
+            if (active && t.role == 0) {
+                if (!valid) *bad_flag = 1;
+                out[e] = valid ? (one ? 1 : 0) : 0xff;
+            }
+        } else if (active) {
+            if (!(oka && table_ok)) { *bad_flag = 1; gt_poison(out + 576 * e, t.role); }
+            else gt_store_coeff(out + 576 * e, F, t.role);
+        }
+    }
+    const size_t nq = ngroups - ndirect;
+    const size_t ntasks = nq * TASKS;
     for (;;) {
         const unsigned int claimed = atomicAdd(counter, lane == 0 ? 1u : 0u);
         const unsigned int task = (unsigned int)__builtin_amdgcn_readfirstlane((int)claimed);
         if ((size_t)task >= ntasks) break;
-        const unsigned int p = (unsigned int)(task / ngroups);
-        const size_t g = task % ngroups;
+        const unsigned int p = (unsigned int)(task / nq);
+        const size_t g = ndirect + task % nq;
         const size_t e = g * TRI_PER_WAVE + (lane == 63u ? TRI_PER_WAVE - 1 : trip);
         const bool active = lane < 63u && e < n;
         const size_t i = e < n ? e : n - 1;
