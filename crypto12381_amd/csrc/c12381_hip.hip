@@ -1,11 +1,12 @@
 // Context, workspaces and the C ABI of the batched BLS12-381 backend for MI355X (gfx950).
 // Public interface and reference citations: include/c12381_hip.h.  Kernels: kernels.hpp (k_g1.hip, k_g2gt.hip, k_pair3.hip).
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
 #include <new>
 #include <thread>
 #include <vector>
@@ -201,14 +202,39 @@ int g1_msm_pippenger(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t*
     int32_t* bk = (int32_t*)c->ws[c12381_ctx::WS_MSM_BK];
     hipLaunchKernelGGL(msm_prep_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, pts, sc, cb, W, pts2, k0, v0, c->d_flag);
     HIPCK(c, hipGetLastError());
-    int end_bit = cb;
-    while ((1 << (end_bit - cb)) <= W) ++end_bit;              // keys < (W + 1) << cb
-    size_t tmp_bytes = 0;
-    HIPCK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k0, k1, v0, v1, (int)E, 0, end_bit, c->stream));
-    if ((rc = ensure(c, c12381_ctx::WS_MSM_TMP, tmp_bytes + 256))) return rc;
-    HIPCK(c, hipcub::DeviceRadixSort::SortPairs(c->ws[c12381_ctx::WS_MSM_TMP], tmp_bytes, k0, k1, v0, v1, (int)E, 0, end_bit, c->stream));
+    // Sort by digit inside every window segment (msm_prep_one lays the entries out window by window): bits [0, cb) only — two
+    // 8-bit passes for cb = 16.  rocPRIM's radix sort is called directly; from 2^15 terms on once per segment, below that one
+    // call over all entries with the window bits included (a handful of launches instead of 3 per segment).
+    {
+        size_t tmp_bytes = 0, tb = 0;
+        const bool per_window = n >= ((size_t)1 << 15);
+        int end_bit = cb;
+        while ((1 << (end_bit - cb)) <= W) ++end_bit;              // keys < (W + 1) << cb
+        if (per_window) {
+            HIPCK(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, k0, k1, v0, v1, 2 * n, 0, cb, c->stream));
+            HIPCK(c, rocprim::radix_sort_pairs(nullptr, tb, k0, k1, v0, v1, n, 0, 1, c->stream));
+            if (tb > tmp_bytes) tmp_bytes = tb;
+        } else {
+            HIPCK(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, k0, k1, v0, v1, E, 0, end_bit, c->stream));
+        }
+        if ((rc = ensure(c, c12381_ctx::WS_MSM_TMP, tmp_bytes + 256))) return rc;
+        void* tmp = c->ws[c12381_ctx::WS_MSM_TMP];
+        if (per_window) {
+            for (int w = 0; w < W; ++w) {
+                const size_t off = (size_t)2 * w * n;
+                size_t sz = tmp_bytes;
+                HIPCK(c, rocprim::radix_sort_pairs(tmp, sz, k0 + off, k1 + off, v0 + off, v1 + off, 2 * n, 0, cb, c->stream));
+            }
+            const size_t off = (size_t)2 * W * n;
+            size_t sz = tmp_bytes;
+            HIPCK(c, rocprim::radix_sort_pairs(tmp, sz, k0 + off, k1 + off, v0 + off, v1 + off, n, 0, 1, c->stream));
+        } else {
+            size_t sz = tmp_bytes;
+            HIPCK(c, rocprim::radix_sort_pairs(tmp, sz, k0, k1, v0, v1, E, 0, end_bit, c->stream));
+        }
+    }
     HIPCK(c, hipMemsetAsync(lo, 0, (nbx + 1) * 8, c->stream));
-    hipLaunchKernelGGL(msm_ranges_kernel, dim3(grid_for(E)), dim3(BLOCK), 0, c->stream, E, k1, lo, hi);
+    hipLaunchKernelGGL(msm_ranges_kernel, dim3(grid_for(E)), dim3(BLOCK), 0, c->stream, E, k1, cb, W, lo, hi);
     HIPCK(c, hipGetLastError());
     // buckets in order of decreasing run length (k0 / v0 are free again after the first sort; the sorted size keys go
     // to k1, which the ranges kernel has finished with)
@@ -234,10 +260,14 @@ int g1_msm_pippenger(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t*
     HIPCK(c, hipMemsetAsync(ovf_cnt, 0, 16, c->stream));
     hipLaunchKernelGGL(msm_sizes_kernel, dim3(grid_for(nbx)), dim3(BLOCK), 0, c->stream, nbx, lo, hi, k0, v0, run_cap, ovf_cnt, ovf_seg, ovf_big);
     HIPCK(c, hipGetLastError());
-    size_t tmp2 = 0;
-    HIPCK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, k0, k1, v0, order, (int)nbx, 0, 32, c->stream));
-    if ((rc = ensure(c, c12381_ctx::WS_MSM_TMP, tmp2 + 256))) return rc;
-    HIPCK(c, hipcub::DeviceRadixSort::SortPairs(c->ws[c12381_ctx::WS_MSM_TMP], tmp2, k0, k1, v0, order, (int)nbx, 0, 32, c->stream));
+    {   // run-length keys are below 2^bits(cap): one or two passes instead of four
+        int kb = 1;
+        while (((uint32_t)1 << kb) <= run_cap) ++kb;
+        size_t tmp2 = 0;
+        HIPCK(c, rocprim::radix_sort_pairs(nullptr, tmp2, k0, k1, v0, order, nbx, 0, kb, c->stream));
+        if ((rc = ensure(c, c12381_ctx::WS_MSM_TMP, tmp2 + 256))) return rc;
+        HIPCK(c, rocprim::radix_sort_pairs(c->ws[c12381_ctx::WS_MSM_TMP], tmp2, k0, k1, v0, order, nbx, 0, kb, c->stream));
+    }
     {
         timed tm(c, 5);
         hipLaunchKernelGGL(msm_bucket_kernel, dim3(grid_for(nbx)), dim3(BLOCK), 0, c->stream, nbx, lo, hi, v1, pts2, bk, order, run_cap);

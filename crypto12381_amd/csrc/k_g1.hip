@@ -278,12 +278,10 @@ __global__ void __launch_bounds__(BLOCK, 2) msm_prep_kernel(size_t n, const uint
     if (!msm_prep_one(i, n, rp, rs, c, W, pts2, keys, vals)) *bad_flag = 1;
 }
 
-__global__ void __launch_bounds__(BLOCK, 2) msm_ranges_kernel(size_t E, const uint32_t* keys, uint32_t* lo, uint32_t* hi) {
+__global__ void __launch_bounds__(BLOCK, 2) msm_ranges_kernel(size_t E, const uint32_t* keys, int c, int W, uint32_t* lo, uint32_t* hi) {
     const size_t j = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (j >= E) return;
-    const uint32_t k = keys[j];
-    if (j == 0 || keys[j - 1] != k) lo[k] = (uint32_t)j;
-    if (j + 1 == E || keys[j + 1] != k) hi[k] = (uint32_t)(j + 1);
+    msm_ranges_one(j, E, keys, c, W, lo, hi);
 }
 
 // sort key for "longest run first": buckets are handed to lanes in order of decreasing size, so the 64 lanes of a
@@ -298,7 +296,7 @@ __global__ void __launch_bounds__(BLOCK, 2) msm_sizes_kernel(size_t nbk, const u
     const size_t b = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (b >= nbk) return;
     const uint32_t len = hi[b] - lo[b];
-    key[b] = 0xffffffffu - (len < cap ? len : cap);
+    key[b] = cap - (len < cap ? len : cap);              // 0 = longest: ascending order of this key is decreasing run length; < 2^bits(cap)
     ident[b] = (uint32_t)b;
     if (len > cap) {
         const uint32_t sl = cap / 2, ns = (len - cap + sl - 1) / sl;

@@ -8,9 +8,11 @@
 // (msm_small_term) — so the sum equals the reference's chain of multiply() results for every input, points outside the
 // order-r subgroup included.  Structure:
 //   prep     per point: parse, on-curve check, Montgomery form of P and of P' = (beta x, -y); per (half, window)
-//            one (key = window << c | digit, value = 2 i + half) entry, zero digits get the sentinel key (W << c) + 1;
-//            one more entry per point: key W << c if its scalar is below x^2, else the sentinel
-//   sort     device radix sort of the entries by key (hipCUB)
+//            one (key = window << c | digit, value = 2 i + half) entry, laid out window by window (msm_prep_one);
+//            one more entry per point in the small-scalar segment
+//   sort     the window positions are known when the entries are written, so only the c-bit digit is sorted: one rocPRIM
+//            radix sort per window segment on bits [0, c) — two 8-bit passes instead of the three a 20-bit composite key
+//            needs (small products: one call over all entries)
 //   bucket   one lane per (window, digit): sum of its run of points with the complete MIXED addition
 //   wreduce  per window sum_d d B_d by running sums over chunks of buckets, chunk offset by double-and-add
 //   horner   sum_w 2^(c w) R_w
@@ -111,16 +113,28 @@ C12381_HD bool msm_prep_one(size_t i, size_t n, const uint32_t* raw_pt /*24 word
     scalar_mod_r(k);
     uint32_t k0[4], k1[4];
     scalar_glv_split(k0, k1, k);
-    const uint32_t extra = (uint32_t)W << c, none = extra + 1u;
+    // Entry layout (what lets the sort work on c bits only): window w owns the 2n consecutive entries [2 w n, 2 (w + 1) n) —
+    // half 0 of term i at 2 w n + i, half 1 at 2 w n + n + i — with key = w << c | digit; digit 0 (nothing to add: a zero
+    // digit, the point at infinity, a point that is not on the curve) sorts to the front of its window and is skipped by
+    // msm_ranges.  The last n entries are the small-scalar segment: key = W << c | 1 if the term owes [r]phi(P), else W << c.
     const bool small = (k1[0] | k1[1] | k1[2] | k1[3]) == 0u;             // k mod r < x^2: multiply() owes [r]phi(P)
-    keys[(size_t)(2 * W) * n + i] = (usable && small) ? extra : none; vals[(size_t)(2 * W) * n + i] = (uint32_t)(2 * i);
+    keys[(size_t)(2 * W) * n + i] = ((uint32_t)W << c) | ((usable && small) ? 1u : 0u); vals[(size_t)(2 * W) * n + i] = (uint32_t)(2 * i);
     for (int w = 0; w < W; ++w) {
         const uint32_t d0 = msm_digit(k0, w, c), d1 = msm_digit(k1, w, c);
-        const size_t e0 = ((size_t)w) * n + i, e1 = ((size_t)(W + w)) * n + i;
-        keys[e0] = (usable && d0) ? (((uint32_t)w << c) | d0) : none; vals[e0] = (uint32_t)(2 * i);
-        keys[e1] = (usable && d1) ? (((uint32_t)w << c) | d1) : none; vals[e1] = (uint32_t)(2 * i + 1);
+        const size_t e0 = ((size_t)(2 * w)) * n + i, e1 = e0 + n;
+        keys[e0] = ((uint32_t)w << c) | (usable ? d0 : 0u); vals[e0] = (uint32_t)(2 * i);
+        keys[e1] = ((uint32_t)w << c) | (usable ? d1 : 0u); vals[e1] = (uint32_t)(2 * i + 1);
     }
     return ok;
+}
+// sorted entry j -> the bucket whose run it starts / ends.  Buckets: w << c | digit for the digit windows, W << c for the
+// small-scalar bucket; entries with digit 0 belong to no bucket.
+C12381_HD void msm_ranges_one(size_t j, size_t E, const uint32_t* keys, int c, int W, uint32_t* lo, uint32_t* hi) {
+    const uint32_t k = keys[j], d = k & ((1u << c) - 1u);
+    if (d == 0) return;
+    const uint32_t b = (k >> c) < (uint32_t)W ? k : ((uint32_t)W << c);
+    if (j == 0 || keys[j - 1] != k) lo[b] = (uint32_t)j;
+    if (j + 1 == E || keys[j + 1] != k) hi[b] = (uint32_t)(j + 1);
 }
 // bucket: sum of the points whose (sorted) entries lie in [lo, hi)
 // The gather (index -> 112-byte record somewhere in a table of 2n records) is a two-step dependent load of a few

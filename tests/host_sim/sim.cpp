@@ -377,12 +377,16 @@ extern "C" int sim_g1_msm_pippenger(size_t n, const uint8_t* pts96, const uint8_
     }
     std::vector<size_t> order(E);
     for (size_t j = 0; j < E; ++j) order[j] = j;
-    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return keys[a] < keys[b]; });
+    // as the device does it: every window segment of 2n entries (and the small-scalar segment) is sorted on its own by the digit bits
+    for (int w = 0; w <= W; ++w) {
+        const size_t a = (size_t)2 * w * n, b = w < W ? a + 2 * n : E;
+        std::stable_sort(order.begin() + a, order.begin() + b, [&](size_t x, size_t y) { return (keys[x] & ((1u << c) - 1u)) < (keys[y] & ((1u << c) - 1u)); });
+    }
     std::vector<uint32_t> ks(E), vs(E);
     for (size_t j = 0; j < E; ++j) { ks[j] = keys[order[j]]; vs[j] = vals[order[j]]; }
     const size_t nb = (size_t)1 << c, nbk = nb * W;
-    std::vector<size_t> lo(nbk + 2, 0), hi(nbk + 2, 0);          // + the small-scalar bucket (nbk) and the sentinel
-    for (size_t j = 0; j < E; ++j) { if (j == 0 || ks[j] != ks[j - 1]) lo[ks[j]] = j; if (j + 1 == E || ks[j + 1] != ks[j]) hi[ks[j]] = j + 1; }
+    std::vector<uint32_t> lo(nbk + 2, 0), hi(nbk + 2, 0);        // + the small-scalar bucket (nbk)
+    for (size_t j = 0; j < E; ++j) msm_ranges_one(j, E, ks.data(), c, W, lo.data(), hi.data());
     std::vector<int32_t> bkv((nbk + 1) * G1_ENT_DWORDS + 4);
     int32_t* bk = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(bkv.data()) + 15) & ~(uintptr_t)15);
     for (size_t b = 0; b <= nbk; ++b) {
