@@ -17,7 +17,7 @@ static void load_raw(uint32_t* w, const uint8_t* p, int nwords) { std::memcpy(w,
 
 extern "C" {
 
-// op: 0 mul 1 add 2 sub 3 sqr 4 neg 5 inv 6 sqrt-candidate 7 mul_small(12) 8 norm1 round trip
+// op: 0 mul 1 add 2 sub 3 sqr 4 neg 5 inv (divsteps) 6 sqrt-candidate 7 mul_small(12) 8 norm1 round trip 9 inv (Fermat)
 int sim_fp_op_batch(int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
     for (size_t i = 0; i < n; ++i) {
         uint32_t ra[12], rb[12], ro[12];
@@ -33,6 +33,7 @@ int sim_fp_op_batch(int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_
             case 5: fp_inv(r, x); break;
             case 6: fp_sqrt_candidate(r, x); break;
             case 7: fp_mul_small(r, x, 12); break;
+            case 9: fp_inv_fermat(r, x); break;
             case 8: { fp t; fp_add(t, x, y); fp_sub(t, t, y); fp_dbl(t, t); fp_norm1(r, t); fp_sub(r, r, x); } break;
             default: return -1;
         }

@@ -48,6 +48,23 @@ def test_sim_fp_ops(sim):
             assert pow(int.from_bytes(out[48 * i:48 * i + 48], "big"), 2, P) == int(g["a"][i], 16) % P
 
 
+def test_sim_inversion_by_divsteps(sim):
+    """fp_inv (safegcd divsteps, fp.hpp) against Python's modular inverse and against the Fermat ladder it replaced: edge values,
+    values the iteration treats specially (powers of two, p - small, small), a few thousand random ones; 0 -> 0 like FP_inv."""
+    from util import prng
+    vals = [0, 1, 2, 3, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2, P, P + 1, (1 << 384) - 1, (1 << 381) - 1, 0xd201000000010000]
+    vals += [1 << b for b in range(0, 384, 7)] + [(1 << b) - 1 for b in range(1, 384, 11)] + [P - (1 << b) for b in range(0, 380, 13)]
+    vals += [prng(4242, i, 48) for i in range(3000)]
+    a = b"".join((v % (1 << 384)).to_bytes(48, "big") for v in vals)
+    got = _fp(sim, 5, a, None)
+    fermat = _fp(sim, 9, a, None)
+    assert got == fermat
+    for i, v in enumerate(vals):
+        v %= 1 << 384
+        exp = pow(v % P, -1, P) if v % P else 0
+        assert int.from_bytes(got[48 * i:48 * i + 48], "big") == exp, hex(v)
+
+
 def test_sim_glv_split(sim):
     x2 = 0xd201000000010000 ** 2
     ks = [0, 1, R - 1, R, R + 5, (1 << 256) - 1, x2, x2 - 1, x2 + 1, 3 * x2 - 1] + \

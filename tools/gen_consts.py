@@ -163,6 +163,9 @@ def main():
     out.append(arr("FP_P", P, comment="p (Modulus)"))
     out.append(arr("FP_R1", RM % P, comment="R mod p = Montgomery form of 1"))
     out.append(arr("FP_R2", RM * RM % P, comment="R^2 mod p (to-Montgomery multiplier)"))
+    # modular inversion by divsteps (fp_inv): p as 13 limbs of 30 bits, p^-1 mod 2^30
+    out.append("C12381_CONST int32_t SG_P30[13] = {%s};  // p in 30-bit limbs\n" % ", ".join("0x%08x" % ((P >> (30 * i)) & ((1 << 30) - 1)) for i in range(13)))
+    out.append("constexpr uint32_t SG_PINV30 = 0x%xu;   // p^-1 mod 2^30\n" % pow(P, -1, 1 << 30))
     out.append(arr("FP_B3", mont(12), comment="3*b = 12 (G1), Montgomery form"))
     out.append(arr("FP_FOUR", mont(4), comment="b = 4"))
     out.append(arr("FP_HALF", mont(pow(2, -1, P)), comment="1/2"))
