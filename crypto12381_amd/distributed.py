@@ -61,9 +61,9 @@ def msm_sharded_tensors(local_msm_t: Callable[[torch.Tensor, torch.Tensor, int],
         partial = local_msm_t(pts_shard, scalars_shard, 96)
     else:
         partial = torch.zeros(96, dtype=torch.uint8, device=dev)          # empty shard: the point at infinity
-    if world == 1:
+    if not dist.is_initialized():
         gathered = partial
-    else:
+    else:                                                     # also with one rank: the exchange is the same call at every size
         gathered = torch.empty(96 * world, dtype=torch.uint8, device=dev)
         dist.all_gather_into_tensor(gathered, partial.contiguous(), group=group)
     ones = torch.zeros(world, 32, dtype=torch.uint8, device=dev)

@@ -9,6 +9,8 @@ import torch.multiprocessing as mp
 
 from util import golden, scalars
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 pytestmark = pytest.mark.gpu
 
 
@@ -106,3 +108,49 @@ def test_msm_in_parts(oracle_port):
     pts, sc = c.g1_mul(g1 * n, scalars(621, n), 96), scalars(622, n)
     c.close()
     assert ref == oracle_port.g1_msm(pts, sc, 49, 16).hex()
+
+
+RCCL_CODE = r"""
+import os, sys
+sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+import torch
+import torch.distributed as dist
+from util import golden, scalars
+os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29544')
+torch.cuda.set_device(0)
+dev = torch.device('cuda', 0)
+dist.init_process_group(backend='nccl', rank=0, world_size=1, device_id=dev)
+from crypto12381_amd import Context
+from crypto12381_amd.distributed import msm_sharded_tensors
+ctx = Context(0)
+stream = torch.cuda.Stream(device=dev)
+ctx.set_stream(stream.cuda_stream)
+n = 5000
+g1 = bytes.fromhex(golden('g1')['generator'])
+pts = ctx.g1_mul(g1 * n, scalars(631, n), 96)
+sc = scalars(632, n)
+tp = torch.frombuffer(bytearray(pts), dtype=torch.uint8).to(dev)
+ts = torch.frombuffer(bytearray(sc), dtype=torch.uint8).to(dev)
+def local_t(p, s, fmt):
+    o = torch.empty(fmt, dtype=torch.uint8, device=dev)
+    with torch.cuda.stream(stream):
+        ctx.g1_msm_dev(p.numel() // 96, p.data_ptr(), s.data_ptr(), o.data_ptr(), fmt)
+    return o
+with torch.cuda.stream(stream):
+    res = msm_sharded_tensors(local_t, tp, ts, 49)
+ctx.sync()
+print('RESULT', bytes(res.cpu().numpy().tobytes()).hex())
+print('EXPECT', ctx.g1_msm(pts, sc, 49).hex())
+dist.destroy_process_group()
+"""
+
+
+def test_rccl_exchange_on_device_tensors_single_rank():
+    """The device-resident sharded MSM through the nccl (= RCCL) backend: one rank on the one GPU of the test box — the partial
+    point goes through all_gather_into_tensor on a device tensor and the context's stream exactly as on the 8-GPU node."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", RCCL_CODE], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = dict(l.split(" ", 1) for l in r.stdout.splitlines() if l.startswith(("RESULT", "EXPECT")))
+    assert lines["RESULT"] == lines["EXPECT"]
