@@ -6,6 +6,19 @@
 #include "pairing3.hpp"
 #include "fixed_base.hpp"
 
+// Groups left to the tenth-length queue tasks at the end of a launch.  Measured on MI355X (profiles/r02_ab_queued_groups.txt):
+// 2^16 pairings (3121 groups, 2048 resident wavefronts): 2048 queued 21.8 ms, 1024 queued 19.4 ms, 512 queued 20.1 ms;
+// 2^18 BBS+ verifications (12484 groups): 2048 queued 82.0 ms, 1024 queued 82.4 ms, 512 queued 88.9 ms, 256 queued 97.3 ms —
+// the more whole groups a wavefront runs, the further apart the wavefronts finish: a third of the groups, between half a
+// grid and a whole grid.
+__device__ __forceinline__ size_t queue_direct_groups(size_t ngroups, size_t nwaves) {
+    if (ngroups <= nwaves) return 0;
+    size_t queued = ngroups / 3;
+    if (queued < nwaves / 2) queued = nwaves / 2;
+    if (queued > nwaves) queued = nwaves;
+    return ngroups - queued;
+}
+
 using namespace c12381;
 
 namespace {
@@ -209,13 +222,13 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
     constexpr unsigned int MILLER_TASKS = 4, TASKS = MILLER_TASKS + 6;
     constexpr int ROWS = ST_Y1 + ST_ROWS_F;
     // Hybrid schedule.  Wavefronts first claim WHOLE groups (counter[1]: no hand-over, no wait on a slower partner, the state stays
-    // in registers and in the LDS slot) until only the last nwaves / 2 groups are left; those go through the queue in tenth-length
+    // in registers and in the LDS slot) until only the last third of the groups (queue_direct_groups) is left; those go through the queue in tenth-length
     // tasks (counter[0]), which is what evens out the end of the launch: whole groups finish up to a group-time apart (the two
     // wavefronts of a SIMD do not share it evenly, profiles/r02_queue_phase_times.txt), ~5 small tasks per wavefront absorb that.
-    // 2^16 pairings on 2048 resident wavefronts: 2097 whole groups + 1024 queued ones (22.6 -> 20.4 ms with a static split).
+    // 2^16 pairings on 2048 resident wavefronts: 2081 whole groups + 1040 queued ones (22.6 -> 20.4 ms with a static split).
     // ndirect = 0 when the batch fits the grid (queue forced on for a small batch: tests of the queue path).
     const size_t nwaves = (size_t)gridDim.x * (BLOCK / 64);
-    const size_t ndirect = ngroups > nwaves ? ngroups - nwaves / 2 : 0;
+    const size_t ndirect = queue_direct_groups(ngroups, nwaves);
     for (;;) {
         const unsigned int gc = atomicAdd(counter + 1, lane == 0 ? 1u : 0u);
         const size_t g = (size_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)gc);
@@ -389,9 +402,9 @@ __device__ __forceinline__ void pair3_fixed_queue_body(size_t n, const uint8_t* 
     const size_t ngroups = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE;
     constexpr unsigned int MILLER_TASKS = 4, TASKS = MILLER_TASKS + 6;
     constexpr int ROWS = ST_Y1 + ST_ROWS_F;
-    // whole groups first, the last nwaves / 2 groups through the queue (see pair3_queue_body)
+    // whole groups first, the last third of the groups through the queue (see pair3_queue_body)
     const size_t nwaves = (size_t)gridDim.x * (BLOCK / 64);
-    const size_t ndirect = ngroups > nwaves ? ngroups - nwaves / 2 : 0;
+    const size_t ndirect = queue_direct_groups(ngroups, nwaves);
     for (;;) {
         const unsigned int gc = atomicAdd(counter + 1, lane == 0 ? 1u : 0u);
         const size_t g = (size_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)gc);

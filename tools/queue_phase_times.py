@@ -19,7 +19,12 @@ c.pair(p, q)
 c.pair(p, q)
 c.sync()
 a = np.fromfile(path, dtype=np.uint64).reshape(-1, 4)
-groups = (n + 20) // 21
+groups_all = (n + 20) // 21
+nwaves = 2048
+# the kernel's split (k_pair3.hip queue_direct_groups): whole groups first, the last third (between half a grid and a grid) queued
+queued = groups_all if groups_all <= nwaves else min(max(groups_all // 3, nwaves // 2), nwaves)
+groups = queued
+print("groups %d: %d claimed whole, %d through the queue (stamps cover the queued ones)" % (groups_all, groups_all - queued, queued))
 a = a[: groups * 10]
 claim, start, end = a[:, 0].astype(np.float64), a[:, 1].astype(np.float64), a[:, 2].astype(np.float64)
 hw = a[:, 3]
