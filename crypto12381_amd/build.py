@@ -27,6 +27,12 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # calls) returned wrong values for a few lanes of a full-size batch while passing every small test — not worth the risk.
 CFLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-fno-optimize-sibling-calls",
           "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+# Round 2 reproduced the wrong-values event with a rebuilt variant: whole wavefront groups wrong, plain grid as
+# well as queue, only with -amdgpu-use-amdgpu-trackers=1; the same source without it is exact on every lane.  The option is
+# refused outright, and the compiler the full-batch parity tests were run with is recorded: another one prints a notice
+# (run tests/test_gpu_full_batch.py before trusting a build from it).
+FORBIDDEN_FLAGS = ("amdgpu-use-amdgpu-trackers",)
+VALIDATED_COMPILER = "AMD clang version 22.0.0git"          # ROCm 7.2.0
 
 
 def _headers():
@@ -47,8 +53,12 @@ _HIPCC_VERSION = None
 def _stamp(unit: str) -> str:
     """hash of everything besides the sources that decides what the object contains"""
     global _HIPCC_VERSION
+    if any(bad in f for f in CFLAGS for bad in FORBIDDEN_FLAGS):
+        raise RuntimeError("build flag known to produce wrong pairings at full size: %s (DESIGN.md 5b)" % ", ".join(FORBIDDEN_FLAGS))
     if _HIPCC_VERSION is None:
         _HIPCC_VERSION = subprocess.run([HIPCC, "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
+        if VALIDATED_COMPILER not in _HIPCC_VERSION:
+            print("crypto12381_amd.build: compiler differs from the validated one (%s): run the full-batch parity tests" % VALIDATED_COMPILER, flush=True)
     return hashlib.sha256("\0".join([HIPCC, *CFLAGS, unit, _HIPCC_VERSION]).encode()).hexdigest()
 
 
