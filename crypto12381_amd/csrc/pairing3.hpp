@@ -23,10 +23,14 @@ struct tri { int role; int base; };      // role 0,1,2 = coefficient a,b,c; base
 
 #if defined(__HIP_DEVICE_COMPILE__)
 C12381_HD void tri_fetch_fp(fp& out, const fp& v, int src_role, const tri& t) {
+#if defined(C12381_MICROBENCH_NO_SHUFFLE)          // csrc/microbench/pair_routines.hip only: what do the cross-lane moves cost?
+    out = v; (void)src_role; (void)t;
+#else
     int src = t.base + src_role;
     src = src > 63 ? 63 : src;
 #pragma unroll
     for (int i = 0; i < NL; ++i) out.l[i] = __shfl(v.l[i], src, 64);
+#endif
 }
 C12381_HD int tri_fetch_int(int v, int src_role, const tri& t) {
     int src = t.base + src_role;
@@ -183,7 +187,7 @@ C12381_HD void f12t_sqr_body(fp4& w, const fp4& x, const tri& t) {
     fp4 xn, z, zc, zn, e, sx;
     tri_fetch_fp4(xn, x, tri_next(t), t);
     fp4_sqr_core(z, x);
-    fp4_addn(sx, x, xn);
+    fp4_add(sx, x, xn);                                    // limbs < 2^29 + slack: within the operand bound of the Fp2 products (host simulation asserts it)
     fp4_sqr_core(zc, sx);
     tri_fetch_fp4(zn, z, tri_next(t), t);
     fp4_sub(e, zc, z); fp4_sub(e, e, zn); fp4_norm1(e, e);

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Small fixed workload for rocprofv3 counter passes: one 2^18 G1 scalar-mul launch and one 2^16 pairing
-launch through the C ABI (host-pointer entry points).  Usage: python3 tools/prof_driver.py [g1|pair|both]"""
+launch through the C ABI (host-pointer entry points).  Usage: python3 tools/prof_driver.py [g1|pair|both|split]
+(split: the Miller loops alone (miller3_kernel), the final exponentiations alone (fexp3_kernel) and the queue pairing, 2^16 each —
+where the pairing's private-memory traffic comes from; C12381_PAIR_QUEUE=0 selects the plain-grid pairing kernel)"""
 import hashlib
 import os
 import sys
@@ -36,6 +38,13 @@ def main():
         n = 1 << 16
         p = c.g1_mul(G1 * 1024, sc(3, 1024), 96) * (n // 1024)
         q = c.g2_mul(G2 * 1024, sc(4, 1024), 192) * (n // 1024)
+        c.pair(p, q)
+    if what == "split":
+        n = 1 << 16
+        p = c.g1_mul(G1 * 1024, sc(3, 1024), 96) * (n // 1024)
+        q = c.g2_mul(G2 * 1024, sc(4, 1024), 192) * (n // 1024)
+        f = c.miller(p, q)
+        c.fexp(f)
         c.pair(p, q)
     c.close()
 
