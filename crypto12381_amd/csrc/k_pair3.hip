@@ -42,10 +42,10 @@ __device__ __forceinline__ void gt_store_coeff(uint8_t* o576, const fp4& x, int 
     fp_to_raw48(raw, x.a.a); store_raw48(o + 144, raw);
 }
 
-// One Fp4 per lane in LDS (240-byte stride: 16-byte aligned, lanes spread over the banks): the running Miller value and
-// the accumulator of the exponentiations by x live here, so the out-of-line tower routines read and write their hot
-// operand at LDS latency.  60 KB per workgroup, two workgroups per CU.
-struct alignas(16) fp4_slot { fp4 v; int32_t pad[4]; };
+// One pair_slot per lane in LDS (pairing3.hpp: the Fp4 + one Fp, 304-byte stride): the running Miller value and the accumulator
+// of the exponentiations by x live here, so the out-of-line tower routines read and write their hot operand at LDS latency.
+// 76 KB per workgroup, two workgroups per CU.
+typedef pair_slot fp4_slot;
 
 __device__ __forceinline__ void gt_load_coeff(fp4& x, const uint8_t* p576, int role) {
     const uint8_t* p = p576 + (role == 0 ? 384 : (role == 1 ? 192 : 0));

@@ -23,7 +23,7 @@ using namespace c12381;
 #define PR_WAVES 2
 #endif
 
-struct alignas(16) fp4_slot { fp4 v; int32_t pad[4]; };
+typedef pair_slot fp4_slot;
 
 __device__ __forceinline__ void load_fp(fp& r, const int32_t* p) {
 #pragma unroll
@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(BLOCK, PR_WAVES) routine_kernel(int iters, con
     const int32_t* sp = seed + (gid % 4096) * 8 * NL;
     fp4 a; fp2 tc; fp px, py;
     load_fp4(a, sp);
-    { fp4 h0; load_fp4(h0, sp + 4 * NL); slot_store(H, h0); }
+    { fp4 h0; load_fp4(h0, sp + 4 * NL); slot_store(H, h0); slot_psel_store(H, a.a.a); }
     tc = a.b; px = a.a.a; py = a.a.b;
     uint64_t t0 = 0, r0 = 0;
     if (threadIdx.x == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
@@ -68,6 +68,7 @@ __global__ void __launch_bounds__(BLOCK, PR_WAVES) routine_kernel(int iters, con
         else if constexpr (KIND == 7) { fp r; fp_mul(r, px, py); fp_mul(px, r, py); }          // two dependent Fp products, registers only
         else if constexpr (KIND == 8) { fp2 r; fp2_mul(r, tc, a.a); fp2_mul(tc, r, a.a); }      // two dependent Fp2 products
         else if constexpr (KIND == 9) { f12t_sqr_h(H, t); miller3_dbl_line(H, tc, px, py, false, t); }   // one Miller iteration without addition step
+        else if constexpr (KIND == 11) { miller3_regs R = m3r_pack(tc, H, t.role | (t.base << 2)); R = miller3_iter(R); m3r_tc(tc, R); }   // the same as ONE routine
     }
     if (threadIdx.x == 0) {
         const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -127,6 +128,7 @@ int main(int argc, char** argv) {
     if (run<0>("f12t_sqr_h", iters, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
     if (run<1>("miller3_dbl_line", iters, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
     if (run<9>("sqr + dbl_line", iters, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
+    if (run<11>("miller3_iter", iters, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
     if (run<2>("f12t_usqr_h", iters * 2, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
     if (run<3>("f12t_mul_h (LDS)", iters, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
     if (run<10>("f12t_mul (private)", iters, blocks, d_seed, d_sink, d_stamps, wps)) return 1;

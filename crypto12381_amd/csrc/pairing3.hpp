@@ -89,6 +89,62 @@ C12381_HD void slot_unpark(fp4& r, const fp4& slot) { r = slot; }
 C12381_HD void slot_park(fp4& slot, const fp4& r) { slot = r; }
 #endif
 
+// The slot as the kernels allocate it: the Fp4, then one Fp of the same lane — the affine G1 coordinate this lane's role needs
+// in the doubling step (px for role 0, py for roles 1 and 2), kept here for the whole Miller loop so that it is not read from
+// private memory every iteration.  304-byte stride = 76 dwords: 16 lanes x 16 bytes hit 64 distinct banks (76 = 12 mod 64).
+// 256 lanes x 304 B = 76 KB per workgroup, two workgroups per CU (of 160 KB).
+struct alignas(16) pair_slot { fp4 v; fp psel; int32_t pad[6]; };
+#if defined(__HIP_DEVICE_COMPILE__)
+static_assert(sizeof(pair_slot) == 304, "pair_slot stride");
+C12381_HD void slot_psel_store(fp4& slot, const fp& v) {       // 4 rows: 14 dwords + 2 of the pad
+    c12381_lds_v4i* p = (c12381_lds_v4i*)(&slot) + 14;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        c12381_v4i w;
+        w.x = v.l[4 * i]; w.y = v.l[4 * i + 1]; w.z = i < 3 ? v.l[(4 * i + 2) % NL] : 0; w.w = i < 3 ? v.l[(4 * i + 3) % NL] : 0;
+        p[i] = w;
+    }
+}
+C12381_HD void slot_psel_load(fp& v, const fp4& slot) {
+    const volatile c12381_lds_v4i* p = (const volatile c12381_lds_v4i*)(&slot) + 14;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const c12381_v4i w = p[i];
+        v.l[4 * i] = w.x; v.l[4 * i + 1] = w.y;
+        if (i < 3) { v.l[4 * i + 2] = w.z; v.l[4 * i + 3] = w.w; }
+    }
+}
+// The register file of miller3_iter's interface: the running point coordinate (28 dwords), the iteration's flags and the LDS
+// address of the lane's slot as ONE 32-dword vector — it is argument and return value, travels in v0..v31 both ways and stays
+// there from one iteration to the next (a 112-byte struct would be passed through private memory by the calling convention,
+// and a 28-element vector is legalised through a stack temporary).
+typedef int32_t miller3_regs __attribute__((ext_vector_type(32)));
+typedef __attribute__((address_space(3))) fp4 c12381_lds_fp4;
+C12381_HD miller3_regs m3r_make(const fp2& tc, int info, int slot) {       // one build: no chain of partial vectors
+    const miller3_regs r = {tc.a.l[0], tc.a.l[1], tc.a.l[2], tc.a.l[3], tc.a.l[4], tc.a.l[5], tc.a.l[6], tc.a.l[7], tc.a.l[8], tc.a.l[9],
+                            tc.a.l[10], tc.a.l[11], tc.a.l[12], tc.a.l[13], tc.b.l[0], tc.b.l[1], tc.b.l[2], tc.b.l[3], tc.b.l[4], tc.b.l[5],
+                            tc.b.l[6], tc.b.l[7], tc.b.l[8], tc.b.l[9], tc.b.l[10], tc.b.l[11], tc.b.l[12], tc.b.l[13], info, slot, 0, 0};
+    return r;
+}
+C12381_HD miller3_regs m3r_pack(const fp2& tc, fp4& F, int info) { return m3r_make(tc, info, (int32_t)(uint32_t)(uintptr_t)(c12381_lds_fp4*)(&F)); }
+C12381_HD miller3_regs m3r_with_tc(const miller3_regs& r, const fp2& tc) { return m3r_make(tc, r[28], r[29]); }
+C12381_HD void m3r_tc(fp2& tc, const miller3_regs& r) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) { tc.a.l[i] = r[i]; tc.b.l[i] = r[NL + i]; }
+}
+C12381_HD int m3r_info(const miller3_regs& r) { return r[28]; }
+C12381_HD fp4& m3r_slot(const miller3_regs& r) { return *(fp4*)(c12381_lds_fp4*)(uintptr_t)(uint32_t)r[29]; }
+#else
+C12381_HD void slot_psel_store(fp4& slot, const fp& v) { reinterpret_cast<pair_slot*>(&slot)->psel = v; }
+C12381_HD void slot_psel_load(fp& v, const fp4& slot) { v = reinterpret_cast<const pair_slot*>(&slot)->psel; }
+struct miller3_regs { fp2 tc; fp4* F; int info; };
+C12381_HD miller3_regs m3r_pack(const fp2& tc, fp4& F, int info) { miller3_regs r; r.tc = tc; r.F = &F; r.info = info; return r; }
+C12381_HD miller3_regs m3r_with_tc(const miller3_regs& r, const fp2& tc) { miller3_regs q = r; q.tc = tc; return q; }
+C12381_HD void m3r_tc(fp2& tc, const miller3_regs& r) { tc = r.tc; }
+C12381_HD int m3r_info(const miller3_regs& r) { return r.info; }
+C12381_HD fp4& m3r_slot(const miller3_regs& r) { return *r.F; }
+#endif
+
 // ------------------------------------------------------------------ inlined Fp4 cores (operands stay in registers)
 C12381_HD void fp4_mul_core(fp4& w, const fp4& x, const fp4& y) {
     fp2 t1, t2, t3, t4;
@@ -197,9 +253,8 @@ C12381_HDN void f12t_sqr(fp4& w, const fp4& x, const tri& t) { fp4 xv = x, r; f1
 C12381_HDN void f12t_sqr_h(fp4& H, const tri& t) { fp4 x, r; slot_load(x, H); f12t_sqr_body(r, x, t); slot_store(H, r); }
 // Granger-Scott unitary squaring (FP12_usqr :147-186): one Fp4 squaring per lane.
 //   w_a = 3 xa^2 - 2 conj(xa),  w_b = 3 s xc^2 + 2 conj(xb),  w_c = 3 xb^2 - 2 conj(xc)
-C12381_HD void f12t_usqr_body(fp4& w, const fp4& x, bool reduce, const tri& t) {
-    fp4 q, qq, sq, three, lin, c1, c2, r;
-    fp4_sqr_core_raw(q, x);                                // un-normalised: one carry round after the select below
+C12381_HD void f12t_usqr_tail(fp4& w, const fp4& q, const fp4& x, bool reduce, const tri& t) {
+    fp4 qq, sq, three, lin, c1, c2, r;
     const int src = t.role == 0 ? t.role : (t.role == 1 ? tri_next(t) : tri_prev(t));
     tri_fetch_fp4(qq, q, src, t);
     fp4_times_i(sq, qq);
@@ -212,8 +267,23 @@ C12381_HD void f12t_usqr_body(fp4& w, const fp4& x, bool reduce, const tri& t) {
     fp4_add(r, three, lin);
     if (reduce) fp4_weak_reduce(w, r); else fp4_norm1(w, r);
 }
+C12381_HD void f12t_usqr_body(fp4& w, const fp4& x, bool reduce, const tri& t) {
+    fp4 q;
+    fp4_sqr_core_raw(q, x);                                // un-normalised: one carry round after the select in the tail
+    f12t_usqr_tail(w, q, x, reduce, t);
+}
 C12381_HDN void f12t_usqr(fp4& w, const fp4& x, bool reduce, const tri& t) { fp4 xv = x, r; f12t_usqr_body(r, xv, reduce, t); w = r; }
-C12381_HDN void f12t_usqr_h(fp4& H, bool reduce, const tri& t) { fp4 x, r; slot_load(x, H); f12t_usqr_body(r, x, reduce, t); slot_store(H, r); }
+// slot form: x is NOT kept in registers across the squaring — the linear part reads it from the slot again (14 LDS reads instead
+// of 56 live registers: with them the routine spilled 7 dwords a call, 315 calls a pairing)
+C12381_HDN void f12t_usqr_h(fp4& H, bool reduce, const tri& t) {
+    fp4 q, x, r;
+    slot_load(x, H);
+    fp4_sqr_core_raw(q, x);
+    C12381_PHASE();
+    slot_unpark(x, H);
+    f12t_usqr_tail(r, q, x, reduce, t);
+    slot_store(H, r);
+}
 // FP12_conj :117-123
 C12381_HD void f12t_conj(fp4& w, const fp4& x, const tri& t) {
     fp4 c1, c2;
@@ -402,7 +472,14 @@ C12381_HD bool f12t_is_one(const fp4& x, const tri& t) {
 // ------------------------------------------------------------------ Miller loop on a triple
 // Doubling step: role 0/1/2 holds X/Y/Z of T in `tc`.  Three Fp2 products per lane (PAIR_double :40-78 +
 // ECP2_dbl ecp2_BLS12381.cpp:358-409); the three line coefficients are then shared with all lanes.
+C12381_HD void miller3_dbl_step_sel(fp2& tc, fp2& l0, fp2& l1, fp2& l2, const fp& sel, const tri& t);
 C12381_HD void miller3_dbl_step_core(fp2& tc, fp2& l0, fp2& l1, fp2& l2, const fp& px, const fp& py, const tri& t) {
+    fp sel;
+    fp_select(sel, t.role == 0, px, py);
+    miller3_dbl_step_sel(tc, l0, l1, l2, sel, t);
+}
+// sel: px on role 0, py on roles 1 and 2 (role 2's product is not used)
+C12381_HD void miller3_dbl_step_sel(fp2& tc, fp2& l0, fp2& l1, fp2& l2, const fp& sel, const tri& t) {
     fp2 yt, zt, s0, t0, t2b, z8, a, b, p2, u, y3p, p3, own, piece;
     tri_fetch_fp2(yt, tc, 1, t);                           // Y to everyone
     tri_fetch_fp2(zt, tc, 2, t);                           // Z to everyone
@@ -435,8 +512,6 @@ C12381_HD void miller3_dbl_step_core(fp2& tc, fp2& l0, fp2& l1, fp2& l2, const f
     fp2_dbl(cc, s0); fp2_add(cc, cc, s0);                  // a: 3X^2
     fp2_dbl(aa, p2); fp2_neg(aa, aa); fp2_mul_ip(aa, aa);  // b: -2YZ(1+i)
     fp2_select(a, t.role == 0, cc, aa);
-    fp sel;
-    fp_select(sel, t.role == 0, px, py);
     fp2_norm1(a, a);
     fp2_mul_fp(pm, a, sel);
     fp2_sub(bb, t2b, t0); fp2_norm1(bb, bb);
@@ -467,6 +542,79 @@ C12381_HDN void miller3_dbl_line(fp4& F, fp2& tc, const fp& px, const fp& py, bo
     f12t_mul_line_core(x, l0, l1, l2, t);
     slot_store(F, x);
 }
+// ONE iteration of the loop of one pair without its addition step: f <- f^2, T <- 2T, f <- f * line — in one out-of-line routine.
+// The running coordinate travels in registers (argument and return value), f and the G1 coordinate in the lane's slot: the
+// iteration touches no private memory (as three routines it re-read tc, px, py and wrote tc back every iteration: 24 KB per lane
+// and Miller loop, the largest part of the pairing kernels' traffic past L2, profiles/r02_traffic_split.txt).
+// info = role | base << 2 | skip << 8.  The squaring forms (x + x')^2 first and reads x again from the slot for x^2, so that only
+// one of them is alive with tc during an Fp4 squaring.
+C12381_HD void miller3_iter_body(fp2& tc, fp4& F, int info) {
+    tri t;
+    t.role = info & 3; t.base = (info >> 2) & 63;
+    const bool skip = ((info >> 8) & 1) != 0;
+    {
+        fp4 z, zc, zn, e, w;
+        {
+            fp4 x, xn, sx;
+            slot_load(x, F);
+            tri_fetch_fp4(xn, x, tri_next(t), t);
+            fp4_add(sx, x, xn);                            // limbs < 2^29 + slack: within the operand bound of the Fp2 products
+            C12381_PHASE();
+            fp4_sqr_core(zc, sx);
+            C12381_PHASE();
+        }
+        {
+            fp4 x;
+            slot_unpark(x, F);
+            fp4_sqr_core(z, x);
+        }
+        tri_fetch_fp4(zn, z, tri_next(t), t);
+        fp4_sub(e, zc, z); fp4_sub(e, e, zn); fp4_norm1(e, e);
+        f12t_combine(w, z, zn, e, t);
+        slot_park(F, w);
+    }
+    C12381_PHASE();
+    fp2 l0, l1, l2;
+    {
+        fp2 one2, zero2;
+        fp sel;
+        slot_psel_load(sel, F);
+        miller3_dbl_step_sel(tc, l0, l1, l2, sel, t);
+        fp2_one(one2); fp2_zero(zero2);
+        fp2_select(l0, skip, one2, l0); fp2_select(l1, skip, zero2, l1); fp2_select(l2, skip, zero2, l2);
+    }
+    C12381_PHASE();
+    {
+        fp4 x;
+        slot_unpark(x, F);
+        f12t_mul_line_core(x, l0, l1, l2, t);
+        slot_store(F, x);
+    }
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+// the coordinate arrives as 28 scalar arguments (v0..v27) and leaves as one vector built in a single step: a 32-dword vector
+// ARGUMENT stays one 1024-bit register tuple for as long as any element is alive, and the allocator spills such tuples whole
+#define C12381_M3_28(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) \
+    X(22) X(23) X(24) X(25) X(26) X(27)
+#define C12381_M3_PARAM(i) int32_t a##i,
+#define C12381_M3_TAKE(i) (i < NL ? tc.a.l[i % NL] : tc.b.l[i % NL]) = a##i;
+#define C12381_M3_PASS(i) R[i],
+C12381_HDN miller3_regs miller3_iter_regs(C12381_M3_28(C12381_M3_PARAM) int32_t info, int32_t slot) {
+    fp2 tc;
+    C12381_M3_28(C12381_M3_TAKE)
+    fp4& F = *(fp4*)(c12381_lds_fp4*)(uintptr_t)(uint32_t)slot;
+    miller3_iter_body(tc, F, info);
+    return m3r_make(tc, info, slot);
+}
+C12381_HD miller3_regs miller3_iter(const miller3_regs& R) { return miller3_iter_regs(C12381_M3_28(C12381_M3_PASS) R[28], R[29]); }
+#else
+C12381_HDN miller3_regs miller3_iter(const miller3_regs& R) {
+    miller3_regs Q = R;
+    miller3_iter_body(Q.tc, *Q.F, Q.info);
+    return Q;
+}
+#endif
+
 // ------------------------------------------------------------------ Miller loop on a triple, in pieces
 // (the kernels run it either whole or as two half-ranges of a work queue, see k_pair3.hip)
 C12381_HD void miller3_q(g2p& Q, const fp2& qx, const fp2& qy, bool q_inf) {      // G2 infinity runs as (0:1:0), like PAIR_ate
@@ -483,6 +631,18 @@ C12381_HD void f12t_one(fp4& F, const tri& t) {
     fp4_zero(zero4); one4 = zero4; fp_one(one4.a.a);
     fp4_select(F, t.role == 0, one4, zero4);
 }
+// addition step T <- T +- Q and its line (the 5 iterations whose digit of 3|x| - |x| is non-zero)
+C12381_HD void miller3_add_line(fp4& F, fp2& tc, const fp& px, const fp& py, bool skip, const g2p& Q, bool neg, const tri& t) {
+    fp2 l0, l1, l2, one2, zero2;
+    g2p T, S = Q;
+    tri_fetch_fp2(T.x, tc, 0, t); tri_fetch_fp2(T.y, tc, 1, t); tri_fetch_fp2(T.z, tc, 2, t);
+    if (neg) g2_neg(S, Q);
+    miller_add_step(T, S, l0, l1, l2, px, py);             // replicated on the three lanes
+    fp2_select(tc, t.role == 0, T.x, T.y); fp2_select(tc, t.role == 2, T.z, tc);
+    fp2_one(one2); fp2_zero(zero2);
+    fp2_select(l0, skip, one2, l0); fp2_select(l1, skip, zero2, l1); fp2_select(l2, skip, zero2, l2);
+    f12t_mul_line_h(F, l0, l1, l2, t);
+}
 // everything iteration i does for ONE (P, Q) pair after the squaring: doubling step + line, and the addition step of
 // the 5 iterations whose digit of 3|x| - |x| is non-zero.  skip: P is infinity, the pair contributes 1 (PAIR_ate :448-449).
 C12381_HD void miller3_pair_step(fp4& F, fp2& tc, const fp& px, const fp& py, bool skip, const g2p& Q, int i, const tri& t) {
@@ -490,25 +650,31 @@ C12381_HD void miller3_pair_step(fp4& F, fp2& tc, const fp& px, const fp& py, bo
     constexpr unsigned __int128 N3 = N1 * 3;
     miller3_dbl_line(F, tc, px, py, skip, t);
     const int bt = (int)((N3 >> i) & 1) - (int)((N1 >> i) & 1);
-    if (bt != 0) {                                         // wave-uniform
-        fp2 l0, l1, l2, one2, zero2;
-        g2p T, S = Q;
-        tri_fetch_fp2(T.x, tc, 0, t); tri_fetch_fp2(T.y, tc, 1, t); tri_fetch_fp2(T.z, tc, 2, t);
-        if (bt < 0) g2_neg(S, Q);
-        miller_add_step(T, S, l0, l1, l2, px, py);         // replicated on the three lanes
-        fp2_select(tc, t.role == 0, T.x, T.y); fp2_select(tc, t.role == 2, T.z, tc);
-        fp2_one(one2); fp2_zero(zero2);
-        fp2_select(l0, skip, one2, l0); fp2_select(l1, skip, zero2, l1); fp2_select(l2, skip, zero2, l2);
-        f12t_mul_line_h(F, l0, l1, l2, t);
-    }
+    if (bt != 0) miller3_add_line(F, tc, px, py, skip, Q, bt < 0, t);      // wave-uniform
 }
 // iterations hi .. lo (inclusive, 64 >= hi >= lo >= 1) of the loop for one pair / for two pairs sharing the squarings
+// F: the lane's pair_slot (its psel field is set here)
 C12381_HDN void miller3_range(fp4& F, fp2& tc, const fp& px, const fp& py, bool skip, const g2p& Q, int hi, int lo, const tri& t) {
+    constexpr unsigned __int128 N1 = (unsigned __int128)BLS_X;
+    constexpr unsigned __int128 N3 = N1 * 3;
+    {
+        fp sel;
+        fp_select(sel, t.role == 0, px, py);
+        slot_psel_store(F, sel);
+    }
+    const int info = t.role | (t.base << 2) | (skip ? 256 : 0);
+    miller3_regs R = m3r_pack(tc, F, info);
 #pragma unroll 1
     for (int i = hi; i >= lo; --i) {
-        f12t_sqr_h(F, t);
-        miller3_pair_step(F, tc, px, py, skip, Q, i, t);
+        R = miller3_iter(R);
+        const int bt = (int)((N3 >> i) & 1) - (int)((N1 >> i) & 1);
+        if (bt != 0) {                                         // wave-uniform: the 5 addition steps
+            m3r_tc(tc, R);
+            miller3_add_line(F, tc, px, py, skip, Q, bt < 0, t);
+            R = m3r_with_tc(R, tc);
+        }
     }
+    m3r_tc(tc, R);
 }
 C12381_HDN void miller3_range2(fp4& F, fp2& tc1, const fp& px1, const fp& py1, bool skip1, const g2p& Q1,
                                fp2& tc2, const fp& px2, const fp& py2, bool skip2, const g2p& Q2, int hi, int lo, const tri& t) {

@@ -304,7 +304,8 @@ void* tri3_worker(void* arg) {
     }
     for (size_t i = 0; i < jb->n; ++i) {
         fp px, py; fp2 qx, qy; bool pinf, qinf;
-        fp4 F;
+        pair_slot slot;                   // the Miller loop keeps the lane's G1 coordinate next to the Fp4 (pairing3.hpp)
+        fp4& F = slot.v;
         pair_load(px, py, pinf, qx, qy, qinf, jb->a1 + 96 * i, jb->a2 + 192 * i);
         if (jb->mode == 3) {          // Miller value alone
             miller3_loop(F, px, py, pinf, qx, qy, qinf, t);
