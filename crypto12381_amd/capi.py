@@ -66,10 +66,12 @@ def load_library() -> ctypes.CDLL:
             getattr(lib, name).argtypes = [vp, sz, vp, vp, vp, vp, vp]
         for name in ("c12381_g1_decompress_batch", "c12381_g2_decompress_batch"):
             getattr(lib, name).argtypes = [vp, sz, vp, vp, vp]
-        lib.c12381_miller_batch.argtypes = [vp, sz, vp, vp, vp]
-        lib.c12381_fexp_batch.argtypes = [vp, sz, vp, vp]
-        lib.c12381_gt_op_batch.argtypes = [vp, ci, sz, vp, vp, vp]
-        lib.c12381_gt_is_unity_batch.argtypes = [vp, sz, vp, vp]
+        for name in ("c12381_miller_batch", "c12381_miller_batch_dev"):
+            getattr(lib, name).argtypes = [vp, sz, vp, vp, vp]
+        for name in ("c12381_fexp_batch", "c12381_fexp_batch_dev", "c12381_gt_is_unity_batch", "c12381_gt_is_unity_batch_dev"):
+            getattr(lib, name).argtypes = [vp, sz, vp, vp]
+        for name in ("c12381_gt_op_batch", "c12381_gt_op_batch_dev"):
+            getattr(lib, name).argtypes = [vp, ci, sz, vp, vp, vp]
         for name in ("c12381_g1_from_hash_batch", "c12381_g1_from_hash_batch_dev"):
             getattr(lib, name).argtypes = [vp, sz, vp, vp, ci]
         for name in ("c12381_g1_mul_fixed_batch", "c12381_g1_mul_fixed_batch_dev", "c12381_g2_mul_fixed_batch", "c12381_g2_mul_fixed_batch_dev"):
@@ -386,6 +388,24 @@ class Context:
         out = ctypes.create_string_buffer(max(96 * n, 1))
         self._ck(self.lib.c12381_bbs_plus_sign_batch(self.h, n, nmsg, _p(g1), _p(h0), _p(h), _p(gamma32), _p(x), _p(r), _p(m), _p(out)))
         return out.raw[:96 * n]
+
+    def miller_dev(self, n, g1_ptr, g2_ptr, out_ptr):
+        self._ck(self.lib.c12381_miller_batch_dev(self.h, n, _p(g1_ptr), _p(g2_ptr), _p(out_ptr)))
+
+    def gt_op_dev(self, op, n, a_ptr, b_ptr, out_ptr):
+        self._ck(self.lib.c12381_gt_op_batch_dev(self.h, self.GT_OPS[op], n, _p(a_ptr), _p(b_ptr), _p(out_ptr)))
+
+    def gt_is_unity_dev(self, n, a_ptr, out_ptr):
+        self._ck(self.lib.c12381_gt_is_unity_batch_dev(self.h, n, _p(a_ptr), _p(out_ptr)))
+
+    def g1_decompress_dev(self, n, in_ptr, out_ptr, status_ptr):
+        self._ck(self.lib.c12381_g1_decompress_batch_dev(self.h, n, _p(in_ptr), _p(out_ptr), _p(status_ptr)))
+
+    def g2_decompress_dev(self, n, in_ptr, out_ptr, status_ptr):
+        self._ck(self.lib.c12381_g2_decompress_batch_dev(self.h, n, _p(in_ptr), _p(out_ptr), _p(status_ptr)))
+
+    def bbs_plus_verify_wire_dev(self, n, nh, msg_len, pub_ptr, h_ptr, pk_ptr, sig_ptr, msg_ptr, ok_ptr):
+        self._ck(self.lib.c12381_bbs_plus_verify_wire_batch_dev(self.h, n, nh, msg_len, _p(pub_ptr), _p(h_ptr), _p(pk_ptr), _p(sig_ptr), _p(msg_ptr), _p(ok_ptr)))
 
     def g1_from_hash_dev(self, n, digests_ptr, out_ptr, fmt=96):
         self._ck(self.lib.c12381_g1_from_hash_batch_dev(self.h, n, _p(digests_ptr), _p(out_ptr), fmt))

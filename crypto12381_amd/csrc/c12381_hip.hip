@@ -1051,17 +1051,39 @@ int c12381_g2_decompress_batch(c12381_ctx* c, size_t n, const uint8_t* in97, uin
     HIPCK(c, hipMemcpyAsync(status, s.in1, n, hipMemcpyDeviceToHost, c->stream));
     return read_flag(c);
 }
+static int launch_miller(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* out) {
+    if (pair_lanes() == 1) hipLaunchKernelGGL(miller_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, g1, g2, out, c->d_flag);
+    else hipLaunchKernelGGL(miller3_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, g1, g2, out, c->d_flag);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+static int launch_gt_op(c12381_ctx* c, int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    if (pair_lanes() == 1) hipLaunchKernelGGL(gt_op_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, op, n, a, b, out);
+    else hipLaunchKernelGGL(gt3_op_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, op, n, a, b, out);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+static int launch_gt_is_unity(c12381_ctx* c, size_t n, const uint8_t* a, uint8_t* out) {
+    if (pair_lanes() == 1) hipLaunchKernelGGL(gt_is_unity_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, a, out);
+    else hipLaunchKernelGGL(gt3_is_unity_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, a, out);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
 int c12381_miller_batch(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* out576) {
     int rc = bind(c); if (rc) return rc;
     if (!g1 || !g2 || !out576) return C12381_E_ARG;
     if (n == 0) return 0;
     staged s;
     if ((rc = stage_in(c, s, g1, 96 * n, g2, 192 * n, 576 * n))) return rc;
-    if (pair_lanes() == 1) hipLaunchKernelGGL(miller_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, s.in0, s.in1, s.out, c->d_flag);
-    else hipLaunchKernelGGL(miller3_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, s.in0, s.in1, s.out, c->d_flag);
-    HIPCK(c, hipGetLastError());
+    if ((rc = launch_miller(c, n, s.in0, s.in1, s.out))) return rc;
     if ((rc = stage_out(c, s, out576, 576 * n))) return rc;
     return read_flag(c);
+}
+int c12381_miller_batch_dev(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* out576) {
+    int rc = bind(c); if (rc) return rc;
+    if (!g1 || !g2 || !out576) return C12381_E_ARG;
+    if (n == 0) return 0;
+    return launch_miller(c, n, g1, g2, out576);
 }
 int c12381_gt_op_batch(c12381_ctx* c, int op, size_t n, const uint8_t* a576, const uint8_t* b, uint8_t* out576) {
     int rc = bind(c); if (rc) return rc;
@@ -1070,24 +1092,33 @@ int c12381_gt_op_batch(c12381_ctx* c, int op, size_t n, const uint8_t* a576, con
     staged s;
     const size_t bb = op == 0 ? 576 * n : (op == 2 ? 32 * n : 0);
     if ((rc = stage_in(c, s, a576, 576 * n, bb ? b : nullptr, bb, 576 * n))) return rc;
-    if (pair_lanes() == 1) hipLaunchKernelGGL(gt_op_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, op, n, s.in0, s.in1, s.out);
-    else hipLaunchKernelGGL(gt3_op_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, op, n, s.in0, s.in1, s.out);
-    HIPCK(c, hipGetLastError());
+    if ((rc = launch_gt_op(c, op, n, s.in0, s.in1, s.out))) return rc;
     if ((rc = stage_out(c, s, out576, 576 * n))) return rc;
     return read_flag(c);
 }
+int c12381_gt_op_batch_dev(c12381_ctx* c, int op, size_t n, const uint8_t* a576, const uint8_t* b, uint8_t* out576) {
+    int rc = bind(c); if (rc) return rc;
+    if (op < 0 || op > 3 || !a576 || !out576 || ((op == 0 || op == 2) && !b)) return C12381_E_ARG;
+    if (n == 0) return 0;
+    return launch_gt_op(c, op, n, a576, b, out576);
+}
 int c12381_fexp_batch(c12381_ctx* c, size_t n, const uint8_t* in576, uint8_t* out576) { return c12381_gt_op_batch(c, 3, n, in576, nullptr, out576); }
+int c12381_fexp_batch_dev(c12381_ctx* c, size_t n, const uint8_t* in576, uint8_t* out576) { return c12381_gt_op_batch_dev(c, 3, n, in576, nullptr, out576); }
 int c12381_gt_is_unity_batch(c12381_ctx* c, size_t n, const uint8_t* a576, uint8_t* out) {
     int rc = bind(c); if (rc) return rc;
     if (!a576 || !out) return C12381_E_ARG;
     if (n == 0) return 0;
     staged s;
     if ((rc = stage_in(c, s, a576, 576 * n, nullptr, 0, n))) return rc;
-    if (pair_lanes() == 1) hipLaunchKernelGGL(gt_is_unity_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, s.in0, s.out);
-    else hipLaunchKernelGGL(gt3_is_unity_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, s.in0, s.out);
-    HIPCK(c, hipGetLastError());
+    if ((rc = launch_gt_is_unity(c, n, s.in0, s.out))) return rc;
     if ((rc = stage_out(c, s, out, n))) return rc;
     return read_flag(c);
+}
+int c12381_gt_is_unity_batch_dev(c12381_ctx* c, size_t n, const uint8_t* a576, uint8_t* out) {
+    int rc = bind(c); if (rc) return rc;
+    if (!a576 || !out) return C12381_E_ARG;
+    if (n == 0) return 0;
+    return launch_gt_is_unity(c, n, a576, out);
 }
 
 // Fixed-base tables (fixed_base.hpp): make sure slot `slot` holds the table of the point at `d_base`; everything is

@@ -553,7 +553,7 @@ __global__ void __launch_bounds__(BLOCK, 2) gt3_op_kernel(int op, size_t n, cons
     gt_load_coeff(x, a + 576 * i, t.role);
     if (op == 0) { fp4 y; gt_load_coeff(y, b + 576 * i, t.role); f12t_mul(r, x, y, t); }
     else if (op == 1) { f12t_conj(r, x, t); }
-    else if (op == 2) { uint32_t raw[8], e[8]; load_raw32(raw, b + 32 * i); scalar_from_raw32(e, raw); f12t_pow_generic(r, x, e, t); }
+    else if (op == 2) { uint32_t raw[8], e[8]; load_raw32(raw, b + 32 * i); scalar_from_raw32(e, raw); slot_store(H, x); f12t_pow_generic(H, e, t); slot_load(r, H); }
     else { r = x; f12t_final_exp_ws(r, H, t); }
     if (active) gt_store_coeff(out + 576 * i, r, t.role);
 }

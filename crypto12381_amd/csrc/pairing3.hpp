@@ -428,7 +428,12 @@ C12381_HD void f12t_one(fp4& F, const tri& t);
 // FP12_pow :736-774 on a triple, exponent e < 2^256 used AS GIVEN (the three lanes of a triple hold the same e): the
 // reference's signed-digit ladder over (3e, e) with Granger-Scott squarings — a power only for unitary inputs, like
 // there.  Triples hold different exponents, so both candidates are always formed and selected (fp12_pow_generic).
-C12381_HDN void f12t_pow_generic(fp4& r, const fp4& a, const uint32_t (&e)[8], const tri& t) {
+// H: the lane's slot, holds a on entry and the result on return.  The accumulator starts at 1 and the loop starts at the top
+// bit position, so every triple of the wavefront runs the same 257 iterations: above an exponent's leading digit both steps
+// are identities on 1 (usqr(1) = 1, 1 * 1 = 1), its leading digit is +1 (3e has its top bit one position above any bit of e)
+// and turns the accumulator into a — from there on the sequence is FP12_pow's, for non-unitary inputs too.  Zero digits
+// multiply by 1 (the value is unchanged; the bytes written are canonical either way).
+C12381_HDN void f12t_pow_generic(fp4& H, const uint32_t (&e)[8], const tri& t) {
     uint32_t e3[9];
     {
         uint64_t c = 0;
@@ -436,27 +441,22 @@ C12381_HDN void f12t_pow_generic(fp4& r, const fp4& a, const uint32_t (&e)[8], c
         for (int i = 0; i < 8; ++i) { c += (uint64_t)e[i] * 3u; e3[i] = (uint32_t)c; c >>= 32; }
         e3[8] = (uint32_t)c;
     }
-    int nb = 0;
-#pragma unroll 1
-    for (int i = 0; i < 9 * 32; ++i) if ((e3[i >> 5] >> (i & 31)) & 1u) nb = i + 1;
-    fp4 w = a, ac;
+    fp4 a, ac, one;
+    slot_load(a, H);
     f12t_conj(ac, a, t);
+    f12t_one(one, t);
+    slot_store(H, one);
 #pragma unroll 1
     for (int i = 257; i >= 1; --i) {
-        const bool active = i <= nb - 2;
-        fp4 sq, m, prod, nxt;
-        f12t_usqr(sq, w, true, t);
+        f12t_usqr_h(H, true, t);
         const int b3 = (int)((e3[i >> 5] >> (i & 31)) & 1u);
         const int b1 = i < 256 ? (int)((e[i >> 5] >> (i & 31)) & 1u) : 0;
         const int bt = b3 - b1;
+        fp4 m;
         fp4_select(m, bt < 0, ac, a);
-        f12t_mul(prod, sq, m, t);
-        fp4_select(nxt, bt != 0, prod, sq);
-        fp4_select(w, active, nxt, w);
+        fp4_select(m, bt == 0, one, m);
+        f12t_mul_h(H, m, t);
     }
-    fp4 one;
-    f12t_one(one, t);
-    fp4_select(r, nb == 0, one, w);
 }
 // FP12_isunity: every lane tests its own coefficient, the verdict is combined over the triple
 C12381_HD bool f12t_is_one(const fp4& x, const tri& t) {

@@ -170,14 +170,18 @@ int c12381_g2_decompress_batch_dev(c12381_ctx* ctx, size_t n, const uint8_t* in9
 /* split pairing and GT arithmetic (what the reference's GTMiller / GTPoint types call) ----------- */
 /* pair_ate(fp12&, point2&, point1&) alone (:199 -> 276-279 -> PAIR_ate): the Miller value as FP12_toOctet bytes. */
 int c12381_miller_batch(c12381_ctx* ctx, size_t n, const uint8_t* g1_96, const uint8_t* g2_192, uint8_t* out576);
+int c12381_miller_batch_dev(c12381_ctx* ctx, size_t n, const uint8_t* g1_96, const uint8_t* g2_192, uint8_t* out576);
 /* pair_final_exponentiation(fp12&) alone (:201 -> 281-284 -> PAIR_fexp). */
 int c12381_fexp_batch(c12381_ctx* ctx, size_t n, const uint8_t* in576, uint8_t* out576);
+int c12381_fexp_batch_dev(c12381_ctx* ctx, size_t n, const uint8_t* in576, uint8_t* out576);
 /* op 0: multiply(fp12& r, fp12& v) r*=v (:193 -> 256-259 -> FP12_mul); 1: conjugate (:191 -> 251-254);
  * 2: pow(fp12&, fp12& base, const big&) (:195 -> 261-264 -> FP12_pow; b = 32-byte exponents, used as given,
  *    unitary squarings exactly like the reference); 3: final exponentiation. */
 int c12381_gt_op_batch(c12381_ctx* ctx, int op, size_t n, const uint8_t* a576, const uint8_t* b, uint8_t* out576);
+int c12381_gt_op_batch_dev(c12381_ctx* ctx, int op, size_t n, const uint8_t* a576, const uint8_t* b, uint8_t* out576);
 /* is_unity(fp12&) (:197 -> 271-274 -> FP12_isunity): out[i] = 1 / 0. */
 int c12381_gt_is_unity_batch(c12381_ctx* ctx, size_t n, const uint8_t* a576, uint8_t* out);
+int c12381_gt_is_unity_batch_dev(c12381_ctx* ctx, size_t n, const uint8_t* a576, uint8_t* out);
 
 /* gt[i] = e(g1[i], Q) with ONE G2 argument for the batch (pair(P_i, g2) against a generator or public key — the
  * shape of every verification equation in the reference's examples): pair_ate + pair_final_exponentiation + to_bytes as

@@ -295,7 +295,7 @@ void* tri3_worker(void* arg) {
             gt_load_coeff(x, jb->a1 + 576 * i, jb->role);
             if (op == 0) { fp4 y; gt_load_coeff(y, jb->b1 + 576 * i, jb->role); f12t_mul(r, x, y, t); }
             else if (op == 1) f12t_conj(r, x, t);
-            else if (op == 2) { uint32_t raw[8], e[8]; load_raw(raw, jb->b1 + 32 * i, 8); scalar_from_raw32(e, raw); f12t_pow_generic(r, x, e, t); }
+            else if (op == 2) { uint32_t raw[8], e[8]; load_raw(raw, jb->b1 + 32 * i, 8); scalar_from_raw32(e, raw); r = x; f12t_pow_generic(r, e, t); }
             else if (op == 3) { r = x; f12t_final_exp_ws(r, h, t); }
             else { const bool one = f12t_is_one(x, t); if (jb->role == 0) jb->out[i] = one ? 1 : 0; continue; }
             gt_store_coeff(jb->out + 576 * i, r, jb->role);

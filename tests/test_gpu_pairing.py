@@ -139,6 +139,15 @@ def test_gt_ops_and_split_pairing(ctx, oracle_port):
     assert ctx.fexp(m) == gt
     one = ctx.gt_op("mul", gta, ctx.gt_op("conj", gta))     # unitary: a * conj(a) = 1
     assert ctx.gt_is_unity(one) == b"\x01" * 4 and ctx.gt_is_unity(gta)[:3] == b"\x00" * 3
+    # pow() on inputs that are NOT unitary (Miller values): the reference's unitary squarings make the result a function of the
+    # exact operation sequence (fp12_BLS12381.cpp:736-774) — it has to be reproduced, not "corrected"; exponents of every
+    # length class incl. 0, 1, 2, 3 and the top bit set (a wavefront holds 21 different ones)
+    nm = len(m) // 576
+    reps = 6
+    exps = [0, 1, 2, 3, 4, 5, (1 << 255) + 12345, (1 << 256) - 1, R - 1, R, 1 << 64, (1 << 128) - 1] + [prng(436, i, 32) for i in range(nm * reps - 12)]
+    eb = b"".join(int(v).to_bytes(32, "big") for v in exps)
+    assert ctx.gt_op("pow", m * reps, eb) == oracle_port.gt_op("pow", m * reps, eb)
+    assert ctx.gt_op("pow", gt * reps, eb) == oracle_port.gt_op("pow", gt * reps, eb)
 
 
 def test_pair_fixed_g2(ctx, oracle_port):
