@@ -478,11 +478,13 @@ C12381_HD void miller3_dbl_step_core(fp2& tc, fp2& l0, fp2& l1, fp2& l2, const f
     fp_select(sel, t.role == 0, px, py);
     miller3_dbl_step_sel(tc, l0, l1, l2, sel, t);
 }
-// sel: px on role 0, py on roles 1 and 2 (role 2's product is not used)
+// sel: px on role 0, py on roles 1 and 2 (role 1's product is not used).
+// Who computes what is chosen so that every product finds its operands on its own lane or in a value that is shared anyway:
+// role b never needs Z, and the new Y and Z are produced by the lanes that keep them — six exchanges of an Fp2 value per step
+// (Y, Y^2, 3b'Z^2, three line coefficients) instead of eight.
 C12381_HD void miller3_dbl_step_sel(fp2& tc, fp2& l0, fp2& l1, fp2& l2, const fp& sel, const tri& t) {
-    fp2 yt, zt, s0, t0, t2b, z8, a, b, p2, u, y3p, p3, own, piece;
+    fp2 yt, s0, t0, t2b, z8, a, b, p2, u, y3p, p3, own, piece;
     tri_fetch_fp2(yt, tc, 1, t);                           // Y to everyone
-    tri_fetch_fp2(zt, tc, 2, t);                           // Z to everyone
     fp2_sqr(s0, tc);                                       // a: X^2, b: Y^2, c: Z^2
     tri_fetch_fp2(t0, s0, 1, t);                           // t0 = Y^2 to everyone
     {   // c: 3b' Z^2; shared afterwards
@@ -491,39 +493,35 @@ C12381_HD void miller3_dbl_step_sel(fp2& tc, fp2& l0, fp2& l1, fp2& l2, const fp
         tri_fetch_fp2(t2b, tb, 2, t);
     }
     fp2_mul_small(z8, t0, 8);
-    // round 2: a: X*Y, b: Y*Z, c: t2b * 8Y^2
-    fp2_select(a, t.role == 2, t2b, tc);
-    fp2_select(b, t.role == 0, yt, zt); fp2_select(b, t.role == 2, z8, b);
-    fp2_mul(p2, a, b);                                     // a: xy, b: t1 = YZ, c: x3 = t2b z8
+    // round 2: a: X*Y, b: x3 = t2b * 8Y^2, c: t1 = Z*Y
+    fp2_select(a, t.role == 1, t2b, tc);
+    fp2_select(b, t.role == 1, z8, yt);
+    fp2_mul(p2, a, b);
     // u = Y^2 - 9b' Z^2, y3' = Y^2 + 3b' Z^2
     fp2_dbl(u, t2b); fp2_add(u, u, t2b); fp2_sub(u, t0, u); fp2_norm1(u, u);
     fp2_add(y3p, t0, t2b);
-    // round 3: a: u * xy, b: t1 * z8, c: u * y3'
-    fp2_select(a, t.role == 1, p2, u);
-    fp2_select(b, t.role == 0, p2, z8); fp2_select(b, t.role == 2, y3p, b);
+    // round 3: a: u * xy, b: u * y3', c: t1 * z8
+    fp2_select(a, t.role == 2, p2, u);
+    fp2_select(b, t.role == 0, p2, y3p); fp2_select(b, t.role == 2, z8, b);
     fp2_mul(p3, a, b);
-    // a: X3 = 2 u xy; b: Z3 = t1 z8; c: Y3 = u y3' + x3
+    // a: X3 = 2 u xy; b: Y3 = u y3' + x3; c: Z3 = t1 z8 — each on the lane that holds that coordinate
     fp2 xa, yc;
     fp2_dbl(xa, p3);
     fp2_add(yc, p3, p2);
-    fp2_select(own, t.role == 0, xa, p3); fp2_select(own, t.role == 2, yc, own);   // role b holds Z3, role c holds Y3
-    // line pieces: a: l2 = 3 X^2 px, b: l0 = -2 YZ (1+i) py, c: l1 = 3b'Z^2 - Y^2
+    fp2_select(own, t.role == 0, xa, p3); fp2_select(own, t.role == 1, yc, own);
+    // line pieces: a: l2 = 3 X^2 px, b: l1 = 3b'Z^2 - Y^2, c: l0 = -2 YZ (1+i) py
     fp2 cc, aa, pm, bb;
     fp2_dbl(cc, s0); fp2_add(cc, cc, s0);                  // a: 3X^2
-    fp2_dbl(aa, p2); fp2_neg(aa, aa); fp2_mul_ip(aa, aa);  // b: -2YZ(1+i)
+    fp2_dbl(aa, p2); fp2_neg(aa, aa); fp2_mul_ip(aa, aa);  // c: -2YZ(1+i)
     fp2_select(a, t.role == 0, cc, aa);
     fp2_norm1(a, a);
     fp2_mul_fp(pm, a, sel);
     fp2_sub(bb, t2b, t0); fp2_norm1(bb, bb);
-    fp2_select(piece, t.role == 2, bb, pm);
+    fp2_select(piece, t.role == 1, bb, pm);
     tri_fetch_fp2(l2, piece, 0, t);
-    tri_fetch_fp2(l0, piece, 1, t);
-    tri_fetch_fp2(l1, piece, 2, t);
-    // put Y3 on role 1 and Z3 on role 2
-    fp2 sw;
-    const int src = t.role == 0 ? 0 : (t.role == 1 ? 2 : 1);
-    tri_fetch_fp2(sw, own, src, t);
-    tc = sw;
+    tri_fetch_fp2(l0, piece, 2, t);
+    tri_fetch_fp2(l1, piece, 1, t);
+    tc = own;
 }
 C12381_HDN void miller3_dbl_step(fp2& tc, fp2& l0, fp2& l1, fp2& l2, const fp& px, const fp& py, const tri& t) {
     miller3_dbl_step_core(tc, l0, l1, l2, px, py, t);
