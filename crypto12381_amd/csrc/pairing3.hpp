@@ -160,6 +160,20 @@ C12381_HD void fp4_mul_core(fp4& w, const fp4& x, const fp4& y) {
     fp2_norm1(w.b, t4);
     fp2_norm1(w.a, t3);
 }
+// the same without the final carry round (limbs up to 3 * 2^28): for a product that only enters a difference which is
+// carried afterwards (the Karatsuba middle term)
+C12381_HD void fp4_mul_core_raw(fp4& w, const fp4& x, const fp4& y) {
+    fp2 t1, t2, t3, t4;
+    fp2_mul(t1, x.a, y.a);
+    fp2_mul(t2, x.b, y.b);
+    fp2_add(t3, y.b, y.a);
+    fp2_add(t4, x.b, x.a);
+    fp2_mul(t4, t4, t3);
+    fp2_sub(t4, t4, t1);
+    fp2_sub(w.b, t4, t2);
+    fp2_mul_ip(t3, t2);
+    fp2_add(w.a, t3, t1);
+}
 
 // ------------------------------------------------------------------ Fp12 arithmetic on a triple
 // combine step shared by product and square: given this lane's z = x_r y_r and e = x_r y_{r+1} + x_{r+1} y_r,
@@ -215,7 +229,7 @@ C12381_HDN void f12t_mul_h(fp4& H, const fp4& y, const tri& t) {
             fp4_addn(sx, x, xn); fp4_addn(sy, yv, yn);
         }
         C12381_PHASE();
-        fp4_mul_core(zc, sx, sy);
+        fp4_mul_core_raw(zc, sx, sy);                      // un-normalised: only enters e
         C12381_PHASE();
     }
     {   // x y: x comes back from the slot, which then takes zc; y is read again through a pointer the compiler cannot match
@@ -244,7 +258,7 @@ C12381_HD void f12t_sqr_body(fp4& w, const fp4& x, const tri& t) {
     tri_fetch_fp4(xn, x, tri_next(t), t);
     fp4_sqr_core(z, x);
     fp4_add(sx, x, xn);                                    // limbs < 2^29 + slack: within the operand bound of the Fp2 products (host simulation asserts it)
-    fp4_sqr_core(zc, sx);
+    fp4_sqr_core_raw(zc, sx);                           // un-normalised: zc only enters e, which gets its own carry round
     tri_fetch_fp4(zn, z, tri_next(t), t);
     fp4_sub(e, zc, z); fp4_sub(e, e, zn); fp4_norm1(e, e);
     f12t_combine(w, z, zn, e, t);
@@ -345,7 +359,7 @@ C12381_HD void f12t_mul_line_core(fp4& x, const fp2& l0, const fp2& l1, const fp
     fp2 q0, q1, qn0, qn1, ia, ib;
     fp2_mul(q0, x.a, l2);
     fp2_mul(q1, x.b, l2);
-    fp4_mul_core(p, x, la);
+    fp4_mul_core_raw(p, x, la);                            // carried once, together with the terms added below
     tri_fetch_fp2(qn0, q0, tri_next(t), t);
     tri_fetch_fp2(qn1, q1, tri_next(t), t);
     // roles a, b: + ((1+i) qn0, (1+i) qn1);   role c: + ((1+i) qn1, qn0)
@@ -558,7 +572,7 @@ C12381_HD void miller3_iter_body(fp2& tc, fp4& F, int info) {
             tri_fetch_fp4(xn, x, tri_next(t), t);
             fp4_add(sx, x, xn);                            // limbs < 2^29 + slack: within the operand bound of the Fp2 products
             C12381_PHASE();
-            fp4_sqr_core(zc, sx);
+            fp4_sqr_core_raw(zc, sx);                           // un-normalised: zc only enters e, which gets its own carry round
             C12381_PHASE();
         }
         {
