@@ -1,0 +1,17 @@
+set -o pipefail
+mkdir -p gpurun_out/final
+timeout -k 10 900 python -m pytest tests -m gpu -q 2>&1 | tail -15 > gpurun_out/final/pytest_gpu.log; echo "pytest rc=$?"; tail -2 gpurun_out/final/pytest_gpu.log
+python bench.py --steps 20 --warmup 5 > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err; echo "bench rc=$?"
+ROOT=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/final/prof -o p -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --sampled-parity > $ROOT/gpurun_out/final/bench_under_rocprof.json 2> $ROOT/gpurun_out/final/rocprof.err; echo "rocprof rc=$?"
+cd $ROOT
+bash tools/pmc_traffic.sh gpurun_out/final/pmc > gpurun_out/final/pmc.txt 2>&1; tail -4 gpurun_out/final/pmc.txt
+timeout -k 10 400 python3 tools/soak.py > gpurun_out/final/soak.log 2>&1; echo "soak rc=$?"; tail -2 gpurun_out/final/soak.log
+python - <<'PY'
+import json
+d=json.load(open("gpurun_out/final/bench.json"))
+print(d["value"], d["ms_per_step"], d["roofline"])
+for k in ("pairing","msm","bbs_plus"):
+    if k in d: print(k, d[k]["value"], d[k]["ms_per_step"], d[k].get("roofline",{}).get("frac"), d[k].get("roofline",{}).get("avg_launch_ms"))
+PY
