@@ -185,14 +185,20 @@ C12381_HD void soa_load_g1(g1p& p, const int32_t* base, size_t stride, size_t id
 }
 
 // ------------------------------------------------------------------ per-lane window table
-// Signed 4-bit windows: entries 1..8 of multiples of P, each entry X|Y|Z = 42 dwords padded to 44 (176 B,
-// eleven 16-byte accesses).  A lane's whole table is one contiguous 1408-byte record, so a gather of one
+// Signed 5-bit windows: entries 1..16 of multiples of P (4-bit: 1..8), each entry X|Y|Z = 42 dwords padded to 44 (176 B,
+// eleven 16-byte accesses).  A lane's whole table is one contiguous 2816-byte record, so a gather of one
 // entry touches 176 consecutive bytes of HBM instead of 42 scattered dwords (the limb-major layout of the
 // first version moved ~16x the algorithmic bytes: profiles/r01_pmc_summary_before_table_fix.txt).
-constexpr int G1_WIN = 4;
-constexpr int G1_TAB = 8;                              // entries 1..8
+// Per scalar multiplication: 1 + 125 doublings and 14 + 52 additions (4-bit windows: 1 + 128 and 6 + 66).
+#ifndef C12381_G1_WIN
+#define C12381_G1_WIN 5                                 // 4 or 5; A/B on MI355X: 5 is 3.5 % faster
+#endif
+constexpr int G1_WIN = C12381_G1_WIN;
+static_assert(G1_WIN == 4 || G1_WIN == 5, "window width");
+constexpr int G1_TAB = 1 << (G1_WIN - 1);              // entries 1..8 (1..16)
+constexpr int G1_WINDOWS = G1_WIN == 4 ? 33 : 26;      // 4: 32 biased nibbles + the carry nibble; 5: 26 biased fields cover 130 bits
 constexpr int G1_ENT_DWORDS = 44;
-constexpr int G1_TAB_DWORDS = G1_TAB * G1_ENT_DWORDS;  // 352 dwords = 1408 B per lane
+constexpr int G1_TAB_DWORDS = G1_TAB * G1_ENT_DWORDS;  // 352 dwords = 1408 B per lane (5-bit windows: 2816 B)
 struct alignas(16) q4 { int32_t v[4]; };
 
 C12381_HD void tab_store_g1(int32_t* ent, const g1p& p) {
@@ -216,15 +222,35 @@ C12381_HD void tab_load_g1(g1p& p, const int32_t* ent) {
 }
 // signed digit of window w of k' = k + 0x888...8 (32 nibbles): d = nibble - 8 in [-8, 7]; window 32 is the
 // carry nibble (0 or 1, no bias).  Sum_w d_w 16^w = k.
+// 5-bit windows: k' = k + sum_w 16 * 32^w (w < 26; k < 2^128, so k' < 2^130 and there is no carry window):
+// d = field - 16 in [-16, 15].
+constexpr uint32_t glv_bias_word5(int i) {
+    uint32_t v = 0;
+    for (int w = 0; w < 26; ++w) { const int bit = 5 * w + 4; if ((bit >> 5) == i) v |= 1u << (bit & 31); }
+    return v;
+}
 C12381_HD int glv_digit(const uint32_t (&kb)[5], int w) {
-    const int nib = (int)((kb[w >> 3] >> ((w & 7) * 4)) & 15u);
-    return w == 32 ? nib : nib - 8;
+    if (G1_WIN == 4) {
+        const int nib = (int)((kb[w >> 3] >> ((w & 7) * 4)) & 15u);
+        return w == 32 ? nib : nib - 8;
+    }
+    const int bit = 5 * w, word = bit >> 5, sh = bit & 31;
+    uint32_t v = kb[word] >> sh;
+    if (sh > 27) v |= kb[word + 1] << (32 - sh);
+    return (int)(v & 31u) - 16;
 }
 C12381_HD void glv_bias(uint32_t (&kb)[5], const uint32_t (&k)[4]) {
     uint64_t c = 0;
+    if (G1_WIN == 4) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { c += (uint64_t)k[i] + 0x88888888u; kb[i] = (uint32_t)c; c >>= 32; }
-    kb[4] = (uint32_t)c;
+        for (int i = 0; i < 4; ++i) { c += (uint64_t)k[i] + 0x88888888u; kb[i] = (uint32_t)c; c >>= 32; }
+        kb[4] = (uint32_t)c;
+    } else {
+        constexpr uint32_t B[5] = {glv_bias_word5(0), glv_bias_word5(1), glv_bias_word5(2), glv_bias_word5(3), glv_bias_word5(4)};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { c += (uint64_t)k[i] + B[i]; kb[i] = (uint32_t)c; c >>= 32; }
+        kb[4] = (uint32_t)c + B[4];
+    }
 }
 // acc += sign(d) * T[|d|]  (d == 0 adds the point at infinity: same instruction stream)
 C12381_HD void g1_add_digit(g1p& acc, const int32_t* lane_tab, int d, bool endo) {
@@ -293,7 +319,7 @@ C12381_HDN void g1_glv_small_scalar_term(g1p& acc, const g1p& base) {
     g1_add(acc, s2);
 }
 
-// [k]P for an AFFINE input point (x, y) or infinity.  `lane_tab` = this lane's 1408-byte table record.
+// [k]P for an AFFINE input point (x, y) or infinity.  `lane_tab` = this lane's table record (G1_TAB_DWORDS).
 C12381_HD void g1_scalar_mul(g1p& acc, const fp& px, const fp& py, bool p_is_inf, const uint32_t (&kin)[8], int32_t* lane_tab) {
     uint32_t k[8];
 #pragma unroll
@@ -304,7 +330,7 @@ C12381_HD void g1_scalar_mul(g1p& acc, const fp& px, const fp& py, bool p_is_inf
     glv_bias(kb0, k0);
     glv_bias(kb1, k1);
 
-    // table T[j] = j*P, j = 1..8, stored normalised (limb bound 2^28 + slack)
+    // table T[j] = j*P, j = 1..G1_TAB, stored normalised (limb bound 2^28 + slack)
     g1p base, t;
     base.x = px; base.y = py; fp_one(base.z);
     {   // infinity input: use (0:1:0) as the base so every multiple is infinity
@@ -334,8 +360,11 @@ C12381_HD void g1_scalar_mul(g1p& acc, const fp& px, const fp& py, bool p_is_inf
 
     g1_set_inf(acc);
 #pragma unroll 1
-    for (int w = 32; w >= 0; --w) {
-        if (w != 32) { g1_dbl(acc); g1_dbl(acc); g1_dbl(acc); g1_dbl(acc); }    // wave-uniform
+    for (int w = G1_WINDOWS - 1; w >= 0; --w) {
+        if (w != G1_WINDOWS - 1) {                                              // wave-uniform
+            g1_dbl(acc); g1_dbl(acc); g1_dbl(acc); g1_dbl(acc);
+            if (G1_WIN == 5) g1_dbl(acc);
+        }
         g1_add_digit(acc, lane_tab, glv_digit(kb0, w), false);
         g1_add_digit(acc, lane_tab, glv_digit(kb1, w), true);
     }

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Build an alternative libc12381_hip.so with extra compile flags into crypto12381_amd/lib/exp/lib<name>.so (A/B runs: C12381_LIB).
+# usage: bash tools/build_variant.sh <name> <extra flags...>      e.g.  bash tools/build_variant.sh win5 -DC12381_G1_WIN=5
+set -e
+NAME=$1; shift
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$ROOT/crypto12381_amd/lib/exp; OBJ=$OUT/obj_$NAME
+mkdir -p $OBJ
+FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -fno-optimize-sibling-calls -mllvm -amdgpu-sched-strategy=max-ilp"
+pids=""
+for u in c12381_hip k_g1 k_g2gt k_g2h k_pair3 k_hash_zp k_fixed; do
+  /opt/rocm/bin/hipcc $FLAGS "$@" -c -o $OBJ/$u.o $ROOT/crypto12381_amd/csrc/$u.hip 2> $OBJ/$u.err &
+  pids="$pids $!"
+done
+for p in $pids; do wait $p; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/lib$NAME.so $OBJ/*.o
+rm -rf $OBJ
+ls -la $OUT/lib$NAME.so
