@@ -643,15 +643,78 @@ C12381_HD void f12t_one(fp4& F, const tri& t) {
     fp4_zero(zero4); one4 = zero4; fp_one(one4.a.a);
     fp4_select(F, t.role == 0, one4, zero4);
 }
-// addition step T <- T +- Q and its line (the 5 iterations whose digit of 3|x| - |x| is non-zero)
+// addition step T <- T +- Q and its line (the 5 iterations whose digit of 3|x| - |x| is non-zero), on the three lanes.
+// The values are those of PAIR_add (pair_BLS12381.cpp:81-116) + ECP2_add (ecp2_BLS12381.cpp:413-502) with the second operand
+// affine, Z2 in {1, 0} (0: the G2 argument is infinity and runs as (0 : 1 : 0) with the affine view (0, 1), like there):
+//   line   l0 = (X1 - Z1 x2)(1+i) py,  l1 = (Y1 - Z1 y2) x2 - (X1 - Z1 x2) y2,  l2 = -(Y1 - Z1 y2) px
+//   sum    t0 = X1 x2, t1 = Y1 y2, t2 = Z1 Z2, t3 = X1 y2 + Y1 x2, t4 = Y1 Z2 + Z1 y2, y3 = 3b'(X1 Z2 + Z1 x2),
+//          X3 = t3 (t1 - 3b't2) - y3 t4,  Y3 = y3 3t0 + (t1 - 3b't2)(t1 + 3b't2),  Z3 = (t1 + 3b't2) t4 + 3t0 t3
+// (the products by Z2 and the Karatsuba forms of t3, t4, y3 in the reference are these values).  Five rounds of one Fp2 product per
+// lane — own coordinate times x2 / y2 twice, the two line products, two products of the own output coordinate — instead of the
+// whole one-lane step (16 Fp2 products) replicated on every lane.
 C12381_HD void miller3_add_line(fp4& F, fp2& tc, const fp& px, const fp& py, bool skip, const g2p& Q, bool neg, const tri& t) {
-    fp2 l0, l1, l2, one2, zero2;
-    g2p T, S = Q;
-    tri_fetch_fp2(T.x, tc, 0, t); tri_fetch_fp2(T.y, tc, 1, t); tri_fetch_fp2(T.z, tc, 2, t);
-    if (neg) g2_neg(S, Q);
-    miller_add_step(T, S, l0, l1, l2, px, py);             // replicated on the three lanes
-    fp2_select(tc, t.role == 0, T.x, T.y); fp2_select(tc, t.role == 2, T.z, tc);
-    fp2_one(one2); fp2_zero(zero2);
+    fp2 X1, Y1, Z1, x2, y2, zero2, one2;
+    fp2_zero(zero2); fp2_one(one2);
+    tri_fetch_fp2(X1, tc, 0, t); tri_fetch_fp2(Y1, tc, 1, t); tri_fetch_fp2(Z1, tc, 2, t);
+    x2 = Q.x;
+    {
+        fp2 ny;
+        fp2_neg(ny, Q.y); fp2_norm1(ny, ny);
+        fp2_select(y2, neg, ny, Q.y);
+    }
+    const bool z2_zero = fp2_is_zero(Q.z);
+    // rounds 1, 2: own coordinate times (x2 | y2 | y2) and (y2 | x2 | x2)
+    fp2 B, p1, p2;
+    fp2_select(B, t.role == 0, x2, y2);
+    fp2_mul(p1, tc, B);                                     // a: t0 = X1 x2, b: t1 = Y1 y2, c: zy = Z1 y2
+    fp2_select(B, t.role == 0, y2, x2);
+    fp2_mul(p2, tc, B);                                     // a: X1 y2,      b: Y1 x2,      c: zx = Z1 x2
+    fp2 t0, t1, zy, xy, yx, zx;
+    tri_fetch_fp2(t0, p1, 0, t); tri_fetch_fp2(t1, p1, 1, t); tri_fetch_fp2(zy, p1, 2, t);
+    tri_fetch_fp2(xy, p2, 0, t); tri_fetch_fp2(yx, p2, 1, t); tri_fetch_fp2(zx, p2, 2, t);
+    C12381_PHASE();
+    // values every lane forms for itself (additions only)
+    fp2 aa, cc, t3, t4, y3, t2, z3, t1m, t03, xz, yz, zz;
+    fp2_sub(aa, X1, zx); fp2_norm1(aa, aa);
+    fp2_sub(cc, Y1, zy); fp2_norm1(cc, cc);
+    fp2_add(t3, xy, yx); fp2_norm1(t3, t3);
+    fp2_select(xz, z2_zero, zero2, X1); fp2_select(yz, z2_zero, zero2, Y1); fp2_select(zz, z2_zero, zero2, Z1);
+    fp2_add(t4, yz, zy); fp2_norm1(t4, t4);
+    fp2_add(y3, xz, zx); fp2_mul_b3(y3, y3);
+    fp2_norm1(t2, zz); fp2_mul_b3(t2, t2);
+    fp2_add(z3, t1, t2); fp2_norm1(z3, z3);
+    fp2_sub(t1m, t1, t2); fp2_norm1(t1m, t1m);
+    fp2_mul_small(t03, t0, 3);
+    // operands of rounds 4, 5 (the lane's own coordinate of T + Q) are picked now, so that the six shared values die here
+    fp2 A4, B4, A5, B5;
+    fp2_select(A4, t.role == 0, t3, y3);  fp2_select(A4, t.role == 2, z3, A4);
+    fp2_select(B4, t.role == 0, t1m, t03); fp2_select(B4, t.role == 2, t4, B4);
+    fp2_select(A5, t.role == 0, y3, t1m);  fp2_select(A5, t.role == 2, t03, A5);
+    fp2_select(B5, t.role == 0, t4, z3);   fp2_select(B5, t.role == 2, t3, B5);
+    C12381_PHASE();
+    // round 3: a: aa y2, b: cc x2;  half products: a: aa (1+i) py, b: -cc px
+    fp2 A, p3, aai, ncc, H, h;
+    fp s;
+    fp2_select(A, t.role == 1, cc, aa);
+    fp2_select(B, t.role == 1, x2, y2);
+    fp2_mul(p3, A, B);
+    fp2_mul_ip(aai, aa); fp2_neg(ncc, cc);
+    fp2_select(H, t.role == 1, ncc, aai);
+    fp_select(s, t.role == 1, px, py);
+    fp2_mul_fp(h, H, s);
+    C12381_PHASE();
+    // rounds 4, 5
+    fp2 P4, P5, dif, sum;
+    fp2_mul(P4, A4, B4);
+    fp2_mul(P5, A5, B5);
+    fp2_sub(dif, P4, P5); fp2_add(sum, P4, P5);
+    fp2_select(tc, t.role == 0, dif, sum);
+    C12381_PHASE();
+    // the line
+    fp2 l0, l1, l2, m, tl;
+    tri_fetch_fp2(tl, p3, 0, t); tri_fetch_fp2(m, p3, 1, t);
+    tri_fetch_fp2(l0, h, 0, t); tri_fetch_fp2(l2, h, 1, t);
+    fp2_sub(l1, m, tl); fp2_norm1(l1, l1);
     fp2_select(l0, skip, one2, l0); fp2_select(l1, skip, zero2, l1); fp2_select(l2, skip, zero2, l2);
     f12t_mul_line_h(F, l0, l1, l2, t);
 }

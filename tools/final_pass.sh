@@ -7,6 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/final/prof -o p -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --sampled-parity > $ROOT/gpurun_out/final/bench_under_rocprof.json 2> $ROOT/gpurun_out/final/rocprof.err; echo "rocprof rc=$?"
 cd $ROOT
 bash tools/pmc_traffic.sh gpurun_out/final/pmc > gpurun_out/final/pmc.txt 2>&1; tail -4 gpurun_out/final/pmc.txt
+bash tools/bench_2rank_gloo.sh > gpurun_out/final/bench_2rank_gloo.json 2> gpurun_out/final/bench_2rank_gloo.err; echo "2rank rc=$?"
 timeout -k 10 400 python3 tools/soak.py > gpurun_out/final/soak.log 2>&1; echo "soak rc=$?"; tail -2 gpurun_out/final/soak.log
 python - <<'PY'
 import json
