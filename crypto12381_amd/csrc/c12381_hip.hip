@@ -345,6 +345,7 @@ int c12381_create(int device, c12381_ctx** out) {
         hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming) != hipSuccess) { c12381_destroy(c); return C12381_E_HIP; }
     if (hipMalloc((void**)&c->d_flag, FLAG_WORDS * sizeof(int)) != hipSuccess || hipHostMalloc((void**)&c->h_flag, FLAG_WORDS * sizeof(int)) != hipSuccess ||
         hipMemset(c->d_flag, 0, FLAG_WORDS * sizeof(int)) != hipSuccess) { c12381_destroy(c); return C12381_E_HIP; }
+    if (const char* e = std::getenv("C12381_QUEUE_GROUPS")) set_queue_groups_override(std::atoi(e));      // tuning runs only
     *out = c;
     return 0;
 }
@@ -1141,7 +1142,7 @@ static int fixed_table(c12381_ctx* c, int slot, const uint8_t* d_base, bool is_g
 }
 // Coefficient table of a fixed G2 argument of the Miller loop (pairing3.hpp): same header / cache protocol as above.
 static int lines_table(c12381_ctx* c, int slot, const uint8_t* d_q192, int need_g2) {
-    const size_t dwords = FB_HEADER_DWORDS + (size_t)FQ_LINES * FQ_LINE_DWORDS;
+    const size_t dwords = FB_HEADER_DWORDS + (size_t)FQ_TABLE_DWORDS;
     int rc;
     if (c->ws_bytes[slot] < dwords * 4) {
         if ((rc = ensure(c, slot, dwords * 4))) return rc;
@@ -1150,7 +1151,8 @@ static int lines_table(c12381_ctx* c, int slot, const uint8_t* d_q192, int need_
     int32_t* buf = (int32_t*)c->ws[slot];
     hipLaunchKernelGGL(fixed_cache_check_kernel, dim3(1), dim3(64), 0, c->stream, d_q192, 192, buf);
     HIPCK(c, hipGetLastError());
-    hipLaunchKernelGGL(g2_lines_table_kernel, dim3(1), dim3(BLOCK), 0, c->stream, d_q192, buf, need_g2);
+    static const int raw = [] { const char* e = std::getenv("C12381_FQ_RAW"); return (e && e[0] == '1') ? 4 : 0; }();
+    hipLaunchKernelGGL(g2_lines_table_kernel, dim3(1), dim3(BLOCK), 0, c->stream, d_q192, buf, need_g2 | raw);
     HIPCK(c, hipGetLastError());
     return 0;
 }

@@ -10,13 +10,20 @@
 // 2^16 pairings (3121 groups, 2048 resident wavefronts): 2048 queued 21.8 ms, 1024 queued 19.4 ms, 512 queued 20.1 ms;
 // 2^18 BBS+ verifications (12484 groups): 2048 queued 82.0 ms, 1024 queued 82.4 ms, 512 queued 88.9 ms, 256 queued 97.3 ms —
 // the more whole groups a wavefront runs, the further apart the wavefronts finish: a third of the groups, between half a
-// grid and a whole grid.
+// grid and two grids (re-measured with the normalised line tables: 12484 groups, 2048 queued 83.2 ms, 4096 80.5, 6144 80.4, all 82.1).
+// tuning runs: C12381_QUEUE_GROUPS = number of groups that go through the queue (c12381_set_queue_groups; 0 = the rule below)
+__device__ int g_queue_groups_override = 0;
 __device__ __forceinline__ size_t queue_direct_groups(size_t ngroups, size_t nwaves) {
     if (ngroups <= nwaves) return 0;
     size_t queued = ngroups / 3;
     if (queued < nwaves / 2) queued = nwaves / 2;
-    if (queued > nwaves) queued = nwaves;
+    if (queued > 2 * nwaves) queued = 2 * nwaves;             // 12484 groups (2^18 BBS+): 2048 queued 83.2 ms, 4096 80.5, 6144 80.4, all 82.1 (r02_ab_queued_groups.txt)
+    const int ov = g_queue_groups_override;
+    if (ov > 0) queued = (size_t)ov < ngroups ? (size_t)ov : ngroups;
     return ngroups - queued;
+}
+namespace c12381 {
+int set_queue_groups_override(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(g_queue_groups_override), &v, sizeof(int)) == hipSuccess ? 0 : -1; }
 }
 
 using namespace c12381;
@@ -367,7 +374,10 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_queue_kernel(size_t n, cons
 // need_g2 != 0: valid only for elements of G2 other than infinity (BBS+ rewrite); need_g2 == 0: any point of the twist
 // and infinity (plain pairing against one Q: the table holds exactly the lines the running-point loop would compute).
 // header[HDR_RULE] remembers which rule the cached flag was computed under.
-__global__ void __launch_bounds__(BLOCK, 2) g2_lines_table_kernel(const uint8_t* q192, int32_t* buf, int need_g2) {
+// need_g2: bit 0 = the point has to be in G2, bit 2 = keep the records raw (A/B switch C12381_FQ_RAW)
+__global__ void __launch_bounds__(BLOCK, 2) g2_lines_table_kernel(const uint8_t* q192, int32_t* buf, int need_g2_flags) {
+    const int need_g2 = need_g2_flags & 1;
+    const bool raw = (need_g2_flags & 4) != 0;
     if (buf[HDR_REBUILD] == 0 && buf[HDR_RULE] == need_g2 + 1) return;    // cached table is current
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     g2p Q;
@@ -377,7 +387,7 @@ __global__ void __launch_bounds__(BLOCK, 2) g2_lines_table_kernel(const uint8_t*
     const bool valid = need_g2 ? (ok && !inf && g2_in_subgroup(Q)) : ok;
     buf[HDR_VALID] = valid ? 1 : 0;
     buf[HDR_RULE] = need_g2 + 1;
-    if (valid) miller_lines_precompute(buf + HDR_DWORDS, Q.x, Q.y, inf);
+    if (valid) miller_lines_precompute(buf + HDR_DWORDS, Q.x, Q.y, inf, !raw);
 }
 // gate[HDR_VALID] = a valid and b valid (the table-driven kernels run), (gate + GATE_OTHER)[HDR_VALID] = the opposite (the generic kernels run)
 __global__ void __launch_bounds__(BLOCK, 2) gate_and_kernel(int32_t* gate, const int32_t* a, const int32_t* b) {

@@ -23,6 +23,7 @@ constexpr int HDR_REBUILD = 49;                  // set by fixed_cache_check_ker
 constexpr int HDR_MAGIC = 50;                    // the header has been written before
 constexpr int HDR_RULE = 51;                     // validity rule the flag was computed under (line tables)
 constexpr int HDR_DWORDS = 64;                   // table data starts here
+int set_queue_groups_override(int v);             // k_pair3.hip: tuning switch (C12381_QUEUE_GROUPS)
 constexpr int GATE_OTHER = 49;                   // (gate + GATE_OTHER)[HDR_VALID] = the complement of gate[HDR_VALID]
 
 __global__ void __launch_bounds__(BLOCK, 2) fp_op_kernel(int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out);

@@ -68,6 +68,10 @@ __global__ void __launch_bounds__(BLOCK, PR_WAVES) routine_kernel(int iters, con
         else if constexpr (KIND == 7) { fp r; fp_mul(r, px, py); fp_mul(px, r, py); }          // two dependent Fp products, registers only
         else if constexpr (KIND == 8) { fp2 r; fp2_mul(r, tc, a.a); fp2_mul(tc, r, a.a); }      // two dependent Fp2 products
         else if constexpr (KIND == 9) { f12t_sqr_h(H, t); miller3_dbl_line(H, tc, px, py, false, t); }   // one Miller iteration without addition step
+        else if constexpr (KIND == 12) miller3_fixed_line_raw(H, seed, it & 63, px, py, false, t);      // line records: any normalised limbs (timing only)
+        else if constexpr (KIND == 13) miller3_fixed_line1(H, seed, it & 63, px, py, false, t);
+        else if constexpr (KIND == 14) miller3_range2_fixed(H, px, py, false, seed + 16384, py, px, false, seed + 32768, 64, 1, t);   // raw tables (format word 0)
+        else if constexpr (KIND == 15) miller3_range2_fixed(H, px, py, false, seed + 65536, py, px, false, seed + 81920, 64, 1, t);   // normalised tables (format word 1)
         else if constexpr (KIND == 11) { miller3_regs R = m3r_pack(tc, H, t.role | (t.base << 2)); R = miller3_iter(R); m3r_tc(tc, R); }   // the same as ONE routine
     }
     if (threadIdx.x == 0) {
@@ -117,6 +121,7 @@ int main(int argc, char** argv) {
     std::vector<int32_t> seed((size_t)4096 * 8 * NL);
     uint64_t s = 0x9e3779b97f4a7c15ull;
     for (auto& v : seed) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (int32_t)(s & LMASK); }
+    seed[16384 + FQ_FMT_WORD] = 0; seed[32768 + FQ_FMT_WORD] = 0; seed[65536 + FQ_FMT_WORD] = 1; seed[81920 + FQ_FMT_WORD] = 1;
     int32_t *d_seed, *d_sink; uint64_t* d_stamps;
     CK(hipMalloc(&d_seed, seed.size() * 4));
     CK(hipMalloc(&d_sink, (size_t)blocks * BLOCK * 4 * NL * 4));
@@ -129,6 +134,10 @@ int main(int argc, char** argv) {
     if (run<1>("miller3_dbl_line", iters, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
     if (run<9>("sqr + dbl_line", iters, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
     if (run<11>("miller3_iter", iters, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
+    if (run<12>("fixed_line (raw)", iters, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
+    if (run<13>("fixed_line (l1 = 1)", iters, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
+    if (run<14>("range2_fixed raw", iters / 20, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
+    if (run<15>("range2_fixed l1 = 1", iters / 20, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
     if (run<2>("f12t_usqr_h", iters * 2, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
     if (run<3>("f12t_mul_h (LDS)", iters, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
     if (run<10>("f12t_mul (private)", iters, blocks, d_seed, d_sink, d_stamps, wps)) return 1;

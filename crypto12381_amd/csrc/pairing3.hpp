@@ -48,6 +48,21 @@ C12381_HD void tri_fetch_fp4(fp4& out, const fp4& v, int s, const tri& t) { tri_
 C12381_HD int tri_next(const tri& t) { return t.role == 2 ? 0 : t.role + 1; }
 C12381_HD int tri_prev(const tri& t) { return t.role == 0 ? 2 : t.role - 1; }
 
+// A pointer or integer that is the same on every lane of the wavefront, as the compiler cannot know it of a function argument:
+// the copy lives in SGPRs, which survive the out-of-line calls of the hot loops — an argument in a VGPR is clobbered by every
+// call (the big routines save nothing) and is reloaded from private memory before the next one, a load whose latency is exposed.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T> C12381_HD T* wave_uniform(T* p) {
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (T*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+C12381_HD int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#else
+template <class T> C12381_HD T* wave_uniform(T* p) { return p; }
+C12381_HD int wave_uniform(int v) { return v; }
+#endif
+
 // ------------------------------------------------------------------ the per-lane LDS slot
 // The running Fp12 coefficient of the Miller loop and of the exponentiations lives in one 224-byte LDS slot per lane (k_pair3.hip).
 // The out-of-line routines below that end in _h take THAT slot: they move it with explicit LDS instructions (ds_read_b128 /
@@ -371,6 +386,29 @@ C12381_HD void f12t_mul_line_core(fp4& x, const fp2& l0, const fp2& l1, const fp
     fp2_add(p.a, p.a, ia);
     fp2_add(p.b, p.b, ib);
     fp4_norm1(x, p);
+}
+// the same for a line whose s-coefficient is 1 (l1 = 1: the lines of a fixed G2 argument are stored divided by it, see
+// miller_lines_precompute): x (l0 + s) = (xa l0 + (1+i) xb) + (xa + xb l0) s — two Fp2 products instead of Karatsuba's three
+C12381_HD void f12t_mul_line1_core(fp4& x, const fp2& l0, const fp2& l2, const tri& t) {
+    fp4 p;
+    fp2 q0, q1, qn0, qn1, ia, ib, t1, t2, ix;
+    fp2_mul(q0, x.a, l2);
+    fp2_mul(q1, x.b, l2);
+    fp2_mul(t1, x.a, l0);
+    fp2_mul(t2, x.b, l0);
+    fp2_mul_ip(ix, x.b);
+    fp2_add(p.a, t1, ix);
+    fp2_add(p.b, x.a, t2);
+    tri_fetch_fp2(qn0, q0, tri_next(t), t);
+    tri_fetch_fp2(qn1, q1, tri_next(t), t);
+    fp2 pick;
+    fp2_select(pick, t.role == 2, qn1, qn0);
+    fp2_mul_ip(ia, pick);
+    fp2_mul_ip(ib, qn1);
+    fp2_select(ib, t.role == 2, qn0, ib);
+    fp2_add(p.a, p.a, ia);
+    fp2_add(p.b, p.b, ib);
+    fp4_weak_reduce(x, p);                                 // x passes through unmultiplied (xa, (1+i) xb): without a reduction its value bound would double per line
 }
 C12381_HDN void f12t_mul_line(fp4& x, const fp2& l0, const fp2& l1, const fp2& l2, const tri& t) { f12t_mul_line_core(x, l0, l1, l2, t); }
 C12381_HDN void f12t_mul_line_h(fp4& H, const fp2& l0, const fp2& l1, const fp2& l2, const tri& t) {
@@ -783,7 +821,9 @@ C12381_HDN void miller3_rangeK(fp4& F, miller3_pair* pr, int K, int hi, int lo, 
 // BBS+ verification) the 69 coefficient triples are computed once — by running the one-lane steps with P = (1, 1) —
 // and an iteration costs four Fp multiplications per line instead of the G2 doubling.
 constexpr int FQ_LINES = 69;                         // 64 doubling steps + 5 addition steps, in loop order
-constexpr int FQ_LINE_DWORDS = 6 * NL;               // c0, c1, c2: 336 B = 21 16-byte words
+constexpr int FQ_LINE_DWORDS = 6 * NL;               // record stride: c0, c1, c2 (336 B = 21 16-byte words); normalised records use c0/c1, c2/c1 (224 B)
+constexpr int FQ_FMT_WORD = FQ_LINES * FQ_LINE_DWORDS;  // tab[FQ_FMT_WORD]: 1 = every record is (c0/c1, c2/c1), 0 = raw (c0, c1, c2)
+constexpr int FQ_TABLE_DWORDS = FQ_FMT_WORD + 4;
 constexpr int fq_line_index(int i) {                 // index of iteration i's doubling line (its addition line follows)
     constexpr unsigned __int128 N1 = (unsigned __int128)BLS_X;
     constexpr unsigned __int128 N3 = N1 * 3;
@@ -803,7 +843,7 @@ C12381_HD void fq_load_line(fp2& c0, fp2& c1, fp2& c2, const int32_t* src) {
 }
 // one lane: the whole coefficient table of Q (affine point of the twist; "infinity" runs as (0:1:0) with the affine
 // view (0, 1), exactly as the running-point loop does — the coefficients are the same field elements either way)
-C12381_HDN void miller_lines_precompute(int32_t* tab, const fp2& qx, const fp2& qy, bool q_inf = false) {
+C12381_HDN void miller_lines_precompute(int32_t* tab, const fp2& qx, const fp2& qy, bool q_inf = false, bool normalise = true) {
     g2p Q, T;
     miller3_q(Q, qx, qy, q_inf);
     T = Q;
@@ -827,10 +867,43 @@ C12381_HDN void miller_lines_precompute(int32_t* tab, const fp2& qx, const fp2& 
             fq_store_line(tab + (size_t)(k++) * FQ_LINE_DWORDS, n0, n1, n2);
         }
     }
+    // Normalised form: every line divided by its s-coefficient c1.  A factor in Fp2 of a line changes the Miller value by a
+    // factor in Fp2, and (p^12 - 1)/r is a multiple of p^2 - 1 (r divides p^4 - p^2 + 1), so the final exponentiation removes
+    // it: the GT value — the only thing the fixed-argument kernels output — is unchanged, and the line product needs four Fp2
+    // products per lane instead of five (f12t_mul_line1_core).  One simultaneous inversion over the 69 coefficients; a table
+    // with a vanishing c1 (G2 infinity: the addition lines are (0, 0, -px)) stays raw.
+    if (!normalise) { tab[FQ_FMT_WORD] = 0; return; }      // A/B switch (C12381_FQ_RAW)
+    fp2 pref[FQ_LINES];
+    fp2 run;
+    fp2_one(run);
+#pragma unroll 1
+    for (int j = 0; j < FQ_LINES; ++j) {
+        fp2 c0, c1, c2, nr;
+        fq_load_line(c0, c1, c2, tab + (size_t)j * FQ_LINE_DWORDS);
+        fp2_mul(nr, run, c1);
+        fp2_norm1(run, nr);
+        pref[j] = run;
+    }
+    if (fp2_is_zero(run)) { tab[FQ_FMT_WORD] = 0; return; }
+    fp2 inv;
+    fp2_inv(inv, run);
+#pragma unroll 1
+    for (int j = FQ_LINES - 1; j >= 0; --j) {
+        fp2 c0, c1, c2, ij, ni, a0, a2, n0, n2;
+        fq_load_line(c0, c1, c2, tab + (size_t)j * FQ_LINE_DWORDS);
+        if (j > 0) { fp2_mul(ij, inv, pref[j - 1]); } else { ij = inv; }
+        fp2_norm1(ij, ij);
+        fp2_mul(ni, inv, c1); fp2_norm1(inv, ni);
+        fp2_mul(a0, c0, ij); fp2_mul(a2, c2, ij);
+        fp2_norm1(n0, a0); fp2_norm1(n2, a2);
+        msm_store_pt(tab + (size_t)j * FQ_LINE_DWORDS, n0.a, n0.b);
+        msm_store_pt(tab + (size_t)j * FQ_LINE_DWORDS + 2 * NL, n2.a, n2.b);
+    }
+    tab[FQ_FMT_WORD] = 1;
 }
 // f *= line(tab[k]) evaluated at P = (px, py): role 0 forms l0 = c0 py, role 1 forms l2 = c2 px (role 2 repeats role 1), and
-// the triple shares the two products — one Fp2-by-Fp product per lane instead of two
-C12381_HDN void miller3_fixed_line(fp4& F, const int32_t* tab, int k, const fp& px, const fp& py, bool skip, const tri& t) {
+// the triple shares the two products — one Fp2-by-Fp product per lane instead of two.  Raw records (c0, c1, c2):
+C12381_HDN void miller3_fixed_line_raw(fp4& F, const int32_t* tab, int k, const fp& px, const fp& py, bool skip, const tri& t) {
     fp2 c0, c1, c2, l0, l2, one2, zero2, cs, prod;
     fp ps;
     fq_load_line(c0, c1, c2, tab + (size_t)k * FQ_LINE_DWORDS);
@@ -846,37 +919,74 @@ C12381_HDN void miller3_fixed_line(fp4& F, const int32_t* tab, int k, const fp& 
     f12t_mul_line_core(x, l0, c1, l2, t);
     slot_store(F, x);
 }
+// normalised records (c0/c1, c2/c1): the line is l0 + s + l2 (...).  A skipped pair (G1 argument at infinity) multiplies by s
+// alone (l0 = l2 = 0) instead of by 1: a factor in Fp4 is removed by the final exponentiation just like one in Fp2 ((p^12 - 1)/r
+// is a multiple of p^4 - 1), and f keeps going through the same reduction as every other lane's.
+C12381_HDN void miller3_fixed_line1(fp4& F, const int32_t* tab, int k, const fp& px, const fp& py, bool skip, const tri& t) {
+    fp2 c0, c2, l0, l2, cs, prod, zero2;
+    fp ps;
+    const int32_t* rec = tab + (size_t)k * FQ_LINE_DWORDS;
+    msm_load_pt(c0.a, c0.b, rec);
+    msm_load_pt(c2.a, c2.b, rec + 2 * NL);
+    fp2_select(cs, t.role == 0, c0, c2);
+    fp_select(ps, t.role == 0, py, px);
+    fp2_mul_fp(prod, cs, ps);
+    tri_fetch_fp2(l0, prod, 0, t);
+    tri_fetch_fp2(l2, prod, 1, t);
+    fp2_zero(zero2);
+    fp2_select(l0, skip, zero2, l0); fp2_select(l2, skip, zero2, l2);
+    fp4 x;
+    slot_load(x, F);
+    f12t_mul_line1_core(x, l0, l2, t);
+    slot_store(F, x);
+}
+C12381_HD void miller3_fixed_line(fp4& F, const int32_t* tab, bool norm, int k, const fp& px, const fp& py, bool skip, const tri& t) {
+#if defined(C12381_FQ_ONLY_NORM)                                      // experiment: no second path in the loop
+    (void)norm;
+    miller3_fixed_line1(F, tab, k, px, py, skip, t);
+#else
+    if (norm) miller3_fixed_line1(F, tab, k, px, py, skip, t);       // wave-uniform: a property of the table
+    else miller3_fixed_line_raw(F, tab, k, px, py, skip, t);
+#endif
+}
 // iterations hi .. lo of the loop of one pair whose G2 argument is fixed (table tab)
 C12381_HDN void miller3_range_fixed(fp4& F, const fp& px, const fp& py, bool skip, const int32_t* tab, int hi, int lo, const tri& t) {
     constexpr unsigned __int128 N1 = (unsigned __int128)BLS_X;
     constexpr unsigned __int128 N3 = N1 * 3;
     int k = 0;
+    const bool norm = tab[FQ_FMT_WORD] != 0;
 #pragma unroll 1
     for (int j = 64; j > hi; --j) k += 1 + ((((N3 >> j) & 1) != ((N1 >> j) & 1)) ? 1 : 0);
 #pragma unroll 1
     for (int i = hi; i >= lo; --i) {
         f12t_sqr_h(F, t);
-        miller3_fixed_line(F, tab, k++, px, py, skip, t);
-        if (((N3 >> i) & 1) != ((N1 >> i) & 1)) miller3_fixed_line(F, tab, k++, px, py, skip, t);
+        miller3_fixed_line(F, tab, norm, k++, px, py, skip, t);
+        if (((N3 >> i) & 1) != ((N1 >> i) & 1)) miller3_fixed_line(F, tab, norm, k++, px, py, skip, t);
     }
 }
 // iterations hi .. lo of the joint loop of two pairs whose G2 arguments are both fixed (tables tab1, tab2)
-C12381_HDN void miller3_range2_fixed(fp4& F, const fp& px1, const fp& py1, bool skip1, const int32_t* tab1,
-                                     const fp& px2, const fp& py2, bool skip2, const int32_t* tab2, int hi, int lo, const tri& t) {
+C12381_HDN void miller3_range2_fixed(fp4& F, const fp& px1_, const fp& py1_, bool skip1, const int32_t* tab1,
+                                     const fp& px2_, const fp& py2_, bool skip2, const int32_t* tab2, int hi, int lo, const tri& t_) {
     constexpr unsigned __int128 N1 = (unsigned __int128)BLS_X;
     constexpr unsigned __int128 N3 = N1 * 3;
     int k = 0;
+    tab1 = wave_uniform(tab1); tab2 = wave_uniform(tab2);
+    hi = wave_uniform(hi); lo = wave_uniform(lo);
+    const bool norm1 = wave_uniform((int)tab1[FQ_FMT_WORD]) != 0, norm2 = wave_uniform((int)tab2[FQ_FMT_WORD]) != 0;
+    const fp& px1 = *wave_uniform(&px1_); const fp& py1 = *wave_uniform(&py1_);
+    const fp& px2 = *wave_uniform(&px2_); const fp& py2 = *wave_uniform(&py2_);
+    const tri& t = *wave_uniform(&t_);
 #pragma unroll 1
     for (int j = 64; j > hi; --j) k += 1 + ((((N3 >> j) & 1) != ((N1 >> j) & 1)) ? 1 : 0);
 #pragma unroll 1
     for (int i = hi; i >= lo; --i) {
         f12t_sqr_h(F, t);
-        miller3_fixed_line(F, tab1, k, px1, py1, skip1, t);
-        miller3_fixed_line(F, tab2, k, px2, py2, skip2, t);
+        miller3_fixed_line(F, tab1, norm1, k, px1, py1, skip1, t);
+        miller3_fixed_line(F, tab2, norm2, k, px2, py2, skip2, t);
         ++k;
         if (((N3 >> i) & 1) != ((N1 >> i) & 1)) {           // wave-uniform: addition step of this iteration
-            miller3_fixed_line(F, tab1, k, px1, py1, skip1, t);
-            miller3_fixed_line(F, tab2, k, px2, py2, skip2, t);
+            miller3_fixed_line(F, tab1, norm1, k, px1, py1, skip1, t);
+            miller3_fixed_line(F, tab2, norm2, k, px2, py2, skip2, t);
             ++k;
         }
     }

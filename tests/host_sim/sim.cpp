@@ -610,7 +610,7 @@ int sim_g2_fixed_mul_batch(size_t n, const uint8_t* base192, const uint8_t* scal
 
 // e(a_i, W) * e(c_i, G) with the two G2 arguments fixed for the batch: coefficient tables + table-driven joint loop
 extern "C" int sim_pair2_fixed_batch(size_t n, const uint8_t* a96, const uint8_t* w192, const uint8_t* c96, const uint8_t* g192, uint8_t* gt576) {
-    std::vector<int32_t> t1v(FQ_LINES * FQ_LINE_DWORDS + 4), t2v(FQ_LINES * FQ_LINE_DWORDS + 4);
+    std::vector<int32_t> t1v(FQ_TABLE_DWORDS + 4), t2v(FQ_TABLE_DWORDS + 4);
     int32_t* t1 = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(t1v.data()) + 15) & ~(uintptr_t)15);
     int32_t* t2 = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(t2v.data()) + 15) & ~(uintptr_t)15);
     fp2 qx, qy;
