@@ -941,20 +941,19 @@ C12381_HDN void miller3_fixed_line1(fp4& F, const int32_t* tab, int k, const fp&
     slot_store(F, x);
 }
 C12381_HD void miller3_fixed_line(fp4& F, const int32_t* tab, bool norm, int k, const fp& px, const fp& py, bool skip, const tri& t) {
-#if defined(C12381_FQ_ONLY_NORM)                                      // experiment: no second path in the loop
-    (void)norm;
-    miller3_fixed_line1(F, tab, k, px, py, skip, t);
-#else
     if (norm) miller3_fixed_line1(F, tab, k, px, py, skip, t);       // wave-uniform: a property of the table
     else miller3_fixed_line_raw(F, tab, k, px, py, skip, t);
-#endif
 }
 // iterations hi .. lo of the loop of one pair whose G2 argument is fixed (table tab)
-C12381_HDN void miller3_range_fixed(fp4& F, const fp& px, const fp& py, bool skip, const int32_t* tab, int hi, int lo, const tri& t) {
+C12381_HDN void miller3_range_fixed(fp4& F, const fp& px_, const fp& py_, bool skip, const int32_t* tab, int hi, int lo, const tri& t_) {
     constexpr unsigned __int128 N1 = (unsigned __int128)BLS_X;
     constexpr unsigned __int128 N3 = N1 * 3;
     int k = 0;
-    const bool norm = tab[FQ_FMT_WORD] != 0;
+    tab = wave_uniform(tab);
+    hi = wave_uniform(hi); lo = wave_uniform(lo);
+    const bool norm = wave_uniform((int)tab[FQ_FMT_WORD]) != 0;
+    const fp& px = *wave_uniform(&px_); const fp& py = *wave_uniform(&py_);
+    const tri& t = *wave_uniform(&t_);
 #pragma unroll 1
     for (int j = 64; j > hi; --j) k += 1 + ((((N3 >> j) & 1) != ((N1 >> j) & 1)) ? 1 : 0);
 #pragma unroll 1
