@@ -1,6 +1,6 @@
 """GPU parity of the code paths that are selected through the environment (A/B switches kept for measurements):
 the one-lane pairing kernels, the forced naive / bucket MSM, the generic path behind the fixed-base entry points, the
-one-lane-per-point G2 kernel.
+one-lane-per-point G2 kernel, raw line tables of a fixed G2 argument, the queue split override.
 Each variant runs in a child process (the switches are read once per process) against the golden vectors."""
 import os
 import subprocess
@@ -24,6 +24,10 @@ g = golden('pairing')
 assert c.pair(cat(g['g1']), cat(g['g2'])) == cat(g['gt'])
 assert list(c.pair_eq(cat(g['eq_a1']), cat(g['eq_a2']), cat(g['eq_b1']), cat(g['eq_b2']))) == g['eq']
 assert list(c.pair_eq(cat(g['eq2_a1']), cat(g['eq2_a2']), cat(g['eq2_b1']), cat(g['eq2_b2']))) == g['eq2']
+g1s, g2s = cat(g['g1']), cat(g['g2'])
+for k in (0, 5, 7):                                          # table-driven Miller loop (normalised or raw line records) == generic pairing
+    q = g2s[192 * k:192 * k + 192]
+    assert c.pair_fixed_g2(g1s, q) == c.pair(g1s, q * (len(g1s) // 96))
 g = golden('g1')
 pts, sc = cat(g['points']), cat(g['scalars'])
 assert c.g1_msm(pts, sc, 49).hex() == g['msm49']
@@ -44,8 +48,10 @@ print('variant ok')
 
 
 @pytest.mark.parametrize("env", [{"C12381_PAIR_LANES": "1"}, {"C12381_MSM": "naive"}, {"C12381_MSM": "bucket"}, {"C12381_FIXED_BASE": "0"},
-                                 {"C12381_PAIR_QUEUE": "1"}, {"C12381_PAIR_QUEUE": "0"}, {"C12381_G2_LANES": "1"}, {}],
-                         ids=["one-lane-pairing", "msm-naive", "msm-bucket", "fixed-base-off", "pair-queue-on", "pair-queue-off", "g2-one-lane", "defaults"])
+                                 {"C12381_PAIR_QUEUE": "1"}, {"C12381_PAIR_QUEUE": "0"}, {"C12381_G2_LANES": "1"}, {"C12381_FQ_RAW": "1"},
+                                 {"C12381_PAIR_QUEUE": "1", "C12381_QUEUE_GROUPS": "1"}, {}],
+                         ids=["one-lane-pairing", "msm-naive", "msm-bucket", "fixed-base-off", "pair-queue-on", "pair-queue-off", "g2-one-lane", "raw-line-tables",
+                              "queue-groups-override", "defaults"])
 def test_environment_selected_paths(env):
     e = dict(os.environ)
     e.update(env)
