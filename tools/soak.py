@@ -44,6 +44,25 @@ for n in (43009, 50000, 65536, 65541, 100003, 131072, 262144):
     print("n=%7d ok  (%.1f s elapsed)" % (n, time.time() - t_start), flush=True)
 print("soak ok: %d queue-kernel launches" % launches)
 
+# the table-driven kernels (one G2 argument for the batch, normalised line tables): repeated launches at odd sizes, every output
+# equal to the generic pairing of the same inputs; then the same with the G2 argument at infinity (raw tables)
+for qfix, label in ((q[:192], "point"), (bytes(192), "infinity")):
+    dq1 = torch.frombuffer(bytearray(qfix), dtype=torch.uint8).to(dev)
+    for n in (43009, 65541, 131072):
+        rep = (n + base - 1) // base
+        dp = torch.frombuffer(bytearray((p * rep)[:96 * n]), dtype=torch.uint8).to(dev)
+        dqn = dq1.repeat(n)
+        ref = torch.empty(576 * n, dtype=torch.uint8, device=dev)
+        out = torch.empty(576 * n, dtype=torch.uint8, device=dev)
+        c.pair_dev(n, dp.data_ptr(), dqn.data_ptr(), ref.data_ptr()); c.sync()
+        for it in range(6):
+            c.pair_fixed_g2_dev(n, dp.data_ptr(), dq1.data_ptr(), out.data_ptr())
+            assert c.sync() == 0
+            assert torch.equal(out, ref), (label, n, it)
+            launches += 1
+        print("fixed G2 %-8s n=%7d ok  (%.1f s elapsed)" % (label, n, time.time() - t_start), flush=True)
+print("soak ok incl. table-driven kernels: %d launches" % launches)
+
 # two contexts driving the same GPU at once: each queue grid is only partly resident, tasks still only ever wait for
 # tasks already claimed by resident wavefronts
 import threading  # noqa: E402
