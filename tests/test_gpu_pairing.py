@@ -91,6 +91,32 @@ def test_pairing_full_size_2_16(ctx, oracle_port):
     assert b"".join(gt[576 * i:576 * i + 576] for i in idx) == exp
 
 
+def test_pairing_of_curve_points_outside_the_subgroups(ctx, oracle_port):
+    """from_bytes checks the curve equation only (ecp_BLS12381.cpp:495-545, ecp2_BLS12381.cpp:225-266), and PAIR_ate / PAIR_fexp run on
+    whatever they are given: Miller values and pairings of random curve points (decoded from random x, almost never in G1 / G2)
+    have to be the reference's — this is where a formula that is only right on the subgroup would show (addition steps, lines)."""
+    m = 96
+    c1 = b"".join(bytes([2 + (i & 1)]) + (prng(451, i, 48) % (1 << 381)).to_bytes(48, "big") for i in range(4 * m))
+    c2 = b"".join(bytes([2 + (i & 1)]) + (prng(452, i, 48) % (1 << 381)).to_bytes(48, "big") + (prng(453, i, 48) % (1 << 381)).to_bytes(48, "big")
+                  for i in range(4 * m))
+    p1, s1 = ctx.g1_decompress(c1)
+    p2, s2 = ctx.g2_decompress(c2)
+    P = b"".join(p1[96 * i:96 * i + 96] for i in range(4 * m) if s1[i] == 1)[:96 * m]
+    Q = b"".join(p2[192 * i:192 * i + 192] for i in range(4 * m) if s2[i] == 1)[:192 * m]
+    n = min(len(P) // 96, len(Q) // 192)
+    assert n >= 64
+    P, Q = P[:96 * n], Q[:192 * n]
+    assert ctx.miller(P, Q) == oracle_port.miller(P, Q)
+    gt = ctx.pair(P, Q)
+    assert gt == oracle_port.pair(P, Q, 16)
+    # the table-driven kernels (normalised lines) and the product kernel on the same points
+    for k in (0, 1):
+        q = Q[192 * k:192 * k + 192]
+        assert ctx.pair_fixed_g2(P, q) == oracle_port.pair(P, q * n, 16)
+    prod = ctx.pair_product(P + P[96:] + P[:96], Q + Q, 2)
+    assert prod == ctx.gt_op("mul", gt, oracle_port.pair(P[96:] + P[:96], Q, 16))
+
+
 def test_decompress_golden(ctx):
     g = golden("g1")
     out, st = ctx.g1_decompress(cat(g["compressed"]))
