@@ -9,8 +9,9 @@ kernel + inversion/encode kernel) over one batch whose inputs are already reside
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line.  Besides the headline it carries one object per remaining BASELINE config, each with its
-own timing, parity against the CPU oracle, `valu_roofline` and (N = 1) `cpu_baseline`:
+own timing, parity against the CPU oracle, `roofline` / `hbm_roofline` and (N = 1) `cpu_baseline`:
     pairing   configs[2]  2^16 ate pairings (the WHOLE batch is compared with the oracle at N = 1)
+    g2_mul / miller / fexp   the G2 scalar multiplication, the Miller loop and the final exponentiation alone
     msm       configs[3]  one product of 2^22 terms
     bbs_plus  configs[4]  2^18 BBS+ verifications (real signatures, a known set of corrupted lanes)
 and `cpu_baselines` for G2 multiplication, Miller loop and final exponentiation alone.
@@ -19,9 +20,12 @@ two STRONG-scaled legs exercise what BASELINE describes for configs 4 and 5:
     msm_sharded       one 2^22-term product, terms split N ways, device-resident partial points (96 B) exchanged by ONE
                       all_gather on the process group's backend (nccl = RCCL over xGMI), local N-term sum on every rank
     bbs_plus_sharded  the 2^18 signatures split N ways, no collective on the data path
-`roofline` follows the contract (bound hbm: algorithmic bytes / kernel time against 8 TB/s); this path is integer-VALU
-bound, so every leg also carries `valu_roofline`: algorithmic 32x32 multiply-adds / kernel time against
-the v_mad_u64_u32 issue rate measured on MI355X (csrc/microbench/valu_rates.hip, profiles/r01_valu_rates.txt).
+`roofline` is the BINDING bound of this path — integer VALU: algorithmic 32x32 multiply-adds / dominant-kernel
+time against `peak` = the multiply-add issue rate measured on MI355X (csrc/microbench/valu_rates.hip, profiles/r03_valu_rates.txt),
+with `peak_theoretical` = 256 CUs x 4 SIMDs x 16 lanes/clock x 2.4 GHz beside it; `traffic` = HBM bytes per launch from the
+FETCH_SIZE / WRITE_SIZE counter passes (profiles/traffic.json).  `hbm_roofline` is the HBM view of the same kernel (algorithmic
+bytes / kernel time against 8 TB/s): evidence that the path is not memory bound.  Legs `g2_mul`, `miller`, `fexp` time the three
+remaining hot-path functions (PAIR_G2mul, PAIR_ate, PAIR_fexp) alone, each against the compiled reference on a sample.
 Only the parity / cpu_baseline legs touch oracle/ (the compiled reference when oracle/_ref is present, else our C port).
 """
 from __future__ import annotations
@@ -60,12 +64,20 @@ MAC32_PAIRING = 4_275_240
 MAC32_MSM_TERM = 16 * (11 * 144 + 8 * 156)
 # one verification as the reference evaluates it (bbs+.cpp:57-73): 1 G2 mul + 2 G1 muls + 2 Miller loops + 1 final exponentiation
 MAC32_BBS_VERIFY = MAC32_G2_MUL + 2 * MAC32_G1_MUL + 2 * MAC32_MILLER + MAC32_FEXP
+# the pipeline as built, counted in the host simulation (tools/count_ops.py, profiles/r03_op_counts.json): one generic G1 multiplication (x A),
+# two table-driven ones (r h0, m h1), four point additions, the product of two pairings against FIXED G2 arguments, 144 / 156 MAC32 per
+# product / reduction like every other figure here
+MAC32_BBS_PIPELINE = 5_427_672
 BYTES_G1_MUL = 224               # 96 in + 32 scalar + 96 out
 BYTES_PAIRING = 864              # 96 + 192 in, 576 out
 BYTES_MSM_TERM = 128             # 96 + 32
 BYTES_BBS_VERIFY = 96 + 32 + 32 + 32 + 1
 HBM_PEAK_GBS = 8000.0
-VALU_PEAK_MAC32 = 3.10e13        # measured v_mad_u64_u32 lane-ops/s, profiles/r01_valu_rates.txt
+VALU_PEAK_MAC32 = 3.10e13        # measured multiply-add lane-ops/s (v_mad_u64_u32 r01; v_mad_i64_i32 rows: profiles/r03_valu_rates.txt)
+# documented ceiling: a wave64 64-bit multiply-add occupies its SIMD for 4 cycles = 16 lanes per clock and SIMD,
+# 256 CUs x 4 SIMDs, 2.4 GHz maximum clock (MI355X_MICROARCH.md)
+VALU_PEAK_THEORETICAL_MAC32 = 256 * 4 * 16 * 2.4e9
+BYTES_G2_MUL = 416               # 192 in + 32 scalar + 192 out
 
 
 def make_scalars(seed: int, n: int, edges: bool = True) -> np.ndarray:
@@ -106,6 +118,8 @@ def main():
     ap.add_argument("--log2-batch", type=int, default=20)
     ap.add_argument("--log2-pairings", type=int, default=16)
     ap.add_argument("--pairings", type=int, default=0, help="exact pairing batch size (overrides --log2-pairings; experiments only)")
+    ap.add_argument("--log2-g2", type=int, default=18, help="batch of the G2 scalar-multiplication leg")
+    ap.add_argument("--no-split", action="store_true", help="skip the g2_mul / miller / fexp legs")
     ap.add_argument("--log2-msm", type=int, default=22)
     ap.add_argument("--log2-bbs", type=int, default=18)
     ap.add_argument("--no-pairing", action="store_true", help="skip the pairings/s leg")
@@ -219,6 +233,37 @@ def main():
         pair = {"npair": npair, "steps": max(1, args.steps), "elapsed": pel, "kernel_ms": pk_ms, "launches": pk_launches,
                 "p1": p1, "q2": q2, "gt": gt}
 
+    # ================================================================== the remaining hot-path functions alone: G2 mul, Miller loop, final exponentiation
+    split = None
+    if pair is not None and not args.no_split:
+        npair = pair["npair"]
+        ng2 = 1 << args.log2_g2
+        ssteps = min(max(1, args.steps), 5)
+        g2_sc_h = make_scalars(3500 + rank, ng2)
+        g2_sc = torch.from_numpy(g2_sc_h).to(dev)
+        reps2 = (ng2 + npair - 1) // npair
+        g2_in = pair["q2"].repeat(reps2)[: ng2 * 192].contiguous() if reps2 > 1 else pair["q2"][: ng2 * 192]
+        g2_out = torch.empty(ng2 * 192, dtype=torch.uint8, device=dev)
+        mil = torch.empty(npair * 576, dtype=torch.uint8, device=dev)
+        fex = torch.empty(npair * 576, dtype=torch.uint8, device=dev)
+        ctx.g2_mul_dev(ng2, g2_in.data_ptr(), g2_sc.data_ptr(), g2_out.data_ptr(), 192)
+        ctx.miller_dev(npair, pair["p1"].data_ptr(), pair["q2"].data_ptr(), mil.data_ptr())
+        ctx.gt_op_dev("fexp", npair, mil.data_ptr(), None, fex.data_ptr())
+        torch.cuda.synchronize(dev)
+        ctx.profile(True)
+        g2_el = timed(lambda: ctx.g2_mul_dev(ng2, g2_in.data_ptr(), g2_sc.data_ptr(), g2_out.data_ptr(), 192), ssteps, 0)
+        mil_el = timed(lambda: ctx.miller_dev(npair, pair["p1"].data_ptr(), pair["q2"].data_ptr(), mil.data_ptr()), ssteps, 0)
+        fex_el = timed(lambda: ctx.gt_op_dev("fexp", npair, mil.data_ptr(), None, fex.data_ptr()), ssteps, 0)
+        g2k_ms, g2k_launches = ctx.profile_read(2)
+        milk_ms, milk_launches = ctx.profile_read(6)
+        fexk_ms, fexk_launches = ctx.profile_read(7)
+        ctx.profile(False)
+        if ctx.sync() != 0:
+            raise SystemExit("bench: invalid input reported by the split kernels")
+        split = {"ng2": ng2, "steps": ssteps, "g2_el": g2_el, "mil_el": mil_el, "fex_el": fex_el, "g2k": (g2k_ms, g2k_launches),
+                 "milk": (milk_ms, milk_launches), "fexk": (fexk_ms, fexk_launches), "g2_in": g2_in, "g2_sc_h": g2_sc_h, "g2_out": g2_out,
+                 "mil": mil, "fex": fex}
+
     # ================================================================== configs[3]: MSM, n = 2^22 per GPU (weak) and sharded (strong)
     msm = None
     if not args.no_msm:
@@ -315,13 +360,18 @@ def main():
             ctx.bbs_plus_verify_dev(count, 1, dpub[0].data_ptr(), dpub[1].data_ptr(), dpub[2].data_ptr(), dpub[3].data_ptr(), dpub[4].data_ptr(),
                                     A.data_ptr(), x.data_ptr(), r.data_ptr(), m.data_ptr(), ok.data_ptr())
         bsteps = min(max(1, args.steps), 5)
-        bel = timed(bbs_step, bsteps, 1)
+        bbs_step()
+        torch.cuda.synchronize(dev)
+        ctx.profile(True)
+        bel = timed(bbs_step, bsteps, 0)
+        bpk_ms, bpk_launches = ctx.profile_read(4)
+        ctx.profile(False)
         ctx.sync()
         ok_h = okb.cpu().numpy()
         exp_ok = np.ones(nb, dtype=np.uint8); exp_ok[bad_lanes] = 0
         if not (ok_h == exp_ok).all():
             raise SystemExit("bench: BBS+ verdicts differ from the construction (valid signatures / corrupted lanes) — number withheld")
-        bbs = {"n": nb, "steps": bsteps, "elapsed": bel, "A": A_h, "x": xs_h, "r": rs_h, "m": mm_h, "ok": ok_h,
+        bbs = {"n": nb, "steps": bsteps, "elapsed": bel, "pair_ms": bpk_ms, "pair_launches": bpk_launches, "A": A_h, "x": xs_h, "r": rs_h, "m": mm_h, "ok": ok_h,
                "pub": (pub_g1, g2p, pub_h0, pub_h, w)}
         if world > 1:
             gA, gx, gr, gm, gbad = make_sigs(5200, nb) if rank != 0 else (A_h, xs_h, rs_h, mm_h, bad_lanes)
@@ -385,7 +435,7 @@ def main():
         launches_per_step = mul_launches / max(args.steps, 1)
         units_per_launch = n / max(launches_per_step, 1)
         avg_launch_s = (mul_ms / max(mul_launches, 1)) * 1e-3
-        traffic = pair_traffic = None
+        traffic = pair_traffic = msm_traffic = bbs_traffic = None
         tr_path = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tr_path):
             try:
@@ -394,7 +444,7 @@ def main():
                 if pair is not None:
                     pair_traffic = tj["pair_kernel"]["hbm_bytes_per_launch"] * pair["npair"] / tj["pair_kernel"]["units_per_launch"]
             except Exception:
-                traffic = pair_traffic = None
+                traffic = pair_traffic = msm_traffic = bbs_traffic = None
 
         def hbm(bytes_per_unit, units, secs, kernel, tr=None, **more):
             a = bytes_per_unit * units / secs / 1e9
@@ -403,10 +453,14 @@ def main():
             d.update(more)
             return d
 
-        def valu(mac_per_unit, units, secs, **more):
+        def valu(mac_per_unit, units, secs, kernel=None, tr=None, **more):
+            """the binding roofline: algorithmic multiply-adds per launch / average launch time against the measured multiply-add rate"""
             a = mac_per_unit * units / secs
-            d = {"bound": "int-valu", "achieved": a / 1e9, "peak": VALU_PEAK_MAC32 / 1e9, "unit": "GMAC32/s", "frac": a / VALU_PEAK_MAC32,
-                 "algorithmic_mac32_per_unit": mac_per_unit}
+            d = {"bound": "int-valu", "achieved": a / 1e9, "peak": VALU_PEAK_MAC32 / 1e9, "peak_theoretical": VALU_PEAK_THEORETICAL_MAC32 / 1e9,
+                 "unit": "GMAC32/s", "frac": a / VALU_PEAK_MAC32, "frac_of_theoretical": a / VALU_PEAK_THEORETICAL_MAC32, "traffic": tr,
+                 "algorithmic_mac32_per_unit": mac_per_unit, "avg_launch_ms": secs * 1e3}
+            if kernel:
+                d["kernel"] = kernel
             d.update(more)
             return d
         result = {
@@ -416,11 +470,11 @@ def main():
             "vs_baseline": None, "dtype": "int64 accumulate over 14x28-bit signed limbs", "data": "synthetic",
             "config": {"workload": "configs[1]: batch of 2^%d random G1 scalar-muls (96-B affine in, 32-B scalar, 96-B affine out) per GPU"
                                    % args.log2_batch, "batch_per_gpu": n, "parallelism": "independent shards x%d" % world},
-            "roofline": hbm(BYTES_G1_MUL, units_per_launch, avg_launch_s, "g1_mul_kernel", traffic, launches=int(mul_launches),
-                            units_per_launch=units_per_launch, note="integer-VALU-bound path: see valu_roofline for the binding resource"),
-            "valu_roofline": valu(MAC32_G1_MUL, units_per_launch, avg_launch_s, finish_kernel_ms_per_step=fin_ms / max(args.steps, 1)),
+            "roofline": valu(MAC32_G1_MUL, units_per_launch, avg_launch_s, "g1_mul_kernel", traffic, launches=int(mul_launches),
+                             units_per_launch=units_per_launch, finish_kernel_ms_per_step=fin_ms / max(args.steps, 1)),
+            "hbm_roofline": hbm(BYTES_G1_MUL, units_per_launch, avg_launch_s, "g1_mul_kernel", traffic,
+                                note="not the binding bound: the path is integer-VALU bound (roofline)"),
         }
-        cpu_extra = {}
         if do_cpu:
             sample = min(n, 1 << 16)
             sp, ss = pts_h[:sample].tobytes(), sc_h[:sample].tobytes()
@@ -463,35 +517,62 @@ def main():
                     raise SystemExit("bench: GPU pairing results differ from the CPU oracle — number withheld")
                 checked, ps = len(pidx), len(pidx)
             avg_s = pair["kernel_ms"] / max(pair["launches"], 1) * 1e-3
-            kname = ("pair_kernel" if os.environ.get("C12381_PAIR_LANES", "3") == "1" else
-                     ("pair3_queue_kernel" if (npair + 20) // 21 > 2048 and os.environ.get("C12381_PAIR_QUEUE", "") != "0" else "pair3_kernel"))
+            kname = "pair3_queue_kernel" if (npair + 20) // 21 > 2048 else "pair3_kernel"
             result["pairing"] = {
                 "metric": "ate pairings/s per MI355X (batch 2^%d per GPU), bit-exact vs CPU" % args.log2_pairings,
                 "value": world * npair * pair["steps"] / pair["elapsed"], "unit": "pairings/s", "steps": pair["steps"],
                 "ms_per_step": pair["elapsed"] / pair["steps"] * 1e3,
                 "config": {"workload": "configs[2]: 2^%d pairings e(P_i, Q_i) -> 576-B GT each, per GPU" % args.log2_pairings},
                 "parity": {"checked_lanes": checked, "of": npair, "oracle": kind, "bit_exact": True},
-                "roofline": hbm(BYTES_PAIRING, npair, avg_s, kname, pair_traffic),
-                "valu_roofline": valu(MAC32_PAIRING, npair, avg_s),
+                "roofline": valu(MAC32_PAIRING, npair, avg_s, kname, pair_traffic),
+                "hbm_roofline": hbm(BYTES_PAIRING, npair, avg_s, kname, pair_traffic),
             }
             if do_cpu:
                 result["pairing"]["cpu_baseline"] = {"value": ps / cpu_ps, "unit": "pairings/s", "cores": cores, "kind": kind,
                                                      "sample": ("the whole batch of %d pairings, %d threads; every lane bit-exact vs GPU" % (ps, cores)) if full
                                                      else "%d sampled lanes" % ps}
-                # G2 multiplication, Miller loop and final exponentiation alone, same box, same threads
-                ns = min(npair, 1 << 12)
-                t4 = time.perf_counter(); q_cpu = orc.g2_mul(q2_h[:ns].tobytes(), sc_h[:ns].tobytes(), 192, cores); g2_s = time.perf_counter() - t4
-                q_gpu = ctx.g2_mul(q2_h[:ns].tobytes(), sc_h[:ns].tobytes(), 192)
-                t5 = time.perf_counter(); m_cpu = orc.miller_t(p1_h[:ns].tobytes(), q2_h[:ns].tobytes(), cores); mil_s = time.perf_counter() - t5
-                t6 = time.perf_counter(); f_cpu = orc.fexp_t(m_cpu, cores); fx_s = time.perf_counter() - t6
-                if q_cpu != q_gpu or f_cpu != gt_h[:ns].tobytes() or ctx.miller(p1_h[:64].tobytes(), q2_h[:64].tobytes()) != m_cpu[:576 * 64]:
-                    raise SystemExit("bench: split CPU baselines differ from the GPU outputs")
-                cpu_extra = {"g2_mul": {"value": ns / g2_s, "unit": "scalar-muls/s", "cores": cores, "kind": kind, "sample": "%d lanes; bit-exact vs GPU" % ns,
-                                        "algorithmic_mac32_per_unit": MAC32_G2_MUL},
-                             "miller_loop": {"value": ns / mil_s, "unit": "Miller loops/s", "cores": cores, "kind": kind,
-                                             "sample": "%d lanes; first 64 Miller values bit-exact vs c12381_miller_batch" % ns, "algorithmic_mac32_per_unit": MAC32_MILLER},
-                             "final_exponentiation": {"value": ns / fx_s, "unit": "final exponentiations/s", "cores": cores, "kind": kind,
-                                                      "sample": "%d lanes; results equal the GPU pairing outputs" % ns, "algorithmic_mac32_per_unit": MAC32_FEXP}}
+
+        # ---------------------------------------------------------------- G2 multiplication, Miller loop, final exponentiation alone
+        if split is not None:
+            npair, ng2, st = pair["npair"], split["ng2"], split["steps"]
+            ns = min(npair, 1 << 12)
+            g2o_h = split["g2_out"].cpu().numpy().reshape(ng2, 192)
+            g2i_h = split["g2_in"].cpu().numpy().reshape(ng2, 192)
+            mil_h = split["mil"].cpu().numpy().reshape(npair, 576)
+            fex_h = split["fex"].cpu().numpy().reshape(npair, 576)
+            # lanes 0..4 carry the edge scalars 0, 1, r - 1, r, 2^256 - 1
+            t4 = time.perf_counter(); q_cpu = orc.g2_mul(g2i_h[:ns].tobytes(), split["g2_sc_h"][:ns].tobytes(), 192, cores); g2_s = time.perf_counter() - t4
+            t5 = time.perf_counter(); m_cpu = orc.miller_t(p1_h[:ns].tobytes(), q2_h[:ns].tobytes(), cores); mil_s = time.perf_counter() - t5
+            t6 = time.perf_counter(); f_cpu = orc.fexp_t(m_cpu, cores); fx_s = time.perf_counter() - t6
+            if q_cpu != g2o_h[:ns].tobytes():
+                raise SystemExit("bench: GPU G2 multiplications differ from the CPU oracle — number withheld")
+            if m_cpu != mil_h[:ns].tobytes():
+                raise SystemExit("bench: GPU Miller values differ from the CPU oracle — number withheld")
+            if f_cpu != fex_h[:ns].tobytes() or not (fex_h == gt_h).all():
+                raise SystemExit("bench: GPU final exponentiations differ from the CPU oracle / the pairing outputs — number withheld")
+
+            def leg(metric, unit, units, el, kprof, mac, nbytes, kernel, workload, parity, cpu_s):
+                k_s = kprof[0] / max(kprof[1], 1) * 1e-3
+                launches_per_step = kprof[1] / max(st, 1)
+                d = {"metric": metric, "value": world * units * st / el, "unit": unit, "steps": st, "ms_per_step": el / st * 1e3,
+                     "config": {"workload": workload}, "parity": parity,
+                     "roofline": valu(mac, units / max(launches_per_step, 1), k_s, kernel, None, launches_per_step=launches_per_step),
+                     "hbm_roofline": hbm(nbytes, units / max(launches_per_step, 1), k_s, kernel)}
+                if do_cpu:
+                    d["cpu_baseline"] = {"value": ns / cpu_s, "unit": unit, "cores": cores, "kind": kind, "sample": "first %d lanes of the same batch, %d threads" % (ns, cores)}
+                return d
+            result["g2_mul"] = leg("G2 scalar-muls/s per MI355X (batch 2^%d per GPU), bit-exact vs CPU" % args.log2_g2, "scalar-muls/s", ng2, split["g2_el"],
+                                   split["g2k"], MAC32_G2_MUL, BYTES_G2_MUL, "g2_mul2_kernel",
+                                   "PAIR_G2mul: 2^%d random (point, scalar) pairs, 192-B affine in / out, 32-B scalars (edge scalars in lanes 0..4)" % args.log2_g2,
+                                   {"checked_lanes": ns, "of": ng2, "oracle": kind, "bit_exact": True}, g2_s)
+            result["miller"] = leg("Miller loops/s per MI355X (batch 2^%d per GPU), the reference's field element" % args.log2_pairings, "Miller loops/s", npair,
+                                   split["mil_el"], split["milk"], MAC32_MILLER, 96 + 192 + 576, "miller3_kernel",
+                                   "PAIR_ate: the 2^%d (P_i, Q_i) of the pairing leg -> 576-B Miller value each" % args.log2_pairings,
+                                   {"checked_lanes": ns, "of": npair, "oracle": kind, "bit_exact": True}, mil_s)
+            result["fexp"] = leg("final exponentiations/s per MI355X (batch 2^%d per GPU)" % args.log2_pairings, "final exponentiations/s", npair,
+                                 split["fex_el"], split["fexk"], MAC32_FEXP, 2 * 576, "gt3_op_kernel",
+                                 "PAIR_fexp: the 2^%d Miller values above -> canonical GT" % args.log2_pairings,
+                                 {"checked_lanes": npair, "of": npair, "oracle": "%s on %d lanes + every lane equal to the pairing leg's output" % (kind, ns), "bit_exact": True}, fx_s)
 
         # ---------------------------------------------------------------- MSM
         if msm is not None:
@@ -509,9 +590,11 @@ def main():
                 "value": world * nm / per, "unit": "terms/s", "steps": msm["steps"], "ms_per_step": per * 1e3,
                 "config": {"workload": "configs[3]: Π g_i^{x_i}, n = 2^%d (96-B affine points, 32-B scalars -> one 96-B point), per GPU" % args.log2_msm},
                 "parity": {"check": "result == G^(sum s_i k_i mod r) by one oracle multiplication over ALL 2^%d terms" % args.log2_msm, "oracle": kind, "bit_exact": True},
-                "roofline": hbm(BYTES_MSM_TERM, nm, bk_s, "msm_bucket_kernel"),
-                "valu_roofline": valu(MAC32_MSM_TERM, nm, bk_s, note="actual count of the bucket method as built: 16 mixed additions per term; "
-                                      "whole product incl. sort/reductions: %.2f ms" % (per * 1e3)),
+                # dominant kernel alone, then the whole product (sorts, preparation, reductions included) against the same peak
+                "roofline": valu(MAC32_MSM_TERM, nm, bk_s, "msm_bucket_kernel", msm_traffic,
+                                 note="actual count of the bucket method as built: 16 mixed additions (11 products + 8 reductions) per term"),
+                "roofline_whole_step": valu(MAC32_MSM_TERM, nm, per, "c12381_g1_msm_dev: prep + sorts + buckets + reductions + Horner + affine"),
+                "hbm_roofline": hbm(BYTES_MSM_TERM, nm, bk_s, "msm_bucket_kernel", msm_traffic),
             }
             if do_cpu:
                 sm = 1 << 14
@@ -542,9 +625,15 @@ def main():
                 "value": world * nb / per, "unit": "verifications/s", "steps": bbs["steps"], "ms_per_step": per * 1e3,
                 "config": {"workload": "configs[4]: 2^%d verifications e(A, w g2^x) == e(g1 h0^r h1^m, g2), real signatures, every 1009th message corrupted" % args.log2_bbs},
                 "parity": {"check": "all %d verdicts equal the construction (valid / corrupted lanes)" % nb, "bit_exact": True},
-                "roofline": hbm(BYTES_BBS_VERIFY, nb, per, "whole pipeline (c12381_bbs_plus_verify_batch_dev)"),
-                "valu_roofline": valu(MAC32_BBS_VERIFY, nb, per, note="effective: the reference's operation sequence per verification over the pipeline's wall time "
-                                      "(the pipeline itself uses fixed-base tables and fixed-G2 lines)"),
+                # the pipeline's OWN operation sequence (x A generic, r h0 and m h1 from tables, two-table product of pairings, one final
+                # exponentiation: tools/count_ops.py -> profiles/r03_op_counts.json) over the wall time of the whole pipeline
+                "roofline": valu(MAC32_BBS_PIPELINE, nb, per, "whole pipeline (c12381_bbs_plus_verify_batch_dev); dominant kernel pair3_prod_fixed_queue_kernel",
+                                 bbs_traffic, pair_kernel_avg_ms=bbs["pair_ms"] / max(bbs["pair_launches"], 1)),
+                "hbm_roofline": hbm(BYTES_BBS_VERIFY, nb, per, "whole pipeline", bbs_traffic),
+                "reference_sequence_equivalent": {"mac32_per_unit": MAC32_BBS_VERIFY, "gmac32_per_s": MAC32_BBS_VERIFY * nb / per / 1e9,
+                                                  "note": "NOT a utilisation figure: the reference's operation sequence (bbs+.cpp:57-73: generic G2 mul, two generic "
+                                                          "G1 muls, two Miller loops with running G2 points, one final exponentiation) per verification over this "
+                                                          "pipeline's wall time"},
             }
             if do_cpu:
                 sb = 1 << 11
@@ -569,8 +658,6 @@ def main():
                                               "value": nb * sh["steps"] / sh["elapsed"], "unit": "verifications/s", "scaling": "strong", "steps": sh["steps"],
                                               "ms_per_step": sh["elapsed"] / sh["steps"] * 1e3, "accepted": sh["accepted"],
                                               "exchange": "none on the data path (independent units)"}
-        if cpu_extra:
-            result["cpu_baselines"] = cpu_extra
         if extras:
             result["extra_configs"] = extras
         print(json.dumps(result), flush=True)

@@ -1,8 +1,14 @@
-"""Build the HIP shared library in-tree (crypto12381_amd/lib/libc12381_hip.so) for gfx950.
+"""Build the HIP shared libraries in-tree for gfx950.
 
-One hipcc compile per translation unit (csrc/*.hip, in parallel), then one link.  Objects are cached under lib/obj/ and
-reused only when (a) no source or header is newer and (b) the stamp next to the object — a hash of the exact command
-line and of `hipcc --version` — matches: an object built with other flags or another compiler is never linked in."""
+    crypto12381_amd/lib/libc12381_hip.so       the product: one code path, reads no environment variable
+    crypto12381_amd/lib/libc12381_hip_exp.so   the same sources with -DC12381_EXPERIMENTS: tuning / diagnostic switches (C12381_*
+                                               environment variables) and the superseded one-lane pairing kernels, for tools/, A/B
+                                               runs and tests/test_gpu_variants.py (selected with C12381_LIB in the Python binding)
+
+One hipcc compile per translation unit (csrc/*.hip, in parallel), then one link per library; the experiments library shares every
+object whose source does not look at the define.  Objects are cached under lib/obj/ and reused only when (a) no source or header is
+newer and (b) the stamp next to the object — a hash of the exact command line, of the compiler-affecting environment and of
+`hipcc --version` — matches: an object built with other flags or another compiler is never linked in."""
 from __future__ import annotations
 
 import hashlib
@@ -13,13 +19,14 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 UNITS = ["c12381_hip.hip", "k_g1.hip", "k_g2gt.hip", "k_g2h.hip", "k_pair3.hip", "k_hash_zp.hip", "k_fixed.hip"]
+EXP_UNITS = ["c12381_hip.hip", "k_g2gt.hip"]                # the units that test C12381_EXPERIMENTS
 LIB = os.path.join(HERE, "lib", "libc12381_hip.so")
+LIB_EXP = os.path.join(HERE, "lib", "libc12381_hip_exp.so")
 OBJ = os.path.join(HERE, "lib", "obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-optimize-sibling-calls: LLVM drops the "callee saves nothing" treatment of an internal function as soon as one
 # call site carries a `tail` marker (which every call passing only non-stack pointers gets); without the marker the
 # big out-of-line field routines do not save ~65 callee-saved VGPRs in their prologues (130 scratch instructions a call)
-# -fno-optimize-sibling-calls: a `tail` call marker costs an internal routine its "callee saves nothing" treatment.
 # max-ilp scheduling: every kernel here runs at a FIXED occupancy (launch bounds: 2 waves per SIMD), so the default strategy's
 # effort to raise occupancy buys nothing, while scheduling for ILP shortens the dependent multiply-add chains (A/B on MI355X,
 # tools/ab_all.sh: pairing kernel 22.8 -> 22.1 ms).  NOT combined with -amdgpu-use-amdgpu-trackers=1: that (experimental)
@@ -29,9 +36,11 @@ CFLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-fno-optimize-
           "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 # Round 2 reproduced the wrong-values event with a rebuilt variant: whole wavefront groups wrong, plain grid as
 # well as queue, only with -amdgpu-use-amdgpu-trackers=1; the same source without it is exact on every lane.  The option is
-# refused outright, and the compiler the full-batch parity tests were run with is recorded: another one prints a notice
+# refused outright — in CFLAGS and in every environment variable through which hipcc / clang accept extra flags — and the
+# compiler the full-batch parity tests were run with is recorded: another one prints a notice
 # (run tests/test_gpu_full_batch.py before trusting a build from it).
 FORBIDDEN_FLAGS = ("amdgpu-use-amdgpu-trackers",)
+FLAG_ENV = ("HIPCC_COMPILE_FLAGS_APPEND", "HIPCC_LINK_FLAGS_APPEND", "HIP_CLANG_FLAGS", "CCC_OVERRIDE_OPTIONS", "HIPCC")
 VALIDATED_COMPILER = "AMD clang version 22.0.0git"          # ROCm 7.2.0
 
 
@@ -50,36 +59,69 @@ def _stale(target: str, deps) -> bool:
 _HIPCC_VERSION = None
 
 
-def _stamp(unit: str) -> str:
-    """hash of everything besides the sources that decides what the object contains"""
+def _flag_env() -> str:
+    return "\0".join("%s=%s" % (k, os.environ.get(k, "")) for k in FLAG_ENV)
+
+
+def _check_flags() -> None:
+    seen = " ".join(CFLAGS) + " " + " ".join(os.environ.get(k, "") for k in FLAG_ENV)
+    for bad in FORBIDDEN_FLAGS:
+        if bad in seen:
+            raise RuntimeError("build flag known to produce wrong pairings at full size: %s (DESIGN.md 5b) — found in CFLAGS or in one of %s"
+                               % (bad, ", ".join(FLAG_ENV)))
+
+
+def _hipcc_version():
+    """`hipcc --version`, or None when there is no compiler on this machine (a GPU box that received the prebuilt library)"""
     global _HIPCC_VERSION
-    if any(bad in f for f in CFLAGS for bad in FORBIDDEN_FLAGS):
-        raise RuntimeError("build flag known to produce wrong pairings at full size: %s (DESIGN.md 5b)" % ", ".join(FORBIDDEN_FLAGS))
     if _HIPCC_VERSION is None:
-        _HIPCC_VERSION = subprocess.run([HIPCC, "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
-        if VALIDATED_COMPILER not in _HIPCC_VERSION:
+        try:
+            _HIPCC_VERSION = subprocess.run([HIPCC, "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
+        except OSError:
+            _HIPCC_VERSION = ""
+        if _HIPCC_VERSION and VALIDATED_COMPILER not in _HIPCC_VERSION:
             print("crypto12381_amd.build: compiler differs from the validated one (%s): run the full-batch parity tests" % VALIDATED_COMPILER, flush=True)
-    return hashlib.sha256("\0".join([HIPCC, *CFLAGS, unit, _HIPCC_VERSION]).encode()).hexdigest()
+    return _HIPCC_VERSION or None
 
 
-def _stamp_ok(unit: str) -> bool:
-    path = os.path.join(OBJ, unit[:-4] + ".stamp")
+def _obj_name(unit: str, exp: bool) -> str:
+    return unit[:-4] + ("_exp" if exp else "")
+
+
+def _stamp(unit: str, exp: bool) -> str:
+    """hash of everything besides the sources that decides what the object contains"""
+    _check_flags()
+    return hashlib.sha256("\0".join([HIPCC, *CFLAGS, "exp" if exp else "", unit, _flag_env(), _hipcc_version() or ""]).encode()).hexdigest()
+
+
+def _stamp_ok(unit: str, exp: bool) -> bool:
+    path = os.path.join(OBJ, _obj_name(unit, exp) + ".stamp")
     try:
-        return open(path).read().strip() == _stamp(unit)
+        return open(path).read().strip() == _stamp(unit, exp)
     except OSError:
         return False
 
 
+def _jobs():
+    return [(u, False) for u in UNITS] + [(u, True) for u in EXP_UNITS]
+
+
 def needs_build() -> bool:
-    return (_stale(LIB, _headers() + [os.path.join(CSRC, u) for u in UNITS])
-            or not all(_stamp_ok(u) and os.path.exists(os.path.join(OBJ, u[:-4] + ".o")) for u in UNITS))
+    if _hipcc_version() is None:
+        # no compiler here: prebuilt libraries are taken as they are (they were stamped where they were built); missing ones are an error
+        if os.path.exists(LIB) and os.path.exists(LIB_EXP):
+            return False
+        raise RuntimeError("crypto12381_amd.build: %s not found and no prebuilt %s — build the library where hipcc is available" % (HIPCC, LIB))
+    srcs = _headers() + [os.path.join(CSRC, u) for u in UNITS]
+    return (_stale(LIB, srcs) or _stale(LIB_EXP, srcs)
+            or not all(_stamp_ok(u, e) and os.path.exists(os.path.join(OBJ, _obj_name(u, e) + ".o")) for u, e in _jobs()))
 
 
-def _compile(unit: str, force: bool, verbose: bool) -> str:
+def _compile(unit: str, exp: bool, force: bool, verbose: bool) -> str:
     src = os.path.join(CSRC, unit)
-    obj = os.path.join(OBJ, unit[:-4] + ".o")
-    if force or _stale(obj, _headers() + [src]) or not _stamp_ok(unit):
-        cmd = [HIPCC, *CFLAGS, "-c", "-o", obj, src]
+    obj = os.path.join(OBJ, _obj_name(unit, exp) + ".o")
+    if force or _stale(obj, _headers() + [src]) or not _stamp_ok(unit, exp):
+        cmd = [HIPCC, *CFLAGS, *(["-DC12381_EXPERIMENTS"] if exp else []), "-c", "-o", obj, src]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
@@ -91,20 +133,24 @@ def _compile(unit: str, force: bool, verbose: bool) -> str:
         # shared out-of-line routines a 512-register budget and drags all of them to occupancy 1 — treat that as an error
         if "failed to meet occupancy target" in r.stderr:
             raise RuntimeError("%s: a kernel missed its occupancy target (see the compiler warning above)" % unit)
-        with open(os.path.join(OBJ, unit[:-4] + ".stamp"), "w") as f:
-            f.write(_stamp(unit) + "\n")
+        with open(os.path.join(OBJ, _obj_name(unit, exp) + ".stamp"), "w") as f:
+            f.write(_stamp(unit, exp) + "\n")
     return obj
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or needs_build():
+        _check_flags()
         os.makedirs(OBJ, exist_ok=True)
-        with ThreadPoolExecutor(max_workers=len(UNITS)) as ex:
-            objs = list(ex.map(lambda u: _compile(u, force, verbose), UNITS))
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True)
+        jobs = _jobs()
+        with ThreadPoolExecutor(max_workers=8) as ex:
+            objs = dict(zip(jobs, ex.map(lambda j: _compile(j[0], j[1], force, verbose), jobs)))
+        for lib, exp in ((LIB, False), (LIB_EXP, True)):
+            link = [objs[(u, exp and u in EXP_UNITS)] for u in UNITS]
+            cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *link]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
     return LIB
 
 

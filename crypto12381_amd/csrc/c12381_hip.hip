@@ -23,13 +23,23 @@
 using namespace c12381;
 
 namespace {
-constexpr size_t G1_CHUNK = (size_t)1 << 17;     // elements per scalar-mul launch = resident lanes at 2 waves/SIMD; table slab 176 MiB (fits the 256 MiB Infinity Cache)
-constexpr size_t G2_CHUNK = (size_t)1 << 17;     // G2 table slab = 352 MiB (2688-byte record per lane)
+// Tuning and diagnostic switches exist only in builds with -DC12381_EXPERIMENTS (crypto12381_amd/lib/libc12381_hip_exp.so: tools/, A/B
+// runs, tests/test_gpu_variants.py).  The default library reads NO environment variable and contains neither the superseded
+// one-lane pairing kernels nor the forced-failure hooks: a stray variable in a caller's environment cannot select another path.
+#ifdef C12381_EXPERIMENTS
+inline const char* tuning_env(const char* name) { return std::getenv(name); }
+#else
+inline const char* tuning_env(const char*) { return nullptr; }
+#endif
+// elements per scalar-mul launch: G1 = the lanes resident at the kernel's occupancy (256 CUs x 4 SIMDs x 64 lanes x waves per SIMD),
+// one machine-filling round per launch; G2 (two lanes per point) = two rounds.  Table slabs: 2816 B per lane (G1 352 MiB, G2 704 MiB at 2 waves)
+constexpr size_t G1_CHUNK = (size_t)65536 * C12381_G1_OCC;
+constexpr size_t G2_CHUNK = (size_t)65536 * C12381_G2H_OCC;
 constexpr int FLAG_WORDS = 4;                    // device status words (read_flag)
 // terms per bucket-method pass (2 * n * windows sort items < 2^31); C12381_MSM_MAX_TERMS lowers it so that tests reach
 // the multi-part path with small inputs
 const size_t MSM_MAX_TERMS = [] {
-    const char* e = std::getenv("C12381_MSM_MAX_TERMS");
+    const char* e = tuning_env("C12381_MSM_MAX_TERMS");
     const size_t v = e ? (size_t)std::strtoull(e, nullptr, 10) : 0;
     return v >= 64 && v < ((size_t)1 << 26) ? v : (size_t)1 << 26;
 }();
@@ -54,6 +64,9 @@ struct c12381_ctx {
     bool profiling = false;
     struct ev_pair { hipEvent_t a, b; int kind; };
     std::vector<ev_pair> events;
+    // diagnostic (experiments builds, C12381_PAIR_STAMPS): per-task time stamps of the last queue pairing launch, on this context's device
+    unsigned long long* stamps = nullptr;
+    size_t stamps_tasks = 0;
 };
 
 namespace {
@@ -178,7 +191,7 @@ int stage_out(c12381_ctx* c, const staged& s, void* hout, size_t bout) {
 
 // window width: msm_window_bits(n), or C12381_MSM_C = 4..16 (tuning runs)
 static int msm_c(size_t n) {
-    static const int forced = [] { const char* e = std::getenv("C12381_MSM_C"); const int v = e ? std::atoi(e) : 0; return v >= 4 && v <= 16 ? v : 0; }();
+    static const int forced = [] { const char* e = tuning_env("C12381_MSM_C"); const int v = e ? std::atoi(e) : 0; return v >= 4 && v <= 16 ? v : 0; }();
     return forced ? forced : msm_window_bits(n);
 }
 // Bucket-method MSM (msm.hpp): prep -> radix sort -> bucket sums -> window reduction -> Horner -> affine.
@@ -321,7 +334,7 @@ int g1_msm_pippenger(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t*
 // C12381_MSM=naive forces the n-scalar-muls + tree-sum path (A/B measurements); default: buckets from 2 terms on (both
 // paths equal the reference's chain of multiply() calls for every input; the bucket path is the faster one at every size)
 static bool msm_use_buckets(size_t n) {
-    static const int mode = [] { const char* e = std::getenv("C12381_MSM"); return e ? (e[0] == 'n' ? 1 : (e[0] == 'b' ? 2 : 0)) : 0; }();
+    static const int mode = [] { const char* e = tuning_env("C12381_MSM"); return e ? (e[0] == 'n' ? 1 : (e[0] == 'b' ? 2 : 0)) : 0; }();
     if (mode == 1) return false;
     return n >= 2;
 }
@@ -345,7 +358,7 @@ int c12381_create(int device, c12381_ctx** out) {
         hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming) != hipSuccess) { c12381_destroy(c); return C12381_E_HIP; }
     if (hipMalloc((void**)&c->d_flag, FLAG_WORDS * sizeof(int)) != hipSuccess || hipHostMalloc((void**)&c->h_flag, FLAG_WORDS * sizeof(int)) != hipSuccess ||
         hipMemset(c->d_flag, 0, FLAG_WORDS * sizeof(int)) != hipSuccess) { c12381_destroy(c); return C12381_E_HIP; }
-    if (const char* e = std::getenv("C12381_QUEUE_GROUPS")) set_queue_groups_override(std::atoi(e));      // tuning runs only
+    if (const char* e = tuning_env("C12381_QUEUE_GROUPS")) set_queue_groups_override(std::atoi(e));      // tuning runs only
     *out = c;
     return 0;
 }
@@ -356,6 +369,7 @@ void c12381_destroy(c12381_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (int i = 0; i < c12381_ctx::WS_COUNT; ++i) if (c->ws[i]) (void)hipFree(c->ws[i]);
+    if (c->stamps) (void)hipFree(c->stamps);
     if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->h_flag) (void)hipHostFree(c->h_flag);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -616,7 +630,7 @@ static int g2_mul_dev_strided(c12381_ctx* c, size_t n, const uint8_t* pts, size_
     const size_t chunk = n < G2_CHUNK ? round_up(n, 64) : G2_CHUNK;
     // C12381_G2_LANES=1 keeps the one-lane-per-point kernel for the batch entry points (A/B measurements); default:
     // two lanes per point (k_g2h.hip), whose per-lane table records are those of G1 (2 x 1408 B per point)
-    static const bool two_lanes = [] { const char* e = std::getenv("C12381_G2_LANES"); return !(e && e[0] == '1'); }();
+    static const bool two_lanes = [] { const char* e = tuning_env("C12381_G2_LANES"); return !(e && e[0] == '1'); }();
     const bool pairwise = finish && two_lanes;
     if ((rc = ensure(c, c12381_ctx::WS_TAB, (size_t)(pairwise ? 2 * G2_TAB * G1_ENT_DWORDS : G2_TAB_DWORDS) * chunk * 4))) return rc;
     int32_t* proj = finish ? (int32_t*)c->ws[c12381_ctx::WS_PROJ] : nullptr;
@@ -703,10 +717,14 @@ int c12381_g2_add_batch(c12381_ctx* c, size_t n, const uint8_t* a, const uint8_t
 
 // ---------------------------------------------------------------- pairing
 // C12381_PAIR_LANES=1 selects the one-lane-per-pairing kernels (kept for A/B measurements); default is 3.
+#ifdef C12381_EXPERIMENTS
 static int pair_lanes() {
-    static const int v = [] { const char* e = std::getenv("C12381_PAIR_LANES"); return (e && e[0] == '1') ? 1 : 3; }();
+    static const int v = [] { const char* e = tuning_env("C12381_PAIR_LANES"); return (e && e[0] == '1') ? 1 : 3; }();
     return v;
 }
+#else
+static constexpr int pair_lanes() { return 3; }
+#endif
 static unsigned grid_tri(size_t n) {
     const size_t waves = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE;
     return (unsigned)((waves * 64 + BLOCK - 1) / BLOCK);
@@ -715,41 +733,39 @@ static unsigned grid_tri(size_t n) {
 // plain grid would end in a mostly idle round.  C12381_PAIR_QUEUE=0 / 1 forces it off / on (A/B measurements, tests).
 constexpr size_t PAIR_QUEUE_WAVES = 2048;                  // resident wavefronts at 2 per SIMD
 static int pair_queue_mode() {
-    static const int v = [] { const char* e = std::getenv("C12381_PAIR_QUEUE"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    static const int v = [] { const char* e = tuning_env("C12381_PAIR_QUEUE"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
     return v;
 }
 // bound of the hand-over spin in the queue kernels (k_pair3.hip queue_wait): 2^20 sleeps of 4096 cycles, about two
 // seconds — three orders of magnitude beyond a task.  C12381_PAIR_SPIN_LIMIT overrides it; a negative value makes every
 // wait fail (tests of the poison path).
 static int pair_spin_limit() {
-    static const int v = [] { const char* e = std::getenv("C12381_PAIR_SPIN_LIMIT"); return e ? std::atoi(e) : (1 << 20); }();
+    static const int v = [] { const char* e = tuning_env("C12381_PAIR_SPIN_LIMIT"); return e ? std::atoi(e) : (1 << 20); }();
     return v;
 }
 // Diagnostic: C12381_PAIR_STAMPS=<file> makes every task of pair3_queue_kernel record its claim / start / end times (s_memtime)
 // into a device buffer that c12381_sync() writes to the file — per-phase durations and hand-over waits (tools/queue_phase_times.py).
 static const char* pair_stamps_path() {
-    static const char* p = std::getenv("C12381_PAIR_STAMPS");
+    static const char* p = tuning_env("C12381_PAIR_STAMPS");
     return p;
 }
-static unsigned long long* g_stamps = nullptr;
-static size_t g_stamps_tasks = 0;
 static unsigned long long* pair_stamps(c12381_ctx* c, size_t n) {
     if (!pair_stamps_path()) return nullptr;
     const size_t tasks = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE * 10;
-    if (g_stamps_tasks < tasks) {
-        if (g_stamps) (void)hipFree(g_stamps);
-        if (hipMalloc((void**)&g_stamps, tasks * 32) != hipSuccess) { g_stamps = nullptr; g_stamps_tasks = 0; return nullptr; }
-        g_stamps_tasks = tasks;
+    if (c->stamps_tasks < tasks) {
+        (void)hipStreamSynchronize(c->stream);              // a kernel of this context may still be writing the old buffer
+        if (c->stamps) (void)hipFree(c->stamps);
+        if (hipMalloc((void**)&c->stamps, tasks * 32) != hipSuccess) { c->stamps = nullptr; c->stamps_tasks = 0; return nullptr; }
+        c->stamps_tasks = tasks;
     }
-    (void)hipMemsetAsync(g_stamps, 0, tasks * 32, c->stream);
-    return g_stamps;
+    (void)hipMemsetAsync(c->stamps, 0, tasks * 32, c->stream);
+    return c->stamps;
 }
 static void pair_stamps_dump(c12381_ctx* c) {
-    if (!pair_stamps_path() || !g_stamps) return;
-    std::vector<unsigned long long> h(g_stamps_tasks * 4);
-    if (hipMemcpy(h.data(), g_stamps, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+    if (!pair_stamps_path() || !c->stamps) return;
+    std::vector<unsigned long long> h(c->stamps_tasks * 4);
+    if (hipMemcpy(h.data(), c->stamps, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
     if (FILE* f = std::fopen(pair_stamps_path(), "wb")) { std::fwrite(h.data(), 8, h.size(), f); std::fclose(f); }
-    (void)c;
 }
 static bool pair_use_queue(size_t n) {
     const int m = pair_queue_mode();
@@ -772,8 +788,10 @@ static int pair_queue_setup(c12381_ctx* c, size_t n, uint4*& state, unsigned int
     return 0;
 }
 static int launch_pair(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt) {
-    if (pair_lanes() == 1) hipLaunchKernelGGL(pair_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag);
-    else if (pair_use_queue(n)) {
+#ifdef C12381_EXPERIMENTS
+    if (pair_lanes() == 1) { hipLaunchKernelGGL(pair_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag); HIPCK(c, hipGetLastError()); return 0; }
+#endif
+    if (pair_use_queue(n)) {
         uint4* st; unsigned int *fl, *ct; unsigned blocks; int rc;
         if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
         hipLaunchKernelGGL(pair3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag, st, fl, ct, pair_spin_limit(), pair_stamps(c, n));
@@ -783,8 +801,10 @@ static int launch_pair(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8_t
 }
 static int launch_pair_eq(c12381_ctx* c, size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, size_t b2_stride, uint8_t* ok,
                           const int32_t* skip_if = nullptr) {
-    if (pair_lanes() == 1) hipLaunchKernelGGL(pair_eq_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, a1, a2, b1, b2, b2_stride, ok, c->d_flag);
-    else if (pair_use_queue(n)) {
+#ifdef C12381_EXPERIMENTS
+    if (pair_lanes() == 1) { hipLaunchKernelGGL(pair_eq_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, a1, a2, b1, b2, b2_stride, ok, c->d_flag); HIPCK(c, hipGetLastError()); return 0; }
+#endif
+    if (pair_use_queue(n)) {
         uint4* st; unsigned int *fl, *ct; unsigned blocks; int rc;
         if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
         hipLaunchKernelGGL(pair3_eq_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, a1, a2, b1, b2, b2_stride, ok, c->d_flag, st, fl, ct, skip_if, pair_spin_limit());
@@ -1053,20 +1073,26 @@ int c12381_g2_decompress_batch(c12381_ctx* c, size_t n, const uint8_t* in97, uin
     return read_flag(c);
 }
 static int launch_miller(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* out) {
-    if (pair_lanes() == 1) hipLaunchKernelGGL(miller_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, g1, g2, out, c->d_flag);
-    else hipLaunchKernelGGL(miller3_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, g1, g2, out, c->d_flag);
+#ifdef C12381_EXPERIMENTS
+    if (pair_lanes() == 1) { hipLaunchKernelGGL(miller_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, g1, g2, out, c->d_flag); HIPCK(c, hipGetLastError()); return 0; }
+#endif
+    hipLaunchKernelGGL(miller3_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, g1, g2, out, c->d_flag);
     HIPCK(c, hipGetLastError());
     return 0;
 }
 static int launch_gt_op(c12381_ctx* c, int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
-    if (pair_lanes() == 1) hipLaunchKernelGGL(gt_op_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, op, n, a, b, out);
-    else hipLaunchKernelGGL(gt3_op_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, op, n, a, b, out);
+#ifdef C12381_EXPERIMENTS
+    if (pair_lanes() == 1) { hipLaunchKernelGGL(gt_op_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, op, n, a, b, out); HIPCK(c, hipGetLastError()); return 0; }
+#endif
+    hipLaunchKernelGGL(gt3_op_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, op, n, a, b, out);
     HIPCK(c, hipGetLastError());
     return 0;
 }
 static int launch_gt_is_unity(c12381_ctx* c, size_t n, const uint8_t* a, uint8_t* out) {
-    if (pair_lanes() == 1) hipLaunchKernelGGL(gt_is_unity_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, a, out);
-    else hipLaunchKernelGGL(gt3_is_unity_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, a, out);
+#ifdef C12381_EXPERIMENTS
+    if (pair_lanes() == 1) { hipLaunchKernelGGL(gt_is_unity_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, a, out); HIPCK(c, hipGetLastError()); return 0; }
+#endif
+    hipLaunchKernelGGL(gt3_is_unity_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, a, out);
     HIPCK(c, hipGetLastError());
     return 0;
 }
@@ -1084,6 +1110,7 @@ int c12381_miller_batch_dev(c12381_ctx* c, size_t n, const uint8_t* g1, const ui
     int rc = bind(c); if (rc) return rc;
     if (!g1 || !g2 || !out576) return C12381_E_ARG;
     if (n == 0) return 0;
+    timed tm(c, 6);
     return launch_miller(c, n, g1, g2, out576);
 }
 int c12381_gt_op_batch(c12381_ctx* c, int op, size_t n, const uint8_t* a576, const uint8_t* b, uint8_t* out576) {
@@ -1101,6 +1128,7 @@ int c12381_gt_op_batch_dev(c12381_ctx* c, int op, size_t n, const uint8_t* a576,
     int rc = bind(c); if (rc) return rc;
     if (op < 0 || op > 3 || !a576 || !out576 || ((op == 0 || op == 2) && !b)) return C12381_E_ARG;
     if (n == 0) return 0;
+    timed tm(c, 7);
     return launch_gt_op(c, op, n, a576, b, out576);
 }
 int c12381_fexp_batch(c12381_ctx* c, size_t n, const uint8_t* in576, uint8_t* out576) { return c12381_gt_op_batch(c, 3, n, in576, nullptr, out576); }
@@ -1151,13 +1179,13 @@ static int lines_table(c12381_ctx* c, int slot, const uint8_t* d_q192, int need_
     int32_t* buf = (int32_t*)c->ws[slot];
     hipLaunchKernelGGL(fixed_cache_check_kernel, dim3(1), dim3(64), 0, c->stream, d_q192, 192, buf);
     HIPCK(c, hipGetLastError());
-    static const int raw = [] { const char* e = std::getenv("C12381_FQ_RAW"); return (e && e[0] == '1') ? 4 : 0; }();
+    static const int raw = [] { const char* e = tuning_env("C12381_FQ_RAW"); return (e && e[0] == '1') ? 4 : 0; }();
     hipLaunchKernelGGL(g2_lines_table_kernel, dim3(1), dim3(BLOCK), 0, c->stream, d_q192, buf, need_g2 | raw);
     HIPCK(c, hipGetLastError());
     return 0;
 }
 static bool fixed_base_enabled() {
-    static const bool on = [] { const char* e = std::getenv("C12381_FIXED_BASE"); return !(e && e[0] == '0'); }();
+    static const bool on = [] { const char* e = tuning_env("C12381_FIXED_BASE"); return !(e && e[0] == '0'); }();
     return on;
 }
 

@@ -118,8 +118,7 @@ C12381_HD void g2_fixed_digit(g2p& acc, const int32_t* tab, const uint32_t (&u)[
             g2p q, e;
             fb_load_g2(q.x, q.y, tab + ((size_t)j * FB_ENTRIES + (d - 1)) * FB_G2_DWORDS);
             fp2_one(q.z);
-            g2_psi<I>(e, q);
-            if (I & 1) { fp2 ny; fp2_neg(ny, e.y); e.y = ny; }
+            g2_psi_signed<I>(e, q, (I & 1) != 0);
             g2_norm1(e, e);
             g2_add(acc, e);
         }

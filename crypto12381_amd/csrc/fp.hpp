@@ -16,6 +16,8 @@
 //     bounds depend only on the operation sequence, never on the data.
 #pragma once
 #include <cstdint>
+#include <type_traits>
+#include <utility>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -43,13 +45,20 @@ namespace c12381 { __device__ __forceinline__ int32_t limb_opaque(int32_t v) { a
 #include "consts.hpp"
 
 #ifdef C12381_CHECK_BOUNDS
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
 #include <execinfo.h>
 #define C12381_BOUNDS(...) __VA_ARGS__
+// operation counters of the host simulation (tools/count_ops.py): columns of 14 x 14 limb products scanned (27 per product) and
+// Montgomery reductions — the work a device routine does in THIS number format, and, priced at 144 / 156 multiply-adds, the
+// algorithmic MAC32 count of SURVEY.md 8(d) for the operation sequence as built
+namespace c12381 { inline std::atomic<unsigned long long> g_ops_cols{0}, g_ops_reds{0}; }
+#define C12381_COUNT(cols, reds) do { c12381::g_ops_cols.fetch_add((cols), std::memory_order_relaxed); c12381::g_ops_reds.fetch_add((reds), std::memory_order_relaxed); } while (0)
 #else
 #define C12381_BOUNDS(...)
+#define C12381_COUNT(cols, reds)
 #endif
 
 namespace c12381 {
@@ -185,6 +194,7 @@ inline void check_mul_operands(const fp& a, const fp& b, const char* where) {
 // 392 v_mad_i64_i32 + 14 v_mul_lo_u32 and ~70 shifts/masks per call.
 C12381_HD void fp_mul(fp& r, const fp& a, const fp& b) {
     C12381_BOUNDS(check_mul_operands(a, b, "fp_mul");)
+    C12381_COUNT(27, 1);
     int32_t m[NL];
     int32_t out[NL];
     int64_t acc = 0;
@@ -218,6 +228,7 @@ C12381_HD void fp_mul(fp& r, const fp& a, const fp& b) {
 // r = a^2 / R mod p.  Cross terms once, doubled per column: 105 + 196 multiply-adds.
 C12381_HD void fp_sqr(fp& r, const fp& a) {
     C12381_BOUNDS(check_mul_operands(a, a, "fp_sqr");)
+    C12381_COUNT(27, 1);
     int32_t m[NL];
     int32_t out[NL];
     int32_t a2[NL];                      // 2a: the cross terms accumulate straight into the column (limbs <= 2^30)
@@ -262,6 +273,7 @@ C12381_HD void fp_sqr(fp& r, const fp& a) {
 // with |limbs| <= LBa, LBb that is  14 * T * LBa * LBb + 14 * 2^56 + 2^40 < 2^63  for T products.
 // Differences are formed by negating one operand's limbs once (fp_raw_neg), squares use a pre-doubled copy.
 C12381_HD void fp_col_acc(int64_t& acc, const fp& a, const fp& b, int k) {
+    C12381_COUNT(1, 0);
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
         const int j = k - i;
@@ -270,6 +282,7 @@ C12381_HD void fp_col_acc(int64_t& acc, const fp& a, const fp& b, int k) {
 }
 // acc += column k of s * a^2 given a2 = 2 s a and ad = s a  (s = +1 or -1): cross terms once, diagonal term
 C12381_HD void fp_col_sqr_acc(int64_t& acc, const fp& a, const fp& a2, const fp& ad, int k) {
+    C12381_COUNT(1, 0);
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
         const int j = k - i;
@@ -295,6 +308,7 @@ C12381_HD void fp_raw_neg_dbl(fp& r, const fp& a) {
 }
 template <class ColFn>
 C12381_HD void fp_reduce_cols(fp& r, ColFn col) {
+    C12381_COUNT(0, 1);
     int32_t m[NL];
     int32_t out[NL];
     int64_t acc = 0;
@@ -315,6 +329,39 @@ C12381_HD void fp_reduce_cols(fp& r, ColFn col) {
         out[k - NL] = C12381_LIMB((int32_t)((uint32_t)acc & LMASK));
         acc >>= LB;
     }
+    out[NL - 1] = (int32_t)acc;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = out[i];
+}
+// The same engine with the column index as a compile-time constant (an index pack instead of `#pragma unroll` loops): forms with
+// four products per column are past the size at which LLVM still honours the unroll request for the outer loops — it then emits
+// real loops with indexed register access (s_set_gpr_idx) and 64-bit unsigned multiply-adds.  Here nothing is left to the
+// unroller's heuristics: col() sees a literal k and its own limb loops have 14 constant iterations with foldable conditions.
+template <int... Ks, class Fn>
+C12381_HD void fp_static_for(std::integer_sequence<int, Ks...>, Fn&& fn) { (fn(std::integral_constant<int, Ks>{}), ...); }
+template <class ColFn>
+C12381_HD void fp_reduce_cols_static(fp& r, ColFn col) {
+    C12381_COUNT(0, 1);
+    int32_t m[NL];
+    int32_t out[NL];
+    int64_t acc = 0;
+    fp_static_for(std::make_integer_sequence<int, NL>{}, [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        col(k, acc);
+#pragma unroll
+        for (int i = 0; i < k; ++i) acc += (int64_t)m[i] * FP_P[k - i];
+        m[k] = (int32_t)(((uint32_t)acc * FP_N0) & LMASK);
+        acc += (int64_t)m[k] * FP_P[0];
+        acc >>= LB;
+    });
+    fp_static_for(std::make_integer_sequence<int, NL - 1>{}, [&](auto kc) {
+        constexpr int k = NL + decltype(kc)::value;
+        col(k, acc);
+#pragma unroll
+        for (int i = k - NL + 1; i < NL; ++i) acc += (int64_t)m[i] * FP_P[k - i];
+        out[k - NL] = C12381_LIMB((int32_t)((uint32_t)acc & LMASK));
+        acc >>= LB;
+    });
     out[NL - 1] = (int32_t)acc;
 #pragma unroll
     for (int i = 0; i < NL; ++i) r.l[i] = out[i];

@@ -56,6 +56,44 @@ C12381_HD void fp2_sqr(fp2& r, const fp2& x) {
                     set_lazy_bounds(rb, 2 * x.a.lb * x.b.lb, 2 * x.a.vb * x.b.vb, "fp2_sqr.b"); })
     r.a = ra; r.b = rb;
 }
+// r = a*b + c*d  (SUB: a*b - c*d) with ONE reduction per coordinate: four limb products per column instead of two reduced
+// Fp2 products (saves 2 x 210 multiply-adds; the lazily reduced sums of the complete addition formulas, like fp_mul2 in G1).
+// Needs 14 * sum(LB*LB over the four products of a coordinate) + 14 * 2^56 + 2^40 < 2^63, e.g. one normalised operand
+// (2^28) against one of limb bound 2^29 in both products.
+template <bool SUB>
+C12381_HD void fp2_mul2(fp2& r, const fp2& a, const fp2& b, const fp2& c, const fp2& d) {
+    fp ra, rb, nab, ca, cb, ncb;                 // (ca, cb) = +-c, ncb = -(+-c.b)
+    fp_raw_neg(nab, a.b);
+    if (SUB) { fp_raw_neg(ca, c.a); fp_raw_neg(cb, c.b); ncb = c.b; }
+    else { ca = c.a; cb = c.b; fp_raw_neg(ncb, c.b); }
+    fp_reduce_cols_static(ra, [&](int k, int64_t& acc) { fp_col_acc(acc, a.a, b.a, k); fp_col_acc(acc, nab, b.b, k);
+                                                    fp_col_acc(acc, ca, d.a, k); fp_col_acc(acc, ncb, d.b, k); });
+    fp_reduce_cols_static(rb, [&](int k, int64_t& acc) { fp_col_acc(acc, a.a, b.b, k); fp_col_acc(acc, a.b, b.a, k);
+                                                    fp_col_acc(acc, ca, d.b, k); fp_col_acc(acc, cb, d.a, k); });
+    C12381_BOUNDS({ check_actual(a.a, "fp2_mul2"); check_actual(a.b, "fp2_mul2"); check_actual(b.a, "fp2_mul2"); check_actual(b.b, "fp2_mul2");
+                    check_actual(c.a, "fp2_mul2"); check_actual(c.b, "fp2_mul2"); check_actual(d.a, "fp2_mul2"); check_actual(d.b, "fp2_mul2");
+                    set_lazy_bounds(ra, a.a.lb * b.a.lb + a.b.lb * b.b.lb + c.a.lb * d.a.lb + c.b.lb * d.b.lb,
+                                    a.a.vb * b.a.vb + a.b.vb * b.b.vb + c.a.vb * d.a.vb + c.b.vb * d.b.vb, "fp2_mul2.a");
+                    set_lazy_bounds(rb, a.a.lb * b.b.lb + a.b.lb * b.a.lb + c.a.lb * d.b.lb + c.b.lb * d.a.lb,
+                                    a.a.vb * b.b.vb + a.b.vb * b.a.vb + c.a.vb * d.b.vb + c.b.vb * d.a.vb, "fp2_mul2.b"); })
+    r.a = ra; r.b = rb;
+}
+// The constants of psi = untwist-Frobenius-twist (ECP2_frob ecp2_BLS12381.cpp:579-590 with X = 1/f) have special shapes on this
+// curve (tools/gen_consts.py asserts them): PSI1_X = c i, PSI3_X = -i, PSI1_Y = a (1 - i), PSI3_Y = -PSI1_Y, PSI2_Y = -1.
+//   conj(x) * (c i)      = c x.b + c x.a i                               two Fp products instead of an Fp2 product
+//   conj(x) * (-i)       = -x.b - x.a i                                  no product
+//   conj(y) * a (1 - i)  = a (y.a - y.b) - a (y.a + y.b) i               two Fp products; `neg` negates the result (the sign of the
+//                                                                         digit and of psi^3 ride along for free)
+C12381_HD void fp2_conj_mul_ci(fp2& r, const fp2& x, const fp& c) { fp ta, tb; fp_mul(ta, x.b, c); fp_mul(tb, x.a, c); r.a = ta; r.b = tb; }
+C12381_HD void fp2_conj_mul_neg_i(fp2& r, const fp2& x) { fp ta, tb; fp_neg(ta, x.b); fp_neg(tb, x.a); r.a = ta; r.b = tb; }
+C12381_HD void fp2_conj_mul_a1mi(fp2& r, const fp2& y, const fp& a, bool neg) {
+    fp d, s, nd, ns;
+    fp_sub(d, y.a, y.b);                       // y.a - y.b
+    fp_add(s, y.a, y.b); fp_neg(s, s);         // -(y.a + y.b)
+    fp_neg(nd, d); fp_neg(ns, s);
+    fp_select(d, neg, nd, d); fp_select(s, neg, ns, s);
+    fp_mul(r.a, d, a); fp_mul(r.b, s, a);
+}
 // r = x * s for s in Fp  (FP2_pmul :231)
 C12381_HD void fp2_mul_fp(fp2& r, const fp2& x, const fp& s) { fp_mul(r.a, x.a, s); fp_mul(r.b, x.b, s); }
 // r = 1/x  (FP2_inv :334): conj(x) / (a^2 + b^2)

@@ -22,21 +22,22 @@ template <class F> C12381_HD void g2_neg(g2pt<F>& r, const g2pt<F>& p) { r.x = p
 template <class F> C12381_HD void fp2_mul_b3(F& r, const F& x) { F t; fp2_mul_small(t, x, 12); fp2_mul_ip(r, t); }
 
 // ECP2_dbl :358-409.  Also returns t0 = Y^2, t1 = Y*Z, t2b = 3b' Z^2 for the Miller-loop line.
+// Operand limb bounds: X <= 2^29, Y and Z normalised (every Y / Z this file produces is a reduction output).
+// Y3 = (Y^2 - 9b'Z^2)(Y^2 + 3b'Z^2) + 3b'Z^2 * 8Y^2 is ONE lazily reduced form (fp2_mul2): 7 reductions for 8 products.
 template <class F> C12381_HD void g2_dbl_core(g2pt<F>& p, F& t0, F& t1, F& t2b) {
-    F t2, x3, y3, z3, u;
+    F t2, x3, y3, z3, z8, u, s;
     fp2_sqr(t0, p.y);
     fp2_mul(t1, p.y, p.z);
     fp2_sqr(t2, p.z);
-    fp2_mul_small(z3, t0, 8);
+    fp2_mul_small(z8, t0, 8);
     fp2_mul_b3(t2b, t2);
-    fp2_mul(x3, t2b, z3);
-    fp2_add(y3, t0, t2b);
-    fp2_mul(z3, t1, z3);
+    fp2_add(s, t0, t2b);
+    fp2_norm1(s, s);                              // Y^2 + 3b'Z^2
+    fp2_mul(z3, t1, z8);
     fp2_dbl(u, t2b); fp2_add(u, u, t2b);          // 9b' Z^2
     fp2_sub(u, t0, u);
     fp2_norm1(u, u);
-    fp2_mul(y3, u, y3);
-    fp2_add(y3, y3, x3);
+    fp2_mul2<false>(y3, u, s, t2b, z8);
     F xy;
     fp2_mul(xy, p.x, p.y);
     fp2_mul(x3, u, xy);
@@ -53,7 +54,8 @@ template <class F> C12381_HDN void g2_dbl_n(g2pt<F>& p, int n) {
     p = q;
 }
 
-// ECP2_add :413-502 (complete).  P limb bound <= 2^29, Q normalised.
+// ECP2_add :413-502 (complete).  P: X <= 2^29, Y and Z normalised; Q normalised.  The three output coordinates are sums of two
+// products each and are reduced once (fp2_mul2): 9 reductions for 12 products, as g1_add.
 template <class F> C12381_HDN void g2_add(g2pt<F>& p, const g2pt<F>& q) {
     F t0, t1, t2, t3, t4, x3, y3, z3;
     fp2_mul(t0, p.x, q.x);
@@ -61,18 +63,18 @@ template <class F> C12381_HDN void g2_add(g2pt<F>& p, const g2pt<F>& q) {
     fp2_mul(t2, p.z, q.z);
     fp2_add(t3, p.x, p.y); fp2_norm1(t3, t3); fp2_add(t4, q.x, q.y); fp2_mul(t3, t3, t4);
     fp2_add(t4, t0, t1); fp2_sub(t3, t3, t4); fp2_norm1(t3, t3);
-    fp2_add(t4, p.y, p.z); fp2_norm1(t4, t4); fp2_add(x3, q.y, q.z); fp2_mul(t4, t4, x3);
+    fp2_add(t4, p.y, p.z); fp2_add(x3, q.y, q.z); fp2_mul(t4, t4, x3);
     fp2_add(x3, t1, t2); fp2_sub(t4, t4, x3); fp2_norm1(t4, t4);
     fp2_add(x3, p.x, p.z); fp2_norm1(x3, x3); fp2_add(y3, q.x, q.z); fp2_mul(x3, x3, y3);
     fp2_add(y3, t0, t2); fp2_sub(y3, x3, y3);
     fp2_mul_small(t0, t0, 3);
     fp2_mul_b3(t2, t2);
-    fp2_add(z3, t1, t2);
+    fp2_add(z3, t1, t2); fp2_norm1(z3, z3);
     fp2_sub(t1, t1, t2); fp2_norm1(t1, t1);
     fp2_mul_b3(y3, y3);
-    fp2_mul(x3, y3, t4); fp2_mul(t2, t3, t1); fp2_sub(p.x, t2, x3);
-    fp2_mul(y3, y3, t0); fp2_mul(t1, t1, z3); fp2_add(p.y, y3, t1);
-    fp2_mul(t0, t0, t3); fp2_mul(z3, z3, t4); fp2_add(p.z, z3, t0);
+    fp2_mul2<true>(p.x, t3, t1, y3, t4);           // X3 = t3 t1 - y3 t4
+    fp2_mul2<false>(p.y, y3, t0, t1, z3);          // Y3 = y3 t0 + t1 z3
+    fp2_mul2<false>(p.z, z3, t4, t0, t3);          // Z3 = z3 t4 + t0 t3
 }
 
 // ------------------------------------------------------------------ SoA access
@@ -96,10 +98,15 @@ C12381_HD void soa_load_g2(g2p& p, const int32_t* base, size_t stride, size_t id
 }
 
 // ------------------------------------------------------------------ per-lane window table (one 2688-byte record)
-constexpr int G2_WIN = 4;
-constexpr int G2_TAB = 8;                               // entries 1..8 (signed digits)
+#ifndef C12381_G2_WIN
+#define C12381_G2_WIN 5                                  // 4 or 5 (signed windows over the four 64-bit GS digits); A/B on MI355X: DESIGN.md 5c
+#endif
+constexpr int G2_WIN = C12381_G2_WIN;
+static_assert(G2_WIN == 4 || G2_WIN == 5, "window width");
+constexpr int G2_TAB = 1 << (G2_WIN - 1);               // entries 1..8 (1..16)
+constexpr int G2_WINDOWS = G2_WIN == 4 ? 17 : 13;       // 4: 16 biased nibbles + the carry nibble; 5: 13 biased fields cover 65 bits
 constexpr int G2_ENT_DWORDS = 6 * NL;                   // 84 dwords = 21 16-byte accesses
-constexpr int G2_TAB_DWORDS = G2_TAB * G2_ENT_DWORDS;   // 672 dwords per lane
+constexpr int G2_TAB_DWORDS = G2_TAB * G2_ENT_DWORDS;   // per lane (one-lane form): 2688 B (4-bit) / 5376 B (5-bit)
 C12381_HD constexpr int g2_ent_dwords(const g2p&) { return G2_ENT_DWORDS; }
 
 C12381_HD void tab_store_g2(int32_t* ent, const g2p& p) {
@@ -130,22 +137,30 @@ C12381_HD void tab_load_g2(g2p& p, const int32_t* ent) {
 // psi^I(X,Y,Z) = (conj^I(X) c_x, conj^I(Y) c_y, conj^I(Z))   (ECP2_frob ecp2_BLS12381.cpp:579-590 applied I times with
 // X = 1/f as PAIR_G2mul does for the M-type twist, pair_BLS12381.cpp:944-947).  psi is a group homomorphism of the
 // twist, so psi^I(d Q) = d psi^I(Q): one table of multiples of Q serves all four sub-scalars.
+// The constants have special shapes (fp2.hpp; tools/gen_consts.py asserts them): c_x = c i | N(c) in Fp | -i and
+// c_y = a(1 - i) | -1 | -a(1 - i) for I = 1 | 2 | 3, so psi^1 costs four Fp products, psi^2 and psi^3 two each (the generic
+// form: two Fp2 products = eight Fp half-products).  r = (-1)^neg psi^I(p): the sign rides on the Y coordinate for free.
 template <int I, class F>
-C12381_HD void g2_psi(g2pt<F>& r, const g2pt<F>& p) {
-    if (I == 0) { r = p; return; }
-    if (I == 2) {
-        fp cx, cy;
-        fp_set_const(cx, PSI2_X); fp_set_const(cy, PSI2_Y);
-        fp2_mul_fp(r.x, p.x, cx); fp2_mul_fp(r.y, p.y, cy); r.z = p.z;
+C12381_HD void g2_psi_signed(g2pt<F>& r, const g2pt<F>& p, bool neg) {
+    if (I == 0 || I == 2) {
+        F ny;
+        fp2_neg(ny, p.y);
+        fp2_select(r.y, neg != (I == 2), ny, p.y);                    // psi^2: c_y = -1
+        r.z = p.z;
+        if (I == 0) { r.x = p.x; return; }
+        fp cx;
+        fp_set_const(cx, PSI2_X);
+        fp2_mul_fp(r.x, p.x, cx);
         return;
     }
-    F cx, cy, t;
-    if (I == 1) { fp2_set_const(cx, PSI1_X_A, PSI1_X_B); fp2_set_const(cy, PSI1_Y_A, PSI1_Y_B); }
-    else { fp2_set_const(cx, PSI3_X_A, PSI3_X_B); fp2_set_const(cy, PSI3_Y_A, PSI3_Y_B); }
-    fp2_conj(t, p.x); fp2_mul(r.x, t, cx);
-    fp2_conj(t, p.y); fp2_mul(r.y, t, cy);
+    fp cy;
+    fp_set_const(cy, PSI1_Y_A);
+    fp2_conj_mul_a1mi(r.y, p.y, cy, neg != (I == 3));                 // psi^3: c_y = -a(1 - i)
+    if (I == 1) { fp cx; fp_set_const(cx, PSI1_X_B); fp2_conj_mul_ci(r.x, p.x, cx); }
+    else fp2_conj_mul_neg_i(r.x, p.x);
     fp2_conj(r.z, p.z);
 }
+template <int I, class F> C12381_HD void g2_psi(g2pt<F>& r, const g2pt<F>& p) { g2_psi_signed<I>(r, p, false); }
 
 // 128-by-64-bit division step for the normalised 64-bit constant |x| (top bit set) with its precomputed reciprocal
 // v = floor((2^128 - 1) / |x|) - 2^64 (Moeller-Granlund, "Improved division by invariant integers", algorithm 4):
@@ -182,14 +197,28 @@ C12381_HD void scalar_gs_split(uint32_t (&u)[4][2], const uint32_t (&k)[8]) {
     }
     u[3][0] = (uint32_t)w[0]; u[3][1] = (uint32_t)(w[0] >> 32);
 }
-// signed digit of window w (0..16) of u' = u + 0x8888888888888888; window 16 is the carry nibble
+// signed digit of window w of the biased digit u':  4-bit windows: u' = u + 0x8888888888888888, d = nibble - 8 in [-8, 7], window 16
+// is the carry nibble (0 or 1);  5-bit windows: u' = u + sum_{w<13} 16 * 32^w < 2^65 (u < |x| < 0.83 * 2^64), d = field - 16 in
+// [-16, 15], no carry window.  sum_w d_w 2^(WIN w) = u.
+constexpr uint32_t gs_bias_word5(int i) {
+    uint32_t v = 0;
+    for (int w = 0; w < 13; ++w) { const int bit = 5 * w + 4; if ((bit >> 5) == i) v |= 1u << (bit & 31); }
+    return v;
+}
 C12381_HD int gs_digit(const uint32_t (&ub)[3], int w) {
-    const int nib = (int)((ub[w >> 3] >> ((w & 7) * 4)) & 15u);
-    return w == 16 ? nib : nib - 8;
+    if (G2_WIN == 4) {
+        const int nib = (int)((ub[w >> 3] >> ((w & 7) * 4)) & 15u);
+        return w == 16 ? nib : nib - 8;
+    }
+    const int bit = 5 * w, word = bit >> 5, sh = bit & 31;
+    uint32_t v = ub[word] >> sh;
+    if (sh > 27 && word < 2) v |= ub[word + 1] << (32 - sh);
+    return (int)(v & 31u) - 16;
 }
 C12381_HD void gs_bias(uint32_t (&ub)[3], const uint32_t (&u)[2]) {
-    uint64_t c = (uint64_t)u[0] + 0x88888888u; ub[0] = (uint32_t)c; c >>= 32;
-    c += (uint64_t)u[1] + 0x88888888u; ub[1] = (uint32_t)c; ub[2] = (uint32_t)(c >> 32);
+    const uint32_t b0 = G2_WIN == 4 ? 0x88888888u : gs_bias_word5(0), b1 = G2_WIN == 4 ? 0x88888888u : gs_bias_word5(1);
+    uint64_t c = (uint64_t)u[0] + b0; ub[0] = (uint32_t)c; c >>= 32;
+    c += (uint64_t)u[1] + b1; ub[1] = (uint32_t)c; ub[2] = (uint32_t)(c >> 32) + (G2_WIN == 4 ? 0u : gs_bias_word5(2));
 }
 // acc += (-1)^I sign(d) psi^I(T[|d|])
 template <int I, class F>
@@ -198,11 +227,7 @@ C12381_HD void g2_add_digit(g2pt<F>& acc, const int32_t* lane_tab, int d) {
     const int idx = mag == 0 ? 1 : mag;
     g2pt<F> q, e, inf;
     tab_load_g2(q, lane_tab + (idx - 1) * g2_ent_dwords(q));
-    g2_psi<I>(e, q);
-    const bool negate = (d < 0) != ((I & 1) != 0);
-    F ny;
-    fp2_neg(ny, e.y);
-    fp2_select(e.y, negate, ny, e.y);
+    g2_psi_signed<I>(e, q, (d < 0) != ((I & 1) != 0));
     g2_set_inf(inf);
     const bool isz = mag == 0;
     fp2_select(e.x, isz, inf.x, e.x); fp2_select(e.y, isz, inf.y, e.y); fp2_select(e.z, isz, inf.z, e.z);
@@ -258,7 +283,8 @@ template <class F> C12381_HDN void g2_gs_zero_digit_terms(g2pt<F>& acc, const g2
 
 // PAIR_G2mul pair_BLS12381.cpp:927-983: R = u0 Q - u1 psi(Q) + u2 psi^2(Q) - u3 psi^3(Q) for the base-|x| digits of
 // k mod r — exactly what the reference evaluates (ECP2_mul4 after gs() and the sign minimisation), on ANY point of
-// the twist; for Q in G2 it equals [k]Q.  64 doublings + 68 additions on one 8-entry table of multiples of Q.
+// the twist; for Q in G2 it equals [k]Q.  Signed 5-bit windows: 60 doublings + 52 additions on one 16-entry table of multiples of Q
+// (1 doubling + 14 additions to build; 4-bit windows: 64 + 68 on 8 entries, 1 + 6).
 // in_g2: the caller asserts Q lies in G2 (C12381_F_IN_SUBGROUP) — the [r]psi^i(Q) terms are then the point at infinity and
 // their evaluation (a membership test of 64 doublings per affected lane) is skipped.
 template <class F> C12381_HDN void g2_scalar_mul(g2pt<F>& acc, const F& qx, const F& qy, bool q_is_inf, const uint32_t (&kin)[8], int32_t* lane_tab, bool in_g2 = false) {
@@ -295,8 +321,8 @@ template <class F> C12381_HDN void g2_scalar_mul(g2pt<F>& acc, const F& qx, cons
     }
     g2_set_inf(acc);
 #pragma unroll 1
-    for (int w = 16; w >= 0; --w) {
-        if (w != 16) g2_dbl_n(acc, 4);
+    for (int w = G2_WINDOWS - 1; w >= 0; --w) {
+        if (w != G2_WINDOWS - 1) g2_dbl_n(acc, G2_WIN);
         g2_add_digit<0>(acc, lane_tab, gs_digit(ub[0], w));
         g2_add_digit<1>(acc, lane_tab, gs_digit(ub[1], w));
         g2_add_digit<2>(acc, lane_tab, gs_digit(ub[2], w));

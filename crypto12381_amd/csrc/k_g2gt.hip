@@ -2,9 +2,7 @@
 //   g2_mul_kernel      bytes -> on-twist check -> windowed [k]Q -> affine -> 97 B / 192 B
 //   g2_add_kernel      complete addition of two affine G2 inputs
 //   g2_decompress_kernel
-//   pair_kernel        Miller loop + final exponentiation -> 576-byte GT (one-lane variant, see k_pair3.hip)
-//   pair_eq_kernel     e(a1,a2) == e(b1,b2): two Miller loops, ONE final exponentiation, is-unity
-//   miller_kernel / gt_op_kernel / gt_is_unity_kernel   the GTMiller and GT operators of the reference
+//   (experiments builds only) pair_kernel / pair_eq_kernel / miller_kernel / gt_op_kernel / gt_is_unity_kernel: the one-lane pairing
 #include "kernels_common.hpp"
 
 using namespace c12381;
@@ -123,6 +121,9 @@ __global__ void __launch_bounds__(BLOCK, 2) g2_add_kernel(size_t n, const uint8_
     g2_store_affine(out + (size_t)fmt * i, p, fmt, !ok);
 }
 
+#ifdef C12381_EXPERIMENTS
+// The first design — one pairing per lane (pairing.hpp) — superseded by the three-lane kernels of k_pair3.hip; kept in experiments
+// builds as an independent implementation for whole-batch cross-checks (tests/test_gpu_variants.py, C12381_PAIR_LANES=1).
 __global__ void __launch_bounds__(BLOCK, 2) pair_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -155,6 +156,8 @@ __global__ void __launch_bounds__(BLOCK, 2) pair_eq_kernel(size_t n, const uint8
     out[i] = valid ? (fp12_is_one(g) ? 1 : 0) : 0xff;
 }
 
+#endif  // C12381_EXPERIMENTS
+
 // ECP2_fromOctet ecp2_BLS12381.cpp:225-266 for 97-byte input: any tag other than 04 is "compressed, sign = tag & 1"
 __global__ void __launch_bounds__(BLOCK, 2) g2_decompress_kernel(size_t n, const uint8_t* in, uint8_t* out, uint8_t* status) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -173,6 +176,7 @@ __global__ void __launch_bounds__(BLOCK, 2) g2_decompress_kernel(size_t n, const
     status[i] = tag == 0 ? 1 : (ok ? 1 : 0);
 }
 
+#ifdef C12381_EXPERIMENTS
 // pair_ate alone: the Miller value as FP12_toOctet bytes (the same field element as the reference's)
 __global__ void __launch_bounds__(BLOCK, 2) miller_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* out, int* bad_flag) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -206,5 +210,7 @@ __global__ void __launch_bounds__(BLOCK, 2) gt_is_unity_kernel(size_t n, const u
     gt_load576(x, a + 576 * i);
     out[i] = fp12_is_one(x) ? 1 : 0;
 }
+
+#endif  // C12381_EXPERIMENTS
 
 }  // namespace c12381

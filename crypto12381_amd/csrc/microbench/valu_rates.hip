@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <algorithm>
 #include <vector>
 #include <string>
 
@@ -22,15 +23,18 @@ constexpr int ITERS = 4096;
 // ---------------------------------------------------------------- part 1
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
+// clk[4 * wave + {0,1}] = s_memtime (shader cycles), [2,3] = s_memrealtime (100 MHz) around the loop: the in-kernel clock
+// is d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6)
 template <int KIND>
-__global__ void __launch_bounds__(256) rate_kernel(uint32_t* out, uint32_t seed) {
+__global__ void __launch_bounds__(256) rate_kernel(uint32_t* out, uint32_t seed, unsigned long long* clk, int iters) {
     uint32_t a = seed + threadIdx.x, b = seed * 3 + blockIdx.x;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime();
     uint64_t acc[8];
     uint32_t r[8];
     double d[8];
     for (int i = 0; i < 8; ++i) { acc[i] = a + i; r[i] = b + i; d[i] = (double)(a + i); }
     double da = (double)a * 1e-9, db = (double)b * 1e-9;
-    for (int it = 0; it < ITERS; ++it) {
+    for (int it = 0; it < iters; ++it) {
         if constexpr (KIND == 0) {       // v_mad_u64_u32, 8 independent 64-bit accumulators
 #define X(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b) : "vcc");
             REP8(X) REP8(X)
@@ -98,6 +102,26 @@ __global__ void __launch_bounds__(256) rate_kernel(uint32_t* out, uint32_t seed)
 #define X(i) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(r[i]) : "v"(a));
             REP8(X) REP8(X)
 #undef X
+        } else if constexpr (KIND == 16) { // v_mad_i64_i32, the instruction every limb product of fp.hpp compiles to (carry-out in an SGPR pair, as the compiler emits it)
+#define X(i) asm volatile("v_mad_i64_i32 %0, s[20:21], %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b) : "s20", "s21");
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 17) { // v_mad_i64_i32, ONE dependent accumulator chain (a column of fp_mul)
+            asm volatile("v_mad_i64_i32 %0, s[20:21], %1, %2, %0\n\tv_mad_i64_i32 %0, s[20:21], %1, %2, %0\n\t"
+                         "v_mad_i64_i32 %0, s[20:21], %1, %2, %0\n\tv_mad_i64_i32 %0, s[20:21], %1, %2, %0\n\t"
+                         "v_mad_i64_i32 %0, s[20:21], %1, %2, %0\n\tv_mad_i64_i32 %0, s[20:21], %1, %2, %0\n\t"
+                         "v_mad_i64_i32 %0, s[20:21], %1, %2, %0\n\tv_mad_i64_i32 %0, s[20:21], %1, %2, %0\n\t"
+                         "v_mad_i64_i32 %0, s[20:21], %1, %2, %0\n\tv_mad_i64_i32 %0, s[20:21], %1, %2, %0\n\t"
+                         "v_mad_i64_i32 %0, s[20:21], %1, %2, %0\n\tv_mad_i64_i32 %0, s[20:21], %1, %2, %0\n\t"
+                         "v_mad_i64_i32 %0, s[20:21], %1, %2, %0\n\tv_mad_i64_i32 %0, s[20:21], %1, %2, %0\n\t"
+                         "v_mad_i64_i32 %0, s[20:21], %1, %2, %0\n\tv_mad_i64_i32 %0, s[20:21], %1, %2, %0"
+                         : "+v"(acc[0]) : "v"(a), "v"(b) : "s20", "s21");
+        } else if constexpr (KIND == 18) { // the mix of an fp_mul column scan: 12 v_mad_i64_i32 + 1 v_mul_lo + 1 v_and + 1 v_ashrrev_i64 + 1 v_and
+#define X(i) asm volatile("v_mad_i64_i32 %0, s[20:21], %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b) : "s20", "s21");
+            REP8(X) X(0) X(1) X(2) X(3)
+#undef X
+            asm volatile("v_mul_lo_u32 %0, %1, %2\n\tv_and_b32 %0, 0xfffffff, %0" : "+v"(r[0]) : "v"((uint32_t)acc[4]), "v"(a));
+            asm volatile("v_ashrrev_i64 %0, 28, %0\n\tv_and_b32 %1, 0xfffffff, %1" : "+v"(acc[5]), "+v"(r[1]));
         } else if constexpr (KIND == 15) { // v_lshl_add_u32
 #define X(i) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(r[i]) : "v"(a));
             REP8(X) REP8(X)
@@ -107,6 +131,11 @@ __global__ void __launch_bounds__(256) rate_kernel(uint32_t* out, uint32_t seed)
     uint32_t s = 0;
     for (int i = 0; i < 8; ++i) s += (uint32_t)acc[i] + (uint32_t)(acc[i] >> 32) + r[i] + (uint32_t)d[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), w1 = __builtin_amdgcn_s_memrealtime();
+    if (clk && (threadIdx.x & 63) == 0) {
+        const size_t w = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        clk[4 * w] = t0; clk[4 * w + 1] = t1; clk[4 * w + 2] = w0; clk[4 * w + 3] = w1;
+    }
 }
 
 // ---------------------------------------------------------------- part 2: S (12 x 32)
@@ -215,30 +244,42 @@ __global__ void __launch_bounds__(256) fpmul_kernel(uint32_t* io, int n_limbs, i
 static uint64_t lcg_state = 0x9e3779b97f4a7c15ull;
 static uint32_t lcg() { lcg_state = lcg_state * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(lcg_state >> 32); }
 
+// waves: 8 per SIMD (blocks = 256 CUs x 8) as in round 1, or 2 per SIMD (the occupancy every kernel of the library runs at)
 template <int KIND>
-int run_rate(const char* name, int ops_per_iter, FILE* fo) {
-    const int blocks = 256 * 8, threads = 256;
+int run_rate(const char* name, int ops_per_iter, FILE* fo, int blocks = 256 * 8, int iters = ITERS * 16) {
+    const int threads = 256;
     uint32_t* d;
+    unsigned long long* dclk;
+    const size_t nw = (size_t)blocks * threads / 64;
     CK(hipMalloc(&d, (size_t)blocks * threads * 4));
+    CK(hipMalloc(&dclk, nw * 32));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    rate_kernel<KIND><<<blocks, threads>>>(d, 12345);
+    rate_kernel<KIND><<<blocks, threads>>>(d, 12345, dclk, iters);
     CK(hipDeviceSynchronize());
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0));
-        rate_kernel<KIND><<<blocks, threads>>>(d, 12345 + rep);
+        rate_kernel<KIND><<<blocks, threads>>>(d, 12345 + rep, dclk, iters);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (ms < best) best = ms;
     }
-    double ops = (double)blocks * threads * ITERS * ops_per_iter;
+    std::vector<unsigned long long> hc(nw * 4);
+    CK(hipMemcpy(hc.data(), dclk, nw * 32, hipMemcpyDeviceToHost));
+    std::vector<double> ghz(nw);
+    for (size_t w = 0; w < nw; ++w) ghz[w] = (double)(hc[4 * w + 1] - hc[4 * w]) / (double)(hc[4 * w + 3] - hc[4 * w + 2]) * 0.1;
+    std::sort(ghz.begin(), ghz.end());
+    const double clock_ghz = ghz[nw / 2];
+    double ops = (double)blocks * threads * iters * ops_per_iter;
     double rate = ops / (best * 1e-3);
-    // lanes/clk/CU at 2.4 GHz nominal
-    double per_clk_cu = rate / 2.4e9 / 256.0;
-    printf("RATE %-28s %8.3f ms  %.4e lane-ops/s  %.2f lane-ops/clk/CU@2.4GHz\n", name, best, rate, per_clk_cu);
-    if (fo) fprintf(fo, "RATE %s %.6f %.6e %.3f\n", name, best, rate, per_clk_cu);
-    CK(hipFree(d));
+    // lanes per clock and CU at the nominal 2.4 GHz and at the clock the chip held inside this kernel
+    double per_clk_cu = rate / 2.4e9 / 256.0, per_clk_cu_real = rate / (clock_ghz * 1e9) / 256.0;
+    printf("RATE %-28s waves/SIMD %d  %8.3f ms  %.4e lane-ops/s  %.2f lane-ops/clk/CU@2.4GHz  in-kernel clock %.3f GHz -> %.2f lane-ops/clk/CU\n",
+           name, blocks / 256, best, rate, per_clk_cu, clock_ghz, per_clk_cu_real);
+    if (fo) fprintf(fo, "RATE %s waves_per_simd=%d ms=%.6f lane_ops_per_s=%.6e per_clk_cu_at_2.4GHz=%.3f in_kernel_clock_GHz=%.3f per_clk_cu_at_that_clock=%.3f\n",
+                    name, blocks / 256, best, rate, per_clk_cu, clock_ghz, per_clk_cu_real);
+    CK(hipFree(d)); CK(hipFree(dclk));
     return 0;
 }
 
@@ -309,6 +350,16 @@ int main(int argc, char** argv) {
     if (run_rate<0>("v_mad_u64_u32", 16, fo)) return 1;
     if (run_rate<13>("v_mad_u64_u32_sgprcarry", 16, fo)) return 1;
     if (run_rate<12>("v_mad_u64_u32_dependent", 16, fo)) return 1;
+    // the instruction the library's limb products are (round 3): 8 and 2 waves per SIMD, independent and dependent chains,
+    // and the instruction mix of one fp_mul column
+    if (run_rate<16>("v_mad_i64_i32", 16, fo)) return 1;
+    if (run_rate<16>("v_mad_i64_i32", 16, fo, 256 * 2)) return 1;
+    if (run_rate<17>("v_mad_i64_i32_dependent", 16, fo)) return 1;
+    if (run_rate<17>("v_mad_i64_i32_dependent", 16, fo, 256 * 2)) return 1;
+    if (run_rate<18>("fp_mul_column_mix(12mad+4)", 16, fo)) return 1;
+    if (run_rate<18>("fp_mul_column_mix(12mad+4)", 16, fo, 256 * 2)) return 1;
+    if (run_rate<0>("v_mad_u64_u32", 16, fo, 256 * 2)) return 1;
+    if (run_rate<5>("v_add_u32", 16, fo, 256 * 2)) return 1;
     if (run_rate<1>("v_mul_lo_u32", 16, fo)) return 1;
     if (run_rate<2>("v_mul_hi_u32", 16, fo)) return 1;
     if (run_rate<3>("v_mad_u32_u24", 16, fo)) return 1;

@@ -60,7 +60,9 @@ int c12381_set_stream(c12381_ctx* ctx, void* hip_stream);
 int c12381_sync(c12381_ctx* ctx);
 /* Per-kernel timing with HIP events on the context's stream (used by bench.py for the roofline
  * figure).  enable != 0 starts a fresh recording; kind: 0 = G1 scalar-mul kernel, 1 = G1 finish
- * (inversion + encode) kernel, 2 = G2 scalar-mul kernel, 3 = pairing kernel, 4 = pairing-equality kernel.  c12381_profile_read synchronises the stream. */
+ * (inversion + encode) kernel, 2 = G2 scalar-mul kernel, 3 = pairing kernel, 4 = pairing-equality kernel, 5 = MSM bucket kernel,
+ * 6 = Miller-loop kernel (c12381_miller_batch_dev), 7 = GT operation / final-exponentiation kernel (c12381_gt_op_batch_dev).
+ * c12381_profile_read synchronises the stream. */
 int c12381_profile(c12381_ctx* ctx, int enable);
 int c12381_profile_read(c12381_ctx* ctx, int kind, double* total_ms, uint64_t* launches);
 /* ABI version: major << 16 | minor */

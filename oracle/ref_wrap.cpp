@@ -157,6 +157,46 @@ int ref_g1_add_batch(size_t n, const uint8_t* a96, const uint8_t* b96, uint8_t* 
     return 0;
 }
 
+// negate(point1&) / sub(point1&, point1&) / equal(point1&, point1&) — src/miracl_core_interface.cpp:124-127, 139-147
+// (ECP_neg, ECP_sub, ECP_equals).  equal: out[i] = the seam's return value (1 / 0).
+int ref_g1_neg_batch(size_t n, const uint8_t* a96, uint8_t* out, int out_fmt) {
+    for (size_t i = 0; i < n; ++i) {
+        mc::point1 A;
+        if (!g1_load(A, a96 + 96 * i)) return -2;
+        mc::negate(A);
+        g1_store(out + (size_t)out_fmt * i, A, out_fmt);
+    }
+    return 0;
+}
+int ref_g1_sub_batch(size_t n, const uint8_t* a96, const uint8_t* b96, uint8_t* out, int out_fmt) {
+    for (size_t i = 0; i < n; ++i) {
+        mc::point1 A, B;
+        if (!g1_load(A, a96 + 96 * i) || !g1_load(B, b96 + 96 * i)) return -2;
+        mc::sub(A, B);
+        g1_store(out + (size_t)out_fmt * i, A, out_fmt);
+    }
+    return 0;
+}
+int ref_g1_equal_batch(size_t n, const uint8_t* a96, const uint8_t* b96, uint8_t* out) {
+    for (size_t i = 0; i < n; ++i) {
+        mc::point1 A, B;
+        if (!g1_load(A, a96 + 96 * i) || !g1_load(B, b96 + 96 * i)) return -2;
+        out[i] = (uint8_t)mc::equal(A, B);
+    }
+    return 0;
+}
+// the same on values that are NOT fresh from the decoder: A = a + b computed through the seam (projective inside the
+// reference), compared with the decoded c — ECP_equals cross-multiplies, the shim compares canonical bytes
+int ref_g1_equal_sum_batch(size_t n, const uint8_t* a96, const uint8_t* b96, const uint8_t* c96, uint8_t* out) {
+    for (size_t i = 0; i < n; ++i) {
+        mc::point1 A, B, C;
+        if (!g1_load(A, a96 + 96 * i) || !g1_load(B, b96 + 96 * i) || !g1_load(C, c96 + 96 * i)) return -2;
+        mc::add(A, B);
+        out[i] = (uint8_t)mc::equal(A, C);
+    }
+    return 0;
+}
+
 // from_bytes(point1&, bytes_view&) on 49-byte compressed input; leading 0x00 => infinity
 // as in include/crypto12381/g1_point.hpp:89-93.  status[i] = 1 ok / 0 reject.
 int ref_g1_decompress_batch(size_t n, const uint8_t* in49, uint8_t* out96, uint8_t* status) {
@@ -234,6 +274,43 @@ int ref_g1_sum_of_products(int n, const uint8_t* pts96, const uint8_t* scalars32
     mc::point1 R;
     mc::sum_of_products(R, n, P.data(), (const mc::big*)K.data());
     g1_store(out, R, out_fmt);
+    return 0;
+}
+
+// negate(point2&) / sub(point2&, point2&) / equal(point2&, point2&) — src/miracl_core_interface.cpp:207-226 (ECP2_neg, ECP2_sub, ECP2_equals)
+int ref_g2_neg_batch(size_t n, const uint8_t* a192, uint8_t* out, int out_fmt) {
+    for (size_t i = 0; i < n; ++i) {
+        mc::point2 A;
+        if (!g2_load(A, a192 + 192 * i)) return -2;
+        mc::negate(A);
+        g2_store(out + (size_t)out_fmt * i, A, out_fmt);
+    }
+    return 0;
+}
+int ref_g2_sub_batch(size_t n, const uint8_t* a192, const uint8_t* b192, uint8_t* out, int out_fmt) {
+    for (size_t i = 0; i < n; ++i) {
+        mc::point2 A, B;
+        if (!g2_load(A, a192 + 192 * i) || !g2_load(B, b192 + 192 * i)) return -2;
+        mc::sub(A, B);
+        g2_store(out + (size_t)out_fmt * i, A, out_fmt);
+    }
+    return 0;
+}
+int ref_g2_equal_batch(size_t n, const uint8_t* a192, const uint8_t* b192, uint8_t* out) {
+    for (size_t i = 0; i < n; ++i) {
+        mc::point2 A, B;
+        if (!g2_load(A, a192 + 192 * i) || !g2_load(B, b192 + 192 * i)) return -2;
+        out[i] = (uint8_t)mc::equal(A, B);
+    }
+    return 0;
+}
+int ref_g2_equal_sum_batch(size_t n, const uint8_t* a192, const uint8_t* b192, const uint8_t* c192, uint8_t* out) {
+    for (size_t i = 0; i < n; ++i) {
+        mc::point2 A, B, C;
+        if (!g2_load(A, a192 + 192 * i) || !g2_load(B, b192 + 192 * i) || !g2_load(C, c192 + 192 * i)) return -2;
+        mc::add(A, B);
+        out[i] = (uint8_t)mc::equal(A, C);
+    }
     return 0;
 }
 
@@ -380,6 +457,26 @@ int ref_gt_op_batch(int op, size_t n, const uint8_t* a576, const uint8_t* b, uin
         } else return -1;
         mc::bytes_view vo{0, 576, (char*)out576 + 576 * i};
         mc::to_bytes(vo, r);
+    }
+    return 0;
+}
+
+// equal(fp12&, fp12&) — src/miracl_core_interface.cpp:266-269 (FP12_equals); with_product: compare a * b (computed through the
+// seam's multiply) with c instead of a with b
+int ref_gt_equal_batch(size_t n, const uint8_t* a576, const uint8_t* b576, const uint8_t* c576, uint8_t* out) {
+    for (size_t i = 0; i < n; ++i) {
+        mc::fp12 x, y, z;
+        char ba[576], bb[576], bc[576];
+        std::memcpy(ba, a576 + 576 * i, 576); std::memcpy(bb, b576 + 576 * i, 576);
+        mc::bytes_view va{576, 576, ba}, vb{576, 576, bb};
+        mc::from_bytes(x, va); mc::from_bytes(y, vb);
+        if (c576) {
+            std::memcpy(bc, c576 + 576 * i, 576);
+            mc::bytes_view vc{576, 576, bc};
+            mc::from_bytes(z, vc);
+            mc::multiply(x, y);
+            out[i] = (uint8_t)mc::equal(x, z);
+        } else out[i] = (uint8_t)mc::equal(x, y);
     }
     return 0;
 }

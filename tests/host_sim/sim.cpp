@@ -17,6 +17,10 @@ static void load_raw(uint32_t* w, const uint8_t* p, int nwords) { std::memcpy(w,
 
 extern "C" {
 
+// operation counters (fp.hpp): reset / read.  cols = scanned product columns (27 per 14 x 14 limb product), reds = reductions
+void sim_ops_reset(void) { g_ops_cols = 0; g_ops_reds = 0; }
+void sim_ops_read(unsigned long long* cols, unsigned long long* reds) { *cols = g_ops_cols.load(); *reds = g_ops_reds.load(); }
+
 // op: 0 mul 1 add 2 sub 3 sqr 4 neg 5 inv (divsteps) 6 sqrt-candidate 7 mul_small(12) 8 norm1 round trip 9 inv (Fermat)
 int sim_fp_op_batch(int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
     for (size_t i = 0; i < n; ++i) {
@@ -95,6 +99,7 @@ int sim_glv_split(const uint8_t* scalar32, uint32_t* k0, uint32_t* k1) {
 #include "../../crypto12381_amd/csrc/fp2.hpp"
 #include "../../crypto12381_amd/csrc/fp12.hpp"
 #include "../../crypto12381_amd/csrc/g2.hpp"
+#include "../../crypto12381_amd/csrc/g2h.hpp"
 #include "../../crypto12381_amd/csrc/pairing.hpp"
 
 static void fp2_from_bytes96(fp2& r, const uint8_t* p) {      // b || a
@@ -122,6 +127,36 @@ int sim_g2_mul_batch(size_t n, const uint8_t* pts192, const uint8_t* scalars32, 
         scalar_from_raw32(k, rs);
         g2p acc;
         g2_scalar_mul(acc, qx, qy, inf, k, tab);
+        uint8_t* o = out + (size_t)fmt * i;
+        if (fp2_is_zero(acc.z)) { std::memset(o, 0, fmt); continue; }
+        fp2 zn, zi, ax, ay;
+        fp2_norm1(zn, acc.z);
+        fp2_inv(zi, zn);
+        fp2_mul(ax, acc.x, zi); fp2_mul(ay, acc.y, zi);
+        if (fmt == 192) { fp2_to_bytes96(o, ax); fp2_to_bytes96(o + 96, ay); }
+        else { o[0] = (uint8_t)(0x02 | fp2_sign(ay)); fp2_to_bytes96(o + 1, ax); }
+    }
+    return 0;
+}
+
+// the TWO-lanes-per-point form of the same multiplication (k_g2h.hip: g2_scalar_mul<fp2h>): both halves in one object, the
+// per-lane routines of fp2h.hpp run once per role, so their limb / value bounds are asserted here
+int sim_g2h_mul_batch(size_t n, const uint8_t* pts192, const uint8_t* scalars32, uint8_t* out, int fmt) {
+    std::vector<int32_t> tabv(2 * G2H_TAB_DWORDS + 4);
+    int32_t* tab = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(tabv.data()) + 15) & ~(uintptr_t)15);
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t rp[48], rs[8], k[8];
+        load_raw(rp, pts192 + 192 * i, 48); load_raw(rs, scalars32 + 32 * i, 8);
+        const bool inf = raw_all_zero(rp, 48);
+        fp2 qx, qy;
+        fp2_from_bytes96(qx, pts192 + 192 * i); fp2_from_bytes96(qy, pts192 + 192 * i + 96);
+        scalar_from_raw32(k, rs);
+        fp2h hx, hy;
+        fp2h_from(hx, qx); fp2h_from(hy, qy);
+        g2hp hacc;
+        g2_scalar_mul(hacc, hx, hy, inf, k, tab);
+        g2p acc;
+        fp2h_to(acc.x, hacc.x); fp2h_to(acc.y, hacc.y); fp2h_to(acc.z, hacc.z);
         uint8_t* o = out + (size_t)fmt * i;
         if (fp2_is_zero(acc.z)) { std::memset(o, 0, fmt); continue; }
         fp2 zn, zi, ax, ay;

@@ -220,6 +220,7 @@ def test_queue_timeout_is_an_internal_error_with_poisoned_outputs():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     e = dict(os.environ)
-    e.update({"C12381_PAIR_SPIN_LIMIT": "-1", "C12381_PAIR_QUEUE": "1"})
+    # the forced time-out exists in the experiments build only (crypto12381_amd/build.py); the product library has no such switch
+    e.update({"C12381_PAIR_SPIN_LIMIT": "-1", "C12381_PAIR_QUEUE": "1", "C12381_LIB": os.path.join(root, "crypto12381_amd", "lib", "libc12381_hip_exp.so")})
     r = subprocess.run([sys.executable, "-c", POISON_CODE], env=e, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "poison ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -98,7 +98,9 @@ def test_msm_in_parts(oracle_port):
         "print(c.g1_msm(pts, sc, 49).hex())\n")
     env = dict(os.environ)
     ref = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1]
+    # the per-pass limit (2^26 terms) can be lowered only in the experiments build — same sources, same multi-part code
     env["C12381_MSM_MAX_TERMS"] = "4500"
+    env["C12381_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "crypto12381_amd", "lib", "libc12381_hip_exp.so")
     parts = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1]
     assert parts == ref
     from crypto12381_amd import Context

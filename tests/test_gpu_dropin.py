@@ -91,3 +91,94 @@ def test_dropin_config1_bilinearity(shim):
     lhs = shim.pair(shim.g1_mul(Pp, x, 96), shim.g2_mul(Qq, y, 192))
     assert lhs.hex() == g["pair_Px_Qy"]
     assert shim.gt_op("pow", shim.pair(Pp, Qq), bytes.fromhex(g["xy"])) == lhs
+
+
+def test_dropin_negate_sub_equal(shim, oracle_ref):
+    """The seven seam functions no other test reaches — negate / sub / equal on point1 and point2, equal on fp12
+    (/root/reference/src/miracl_core_interface.cpp:124-147, 207-226, 266-269: ECP_neg, ECP_sub, ECP_equals, ECP2_*, FP12_equals) —
+    through the shim against the unmodified reference: ordinary points, P - P, infinity on either side, equal and unequal
+    operands, and values that are results of seam arithmetic rather than fresh from the decoder.  (A point with y = 0 does
+    not exist on either curve: #E(Fp) and #E'(Fp2) are odd, so there is no point of order two.)"""
+    import ctypes
+    sz = ctypes.c_size_t
+    g = golden("g1")
+    P = cat(g["points"])[:96 * 6]
+    inf1 = bytes(96)
+    A1 = P + P[:96 * 2] + inf1 + P[:96] + inf1                  # a
+    B1 = P[96:] + P[:96] + P[:96 * 2] + P[:96] + inf1 + inf1    # b: different points, then P - P twice, inf - P, P - inf, inf - inf
+    n1 = len(A1) // 96
+    g2v = golden("g2")
+    Q = cat(g2v["points"])[:192 * 4]
+    inf2 = bytes(192)
+    A2 = Q + Q[:192 * 2] + inf2 + Q[:192] + inf2
+    B2 = Q[192:] + Q[:192] + Q[:192 * 2] + Q[:192] + inf2 + inf2
+    n2 = len(A2) // 192
+    gp = golden("pairing")
+    gt = cat(gp["gt"])
+    gta, gtb, gtm = gt[:576 * 4], gt[576 * 4:576 * 8], cat(gp["gt_mul"])
+    res = {}
+    for name, lib in (("shim", shim), ("ref", oracle_ref)):
+        L = lib.lib
+        r = {}
+        for fmt in (96, 49):
+            o = ctypes.create_string_buffer(fmt * n1)
+            assert L.ref_g1_neg_batch(sz(n1), A1, o, fmt) == 0
+            r["g1_neg%d" % fmt] = o.raw
+            o = ctypes.create_string_buffer(fmt * n1)
+            assert L.ref_g1_sub_batch(sz(n1), A1, B1, o, fmt) == 0
+            r["g1_sub%d" % fmt] = o.raw
+        o = ctypes.create_string_buffer(n1)
+        assert L.ref_g1_equal_batch(sz(n1), A1, B1, o) == 0
+        r["g1_eq"] = o.raw
+        o = ctypes.create_string_buffer(n1)
+        assert L.ref_g1_equal_batch(sz(n1), A1, A1, o) == 0
+        r["g1_eq_self"] = o.raw
+        # (a + b) == c with c = the golden sum (equal) and with c = a (unequal unless b is infinity)
+        ga, gb, gs = cat(g["add_a"]), cat(g["add_b"]), cat(g["add96"])
+        m = len(ga) // 96
+        o = ctypes.create_string_buffer(m)
+        assert L.ref_g1_equal_sum_batch(sz(m), ga, gb, gs, o) == 0
+        r["g1_eq_sum"] = o.raw
+        o = ctypes.create_string_buffer(m)
+        assert L.ref_g1_equal_sum_batch(sz(m), ga, gb, ga, o) == 0
+        r["g1_eq_sum_ne"] = o.raw
+        for fmt in (192, 97):
+            o = ctypes.create_string_buffer(fmt * n2)
+            assert L.ref_g2_neg_batch(sz(n2), A2, o, fmt) == 0
+            r["g2_neg%d" % fmt] = o.raw
+            o = ctypes.create_string_buffer(fmt * n2)
+            assert L.ref_g2_sub_batch(sz(n2), A2, B2, o, fmt) == 0
+            r["g2_sub%d" % fmt] = o.raw
+        o = ctypes.create_string_buffer(n2)
+        assert L.ref_g2_equal_batch(sz(n2), A2, B2, o) == 0
+        r["g2_eq"] = o.raw
+        o = ctypes.create_string_buffer(n2)
+        assert L.ref_g2_equal_batch(sz(n2), A2, A2, o) == 0
+        r["g2_eq_self"] = o.raw
+        ga2, gb2, gs2 = cat(g2v["add_a"]), cat(g2v["add_b"]), cat(g2v["add192"])
+        m2 = len(ga2) // 192
+        o = ctypes.create_string_buffer(m2)
+        assert L.ref_g2_equal_sum_batch(sz(m2), ga2, gb2, gs2, o) == 0
+        r["g2_eq_sum"] = o.raw
+        o = ctypes.create_string_buffer(4)
+        assert L.ref_gt_equal_batch(sz(4), gta, gtb, None, o) == 0
+        r["gt_eq_ne"] = o.raw
+        o = ctypes.create_string_buffer(4)
+        assert L.ref_gt_equal_batch(sz(4), gta, gta, None, o) == 0
+        r["gt_eq_self"] = o.raw
+        o = ctypes.create_string_buffer(4)
+        assert L.ref_gt_equal_batch(sz(4), gta, gtb, gtm, o) == 0             # a * b == the golden product
+        r["gt_eq_prod"] = o.raw
+        o = ctypes.create_string_buffer(4)
+        assert L.ref_gt_equal_batch(sz(4), gta, gtb, gta, o) == 0             # a * b != a
+        r["gt_eq_prod_ne"] = o.raw
+        res[name] = r
+    assert res["shim"].keys() == res["ref"].keys()
+    for k in res["ref"]:
+        assert res["shim"][k] == res["ref"][k], k
+    # and the values are what the group laws say: P - P = infinity, inf - P = -P, P - inf = P
+    s96 = res["ref"]["g1_sub96"]
+    assert s96[96 * 6:96 * 8] == bytes(192) and s96[96 * 8:96 * 9] == res["ref"]["g1_neg96"][:96] and s96[96 * 9:96 * 10] == P[:96] and s96[96 * 10:] == inf1
+    assert res["ref"]["g1_eq_self"] == b"\x01" * n1 and res["ref"]["g1_eq"][:6] == bytes(6) and res["ref"]["g1_eq"][6:8] == b"\x01\x01"
+    assert res["ref"]["g1_eq_sum"] == b"\x01" * (len(cat(g["add_a"])) // 96)
+    assert res["ref"]["gt_eq_self"] == b"\x01" * 4 and res["ref"]["gt_eq_ne"] == bytes(4) and res["ref"]["gt_eq_prod"] == b"\x01" * 4

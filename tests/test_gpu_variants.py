@@ -1,6 +1,8 @@
-"""GPU parity of the code paths that are selected through the environment (A/B switches kept for measurements):
+"""GPU parity of the code paths that the EXPERIMENTS build selects through the environment (A/B switches kept for measurements):
 the one-lane pairing kernels, the forced naive / bucket MSM, the generic path behind the fixed-base entry points, the
-one-lane-per-point G2 kernel, raw line tables of a fixed G2 argument, the queue split override.
+one-lane-per-point G2 kernel, raw line tables of a fixed G2 argument, the queue split override.  The product library
+(libc12381_hip.so) reads no environment variable and has none of these paths; the switches exist in libc12381_hip_exp.so
+(-DC12381_EXPERIMENTS, same sources), which every child process here loads through C12381_LIB.
 Each variant runs in a child process (the switches are read once per process) against the golden vectors."""
 import os
 import subprocess
@@ -13,6 +15,16 @@ from util import golden as golden_g
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXP_LIB = os.path.join(ROOT, "crypto12381_amd", "lib", "libc12381_hip_exp.so")
+
+
+def exp_env(extra):
+    e = dict(os.environ)
+    for k in [k for k in e if k.startswith("C12381_") and k != "C12381_LIB"]:
+        del e[k]
+    e["C12381_LIB"] = EXP_LIB
+    e.update(extra)
+    return e
 
 CODE = r"""
 import sys
@@ -53,8 +65,7 @@ print('variant ok')
                          ids=["one-lane-pairing", "msm-naive", "msm-bucket", "fixed-base-off", "pair-queue-on", "pair-queue-off", "g2-one-lane", "raw-line-tables",
                               "queue-groups-override", "defaults"])
 def test_environment_selected_paths(env):
-    e = dict(os.environ)
-    e.update(env)
+    e = exp_env(env)
     r = subprocess.run([sys.executable, "-c", CODE], env=e, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "variant ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
@@ -91,14 +102,16 @@ def test_full_size_digests_across_implementations():
     kernel, two-lane vs one-lane G2 multiplication, table-driven vs generic G1 multiplication.  The sampled-lane
     comparisons against the CPU oracle (test_gpu_full_size.py, test_gpu_pairing.py) cannot see a fault that hits a few
     lanes of a loaded machine; this can."""
-    def run(env):
-        e = dict(os.environ)
-        e.update(env)
+    def run(env, product=False):
+        e = exp_env(env)
+        if product:
+            del e["C12381_LIB"]
         r = subprocess.run([sys.executable, "-c", DIGEST_CODE], env=e, cwd=ROOT, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
         return dict(line.split() for line in r.stdout.strip().splitlines() if " " in line)
 
-    base = run({})
+    base = run({}, product=True)                                   # the product library
+    assert run({}) == base                                         # the experiments build with no switch set is the same path
     assert base["g1_fixed"] == base["g1_mul"]                      # table-driven == generic, all 2^18 outputs
     one = run({"C12381_PAIR_LANES": "1", "C12381_G2_LANES": "1", "C12381_FIXED_BASE": "0"})
     assert one == base
@@ -127,3 +140,13 @@ def test_ragged_sizes_vs_oracle(oracle_port):
     for n in (1, 2, 20, 21, 22, 41, 42, 43, 63, 64, 85):
         assert ctx.pair(P[:96 * n], Q[:192 * n]) == oracle_port.pair(P[:96 * n], Q[:192 * n], 16), n
     ctx.close()
+
+
+def test_product_library_ignores_the_switches():
+    """libc12381_hip.so reads no tuning variable: with the variable that makes every queue hand-over of the experiments build fail
+    (C12381_PAIR_SPIN_LIMIT=-1, forced queue) set in the environment it still returns the golden pairings."""
+    e = dict(os.environ)
+    e.pop("C12381_LIB", None)
+    e.update({"C12381_PAIR_SPIN_LIMIT": "-1", "C12381_PAIR_QUEUE": "1", "C12381_PAIR_LANES": "1", "C12381_MSM": "naive", "C12381_FIXED_BASE": "0"})
+    r = subprocess.run([sys.executable, "-c", CODE], env=e, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "variant ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

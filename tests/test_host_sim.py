@@ -123,14 +123,31 @@ def test_sim_g1_mul_random_vs_oracle(sim, oracle_port):
     assert out.raw == oracle_port.g1_mul(pts, sc, 49, 4)
 
 
-def test_sim_g2_mul_golden(sim):
+G2_FORMS = ("sim_g2_mul_batch", "sim_g2h_mul_batch")      # one lane per point (fp2) / two lanes per point (fp2h, k_g2h.hip)
+
+
+@pytest.mark.parametrize("form", G2_FORMS)
+def test_sim_g2_mul_golden(sim, form):
     g = golden("g2")
     pts, sc = cat(g["points"]), cat(g["scalars"])
     n = len(pts) // 192
     for fmt, key in ((97, "mul97"), (192, "mul192")):
         out = ctypes.create_string_buffer(fmt * n)
-        assert sim.sim_g2_mul_batch(sz(n), pts, sc, out, fmt) == 0
+        assert getattr(sim, form)(sz(n), pts, sc, out, fmt) == 0
         assert out.raw == cat(g[key])
+
+
+@pytest.mark.parametrize("form", G2_FORMS)
+def test_sim_g2_mul_random_vs_oracle(sim, oracle_port, form):
+    """random points of G2, scalars up to 2^256 and the edge scalars 0, 1, r - 1, r, r + 1, 2^256 - 1 against the oracle"""
+    gen = bytes.fromhex(golden("g2")["generator"])
+    n = 24
+    pts = oracle_port.g2_mul(gen * n, scalars(511, n), 192) + bytes(192)
+    edge = b"".join(int(k).to_bytes(32, "big") for k in (0, 1, R - 1, R, R + 1, (1 << 256) - 1))
+    sc = scalars(512, n - 6, 1 << 256) + edge + scalars(513, 1)
+    out = ctypes.create_string_buffer(192 * (n + 1))
+    assert getattr(sim, form)(sz(n + 1), pts, sc, out, 192) == 0
+    assert out.raw == oracle_port.g2_mul(pts, sc, 192, 4)
 
 
 def test_sim_points_outside_the_subgroup(sim):
@@ -141,8 +158,9 @@ def test_sim_points_outside_the_subgroup(sim):
     assert sim.sim_g1_mul_batch(sz(6), pts, sc, out, 96) == 0 and out.raw == cat(g["offsubgroup_mul96"])
     g = golden("g2")
     pts, sc = cat(g["offsubgroup_points"]), cat(g["offsubgroup_scalars"])
-    out = ctypes.create_string_buffer(192 * 6)
-    assert sim.sim_g2_mul_batch(sz(6), pts, sc, out, 192) == 0 and out.raw == cat(g["offsubgroup_mul192"])
+    for form in G2_FORMS:
+        out = ctypes.create_string_buffer(192 * 6)
+        assert getattr(sim, form)(sz(6), pts, sc, out, 192) == 0 and out.raw == cat(g["offsubgroup_mul192"])
 
 
 def test_sim_small_scalars_outside_the_subgroup(sim):
@@ -162,14 +180,15 @@ def test_sim_small_scalars_outside_the_subgroup(sim):
     g = golden("g2")
     pts, sc = cat(g["offsubgroup_small_points"]), cat(g["offsubgroup_small_scalars"])
     n = len(sc) // 32
-    out = ctypes.create_string_buffer(192 * n)
-    assert sim.sim_g2_mul_batch(sz(n), pts, sc, out, 192) == 0
     exp = cat(g["offsubgroup_small_mul192"])
-    assert [out.raw[192 * i:192 * i + 192] == exp[192 * i:192 * i + 192] for i in range(n)] == [True] * n
     gen = bytes.fromhex(g["generator"])
-    out2 = ctypes.create_string_buffer(192 * n)
-    assert sim.sim_g2_mul_batch(sz(n), gen * n, sc, out2, 192) == 0
-    assert out2.raw[192:384] == gen and out2.raw[:192] == bytes(192)
+    for form in G2_FORMS:
+        out = ctypes.create_string_buffer(192 * n)
+        assert getattr(sim, form)(sz(n), pts, sc, out, 192) == 0
+        assert [out.raw[192 * i:192 * i + 192] == exp[192 * i:192 * i + 192] for i in range(n)] == [True] * n
+        out2 = ctypes.create_string_buffer(192 * n)
+        assert getattr(sim, form)(sz(n), gen * n, sc, out2, 192) == 0
+        assert out2.raw[192:384] == gen and out2.raw[:192] == bytes(192)
 
 
 def test_sim_pairing_golden(sim):

@@ -145,16 +145,45 @@ def test_reference_seeded_scalars(oracle_ref):
 
 
 def test_port_matches_reference_on_fresh_inputs(oracle_port, oracle_ref):
-    """Beyond the committed fixtures: fresh seeded inputs, port vs compiled reference."""
+    """Beyond the committed fixtures: the C restatement (the checker most -m gpu tests use) against the compiled reference on fresh
+    seeded inputs — 384 G1 and 256 G2 multiplications with scalars up to 2^256 and the edge scalars, additions, (de)compression,
+    64 pairings with their Miller values and final exponentiations, GT operations, the bucket product and sum_of_products."""
     from util import scalars
-    n = 12
+    n1, n2, npair = 384, 256, 64
     g1, g2 = oracle_ref.g1_generator(), oracle_ref.g2_generator()
-    pts = oracle_ref.g1_mul(g1 * n, scalars(901, n), 96)
-    q = oracle_ref.g2_mul(g2 * n, scalars(902, n), 192)
-    sc = scalars(903, n, 1 << 256)
-    assert oracle_port.g1_mul(pts, sc, 49, 2) == oracle_ref.g1_mul(pts, sc, 49, 2)
-    assert oracle_port.g2_mul(q, sc, 97, 2) == oracle_ref.g2_mul(q, sc, 97, 2)
-    assert oracle_port.pair(pts[:96 * 4], q[:192 * 4], 2) == oracle_ref.pair(pts[:96 * 4], q[:192 * 4], 2)
+    edge = b"".join(int(k).to_bytes(32, "big") for k in (0, 1, 2, R - 1, R, R + 1, (1 << 128) - 1, (1 << 256) - 1))
+    pts = oracle_ref.g1_mul(g1 * n1, scalars(901, n1), 96)
+    q = oracle_ref.g2_mul(g2 * n2, scalars(902, n2), 192, 4)
+    sc1 = scalars(903, n1 - 8, 1 << 256) + edge
+    sc2 = scalars(904, n2 - 8, 1 << 256) + edge
+    for fmt in (49, 96):
+        assert oracle_port.g1_mul(pts, sc1, fmt, 4) == oracle_ref.g1_mul(pts, sc1, fmt, 4)
+    for fmt in (97, 192):
+        assert oracle_port.g2_mul(q, sc2, fmt, 4) == oracle_ref.g2_mul(q, sc2, fmt, 4)
+    # additions incl. P + P, P + (-P) (the golden files hold the infinity cases), compression round trips
+    half = 96 * (n1 // 2)
+    assert oracle_port.g1_add(pts[:half], pts[half:], 96) == oracle_ref.g1_add(pts[:half], pts[half:], 96)
+    assert oracle_port.g1_add(pts[:half], pts[:half], 49) == oracle_ref.g1_add(pts[:half], pts[:half], 49)
+    h2 = 192 * (n2 // 2)
+    assert oracle_port.g2_add(q[:h2], q[h2:], 192) == oracle_ref.g2_add(q[:h2], q[h2:], 192)
+    c1 = oracle_ref.g1_mul(pts, b"".join((1).to_bytes(32, "big") for _ in range(n1)), 49, 4)
+    assert oracle_port.g1_decompress(c1) == oracle_ref.g1_decompress(c1)
+    c2 = oracle_ref.g2_mul(q, b"".join((1).to_bytes(32, "big") for _ in range(n2)), 97, 4)
+    assert oracle_port.g2_decompress(c2) == oracle_ref.g2_decompress(c2)
+    # pairings: whole value, Miller value, final exponentiation of the Miller value; one lane with each argument at infinity
+    p1 = pts[:96 * (npair - 2)] + bytes(96) + pts[:96]
+    q2 = q[:192 * (npair - 2)] + q[:192] + bytes(192)
+    gt_ref = oracle_ref.pair(p1, q2, 4)
+    assert oracle_port.pair(p1, q2, 4) == gt_ref
+    mil = oracle_ref.miller(p1, q2)
+    assert oracle_port.miller(p1, q2) == mil
+    assert oracle_port.fexp(mil) == oracle_ref.fexp(mil) == gt_ref
+    gta, gtb = gt_ref[:576 * 16], gt_ref[576 * 16:576 * 32]
+    assert oracle_port.gt_op("mul", gta, gtb) == oracle_ref.gt_op("mul", gta, gtb)
+    assert oracle_port.gt_op("pow", gta, sc1[:32 * 16]) == oracle_ref.gt_op("pow", gta, sc1[:32 * 16])
+    assert oracle_port.gt_op("pow", mil[:576 * 8], sc1[-32 * 8:]) == oracle_ref.gt_op("pow", mil[:576 * 8], sc1[-32 * 8:])    # non-unitary bases, edge exponents
+    # products: the header-level chain (g1_msm) and the boundary's sum_of_products
+    assert oracle_port.g1_msm(pts[:96 * 64], sc1[-32 * 64:], 49, 4) == oracle_ref.g1_msm(pts[:96 * 64], sc1[-32 * 64:], 49, 4)
 
 
 def test_hash_to_g1_and_zp_golden(orc):

@@ -199,6 +199,10 @@ def main():
     g3_ = f2mul(g2_, g)
     n2 = (g2_[0] * g2_[0] + g2_[1] * g2_[1]) % P       # psi^2 multiplies X by N(g^2), Y by N(g^3) (both in Fp)
     n3 = (g3_[0] * g3_[0] + g3_[1] * g3_[1]) % P
+    # shapes the device code relies on (g2.hpp g2_psi_signed): PSI1_X = c i, PSI3_X = -i, PSI1_Y = a(1 - i), PSI3_Y = -PSI1_Y, PSI2_Y = -1
+    psi3x, psi3y = (g2_[0] * n2 % P, g2_[1] * n2 % P), (g3_[0] * n3 % P, g3_[1] * n3 % P)
+    assert g2_[0] == 0 and psi3x == (0, P - 1) and n3 == P - 1
+    assert (g3_[0] + g3_[1]) % P == 0 and psi3y == ((P - g3_[0]) % P, (P - g3_[1]) % P)
     out.append("// psi^i(X,Y,Z) = (conj^i(X) * PSIi_X, conj^i(Y) * PSIi_Y, conj^i(Z)) for the G2 GS decomposition (PAIR_G2mul)\n")
     for nm, v in (("PSI1_X", g2_), ("PSI1_Y", g3_), ("PSI3_X", (g2_[0] * n2 % P, g2_[1] * n2 % P)), ("PSI3_Y", (g3_[0] * n3 % P, g3_[1] * n3 % P))):
         out.append(arr(nm + "_A", mont(v[0])))
