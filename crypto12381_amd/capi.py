@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("C12381_LIB") or os.path.join(_HERE, "lib", "libc12381
 E_ARG, E_HIP, E_POINT, E_NOMEM, E_INTERNAL = -1, -2, -3, -4, -5
 F_IN_SUBGROUP = 1
 F_MILLER_ONLY = 2
+F_COMPRESSED_IN = 4
 
 
 class C12381Error(RuntimeError):
@@ -56,8 +57,11 @@ def load_library() -> ctypes.CDLL:
             getattr(lib, name).argtypes = [vp, sz, vp, vp, vp, ci]
         for name in ("c12381_g2_msm", "c12381_g2_msm_dev"):
             getattr(lib, name).argtypes = [vp, sz, vp, vp, vp, ci]
-        for name in ("c12381_g1_mul_batch_flags", "c12381_g1_mul_batch_flags_dev", "c12381_g2_mul_batch_flags", "c12381_g2_mul_batch_flags_dev"):
+        for name in ("c12381_g1_mul_batch_flags", "c12381_g1_mul_batch_flags_dev", "c12381_g2_mul_batch_flags", "c12381_g2_mul_batch_flags_dev",
+                     "c12381_g1_msm_flags", "c12381_g1_msm_flags_dev"):
             getattr(lib, name).argtypes = [vp, sz, vp, vp, vp, ci, ctypes.c_uint]
+        for name in ("c12381_pair_batch_flags", "c12381_pair_batch_flags_dev"):
+            getattr(lib, name).argtypes = [vp, sz, vp, vp, vp, ctypes.c_uint]
         for name in ("c12381_pair_batch", "c12381_pair_batch_dev"):
             getattr(lib, name).argtypes = [vp, sz, vp, vp, vp]
         for name in ("c12381_pair_product_batch", "c12381_pair_product_batch_dev"):
@@ -167,17 +171,29 @@ class Context:
         self._ck(self.lib.c12381_g1_mul_batch(self.h, n, _p(pts), _p(scalars), _p(out), fmt), allow_point=not strict)
         return out.raw[:fmt * n]
 
-    def g1_mul_flags(self, pts: bytes, scalars: bytes, fmt: int = 49, flags: int = 0) -> bytes:
-        n = len(pts) // 96
+    def g1_mul_flags(self, pts: bytes, scalars: bytes, fmt: int = 49, flags: int = 0, strict: bool = True) -> bytes:
+        n = len(scalars) // 32
         out = ctypes.create_string_buffer(max(fmt * n, 1))
-        self._ck(self.lib.c12381_g1_mul_batch_flags(self.h, n, _p(pts), _p(scalars), _p(out), fmt, flags))
+        self._ck(self.lib.c12381_g1_mul_batch_flags(self.h, n, _p(pts), _p(scalars), _p(out), fmt, flags), allow_point=not strict)
         return out.raw[:fmt * n]
 
-    def g2_mul_flags(self, pts: bytes, scalars: bytes, fmt: int = 97, flags: int = 0) -> bytes:
-        n = len(pts) // 192
+    def g2_mul_flags(self, pts: bytes, scalars: bytes, fmt: int = 97, flags: int = 0, strict: bool = True) -> bytes:
+        n = len(scalars) // 32
         out = ctypes.create_string_buffer(max(fmt * n, 1))
-        self._ck(self.lib.c12381_g2_mul_batch_flags(self.h, n, _p(pts), _p(scalars), _p(out), fmt, flags))
+        self._ck(self.lib.c12381_g2_mul_batch_flags(self.h, n, _p(pts), _p(scalars), _p(out), fmt, flags), allow_point=not strict)
         return out.raw[:fmt * n]
+
+    def g1_msm_flags(self, pts: bytes, scalars: bytes, fmt: int = 49, flags: int = 0, strict: bool = True) -> bytes:
+        n = len(scalars) // 32
+        out = ctypes.create_string_buffer(fmt)
+        self._ck(self.lib.c12381_g1_msm_flags(self.h, n, _p(pts), _p(scalars), _p(out), fmt, flags), allow_point=not strict)
+        return out.raw[:fmt]
+
+    def pair_flags(self, g1: bytes, g2: bytes, flags: int = 0, strict: bool = True) -> bytes:
+        n = len(g1) // (49 if flags & F_COMPRESSED_IN else 96)
+        out = ctypes.create_string_buffer(max(576 * n, 1))
+        self._ck(self.lib.c12381_pair_batch_flags(self.h, n, _p(g1), _p(g2), _p(out), flags), allow_point=not strict)
+        return out.raw[:576 * n]
 
     def g1_mul_flags_dev(self, n, pts_ptr, sc_ptr, out_ptr, fmt=49, flags=0):
         self._ck(self.lib.c12381_g1_mul_batch_flags_dev(self.h, n, _p(pts_ptr), _p(sc_ptr), _p(out_ptr), fmt, flags))

@@ -55,7 +55,7 @@ struct c12381_ctx {
     std::vector<hipEvent_t> ev_chunk;     // one per chunk of a scalar-mul batch (main -> side dependencies)
     char err[256] = {0};
     enum { WS_TAB, WS_PROJ, WS_PREF, WS_IN0, WS_IN1, WS_OUT, WS_RED0, WS_RED1, WS_BBS_Q, WS_BBS_B, WS_BBS_IN, WS_BBS_WIRE, WS_BBS_WIRE_IN,
-           WS_PAIR_ST, WS_FQ_W, WS_FQ_G, WS_FQ_GATE, WS_FQ_P, WS_FB_G2, WS_FB_G1_0, WS_FB_G1_1, WS_FB_G1_2, WS_FB_G1_3, WS_MSM_PTS, WS_MSM_K0, WS_MSM_K1, WS_MSM_V0, WS_MSM_V1, WS_MSM_TMP, WS_MSM_RNG, WS_MSM_BK, WS_MSM_ORD, WS_MSM_OVF, WS_COUNT };
+           WS_PAIR_ST, WS_FQ_W, WS_FQ_G, WS_FQ_GATE, WS_FQ_P, WS_FB_G2, WS_FB_G1_0, WS_FB_G1_1, WS_FB_G1_2, WS_FB_G1_3, WS_MSM_PTS, WS_MSM_K0, WS_MSM_K1, WS_MSM_V0, WS_MSM_V1, WS_MSM_TMP, WS_MSM_RNG, WS_MSM_BK, WS_MSM_ORD, WS_MSM_OVF, WS_DEC1, WS_DEC2, WS_COUNT };
     void* ws[WS_COUNT] = {nullptr};
     size_t ws_bytes[WS_COUNT] = {0};
     int* d_flag = nullptr;
@@ -195,7 +195,7 @@ static int msm_c(size_t n) {
     return forced ? forced : msm_window_bits(n);
 }
 // Bucket-method MSM (msm.hpp): prep -> radix sort -> bucket sums -> window reduction -> Horner -> affine.
-int g1_msm_pippenger(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
+int g1_msm_pippenger(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt, int in_fmt = 96) {
     const int cb = msm_c(n), W = msm_windows(cb);
     // nbk digit buckets + ONE more (index nbk, key W << cb): the points whose scalar is below x^2 (msm.hpp)
     const size_t E = msm_entries(n, W), nb = (size_t)1 << cb, nbk = nb * W, nbx = nbk + 1;
@@ -213,7 +213,7 @@ int g1_msm_pippenger(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t*
     uint32_t* lo = (uint32_t*)c->ws[c12381_ctx::WS_MSM_RNG];
     uint32_t* hi = lo + nbx + 1;
     int32_t* bk = (int32_t*)c->ws[c12381_ctx::WS_MSM_BK];
-    hipLaunchKernelGGL(msm_prep_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, pts, sc, cb, W, pts2, k0, v0, c->d_flag);
+    hipLaunchKernelGGL(msm_prep_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, pts, in_fmt, sc, cb, W, pts2, k0, v0, c->d_flag);
     HIPCK(c, hipGetLastError());
     // Sort by digit inside every window segment (msm_prep_one lays the entries out window by window): bits [0, cb) only — two
     // 8-bit passes for cb = 16.  rocPRIM's radix sort is called directly; from 2^15 terms on once per segment, below that one
@@ -450,12 +450,14 @@ int c12381_fp_mulchain_dev(c12381_ctx* c, size_t n, int iters, const uint8_t* a,
 }
 
 // ---------------------------------------------------------------- G1
+// C12381_F_COMPRESSED_IN: pts are n x 49 bytes (the serialized form, g1_point.hpp:87-111 -> ECP_fromOctet): from_bytes -> multiply ->
+// to_bytes in ONE kernel — the square root runs in the kernel's prologue; a rejected encoding is a lane of 0xff + C12381_E_POINT
 int c12381_g1_mul_batch_flags_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt, unsigned flags) {
     int rc = bind(c); if (rc) return rc;
-    if (!pts || !sc || !out || (fmt != 49 && fmt != 96) || (flags & ~(unsigned)C12381_F_IN_SUBGROUP)) return C12381_E_ARG;
+    if (!pts || !sc || !out || (fmt != 49 && fmt != 96) || (flags & ~(unsigned)(C12381_F_IN_SUBGROUP | C12381_F_COMPRESSED_IN))) return C12381_E_ARG;
     if (n == 0) return 0;
     const size_t stride = round_up(n, 64);
-    if ((rc = g1_mul_to_proj(c, n, pts, sc, stride, 96, 0, nullptr, (flags & C12381_F_IN_SUBGROUP) != 0))) return rc;
+    if ((rc = g1_mul_to_proj(c, n, pts, sc, stride, (flags & C12381_F_COMPRESSED_IN) ? 49 : 96, 0, nullptr, (flags & C12381_F_IN_SUBGROUP) != 0))) return rc;
     return g1_finish(c, n, (const int32_t*)c->ws[c12381_ctx::WS_PROJ], stride, out, fmt);
 }
 int c12381_g1_mul_batch_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
@@ -463,10 +465,10 @@ int c12381_g1_mul_batch_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const u
 }
 int c12381_g1_mul_batch_flags(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt, unsigned flags) {
     int rc = bind(c); if (rc) return rc;
-    if (!pts || !sc || !out || (fmt != 49 && fmt != 96) || (flags & ~(unsigned)C12381_F_IN_SUBGROUP)) return C12381_E_ARG;
+    if (!pts || !sc || !out || (fmt != 49 && fmt != 96) || (flags & ~(unsigned)(C12381_F_IN_SUBGROUP | C12381_F_COMPRESSED_IN))) return C12381_E_ARG;
     if (n == 0) return 0;
     staged s;
-    if ((rc = stage_in(c, s, pts, 96 * n, sc, 32 * n, (size_t)fmt * n))) return rc;
+    if ((rc = stage_in(c, s, pts, ((flags & C12381_F_COMPRESSED_IN) ? 49 : 96) * n, sc, 32 * n, (size_t)fmt * n))) return rc;
     if ((rc = c12381_g1_mul_batch_flags_dev(c, n, s.in0, s.in1, s.out, fmt, flags))) return rc;
     if ((rc = stage_out(c, s, out, (size_t)fmt * n))) return rc;
     return read_flag(c);
@@ -493,9 +495,10 @@ int c12381_g1_add_batch(c12381_ctx* c, size_t n, const uint8_t* a, const uint8_t
 // MSM: the bucket method (g1_msm_pippenger); a single term (or C12381_MSM=naive) takes n independent GLV scalar
 // multiplications followed by a tree sum of the projective results (the reference's Π is also n full scalar-muls,
 // g1_point.hpp:389-401).  Both equal the reference's chain for every input.  Only the final point is canonical.
-int c12381_g1_msm_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
+int c12381_g1_msm_flags_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt, unsigned flags) {
     int rc = bind(c); if (rc) return rc;
-    if (!out || (n && (!pts || !sc)) || (fmt != 49 && fmt != 96)) return C12381_E_ARG;
+    if (!out || (n && (!pts || !sc)) || (fmt != 49 && fmt != 96) || (flags & ~(unsigned)C12381_F_COMPRESSED_IN)) return C12381_E_ARG;
+    const int in_fmt = (flags & C12381_F_COMPRESSED_IN) ? 49 : 96;        // compressed terms are decoded by the preparation kernel
     if (n == 0) { HIPCK(c, hipMemsetAsync(out, 0, fmt, c->stream)); return 0; }
     if (n > MSM_MAX_TERMS) {
         // the sort works on 32-bit item counts and (term, half) values: larger products are cut into parts whose
@@ -510,13 +513,13 @@ int c12381_g1_msm_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t
         HIPCK(c, hipStreamSynchronize(c->stream));              // h1 goes out of scope below
         for (size_t p = 0; p < parts; ++p) {
             const size_t lo = p * MSM_MAX_TERMS, m = n - lo < MSM_MAX_TERMS ? n - lo : MSM_MAX_TERMS;
-            if ((rc = g1_msm_pippenger(c, m, pts + 96 * lo, sc + 32 * lo, pp + 96 * p, 96))) return rc;
+            if ((rc = g1_msm_pippenger(c, m, pts + (size_t)in_fmt * lo, sc + 32 * lo, pp + 96 * p, 96, in_fmt))) return rc;
         }
-        return c12381_g1_msm_dev(c, parts, pp, ones, out, fmt);
+        return c12381_g1_msm_flags_dev(c, parts, pp, ones, out, fmt, 0u);
     }
-    if (msm_use_buckets(n)) return g1_msm_pippenger(c, n, pts, sc, out, fmt);
+    if (msm_use_buckets(n)) return g1_msm_pippenger(c, n, pts, sc, out, fmt, in_fmt);
     const size_t stride = round_up(n, 64);
-    if ((rc = g1_mul_to_proj(c, n, pts, sc, stride))) return rc;
+    if ((rc = g1_mul_to_proj(c, n, pts, sc, stride, (size_t)in_fmt))) return rc;
     const int32_t* cur = (const int32_t*)c->ws[c12381_ctx::WS_PROJ];
     size_t cur_n = n, cur_stride = stride;
     int slot = c12381_ctx::WS_RED0;
@@ -531,14 +534,20 @@ int c12381_g1_msm_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t
     }
     return g1_finish(c, 1, cur, cur_stride, out, fmt);
 }
-int c12381_g1_msm(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
+int c12381_g1_msm_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
+    return c12381_g1_msm_flags_dev(c, n, pts, sc, out, fmt, 0u);
+}
+int c12381_g1_msm_flags(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt, unsigned flags) {
     int rc = bind(c); if (rc) return rc;
-    if (!out || (n && (!pts || !sc)) || (fmt != 49 && fmt != 96)) return C12381_E_ARG;
+    if (!out || (n && (!pts || !sc)) || (fmt != 49 && fmt != 96) || (flags & ~(unsigned)C12381_F_COMPRESSED_IN)) return C12381_E_ARG;
     staged s;
-    if ((rc = stage_in(c, s, pts, 96 * n, sc, 32 * n, (size_t)fmt))) return rc;
-    if ((rc = c12381_g1_msm_dev(c, n, s.in0, s.in1, s.out, fmt))) return rc;
+    if ((rc = stage_in(c, s, pts, ((flags & C12381_F_COMPRESSED_IN) ? 49 : 96) * n, sc, 32 * n, (size_t)fmt))) return rc;
+    if ((rc = c12381_g1_msm_flags_dev(c, n, s.in0, s.in1, s.out, fmt, flags))) return rc;
     if ((rc = stage_out(c, s, out, (size_t)fmt))) return rc;
     return read_flag(c);
+}
+int c12381_g1_msm(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
+    return c12381_g1_msm_flags(c, n, pts, sc, out, fmt, 0u);
 }
 // sum_of_products(point1&, int n, point1*, const big*) exactly as the boundary defines it (-> ECP_muln, a plain Pippenger): the sum
 // of the TRUE multiples [k_i mod r]P_i for any curve points.  On G1 it equals c12381_g1_msm — use that for throughput; this entry
@@ -611,12 +620,13 @@ static int g2_finish(c12381_ctx* c, size_t n, uint8_t* d_out, int fmt) {
     HIPCK(c, hipGetLastError());
     return 0;
 }
+// C12381_F_COMPRESSED_IN: pts are n x 97 bytes (g2_point.hpp:73-77 -> ECP2_fromOctet), decoded in the kernel's prologue
 int c12381_g2_mul_batch_flags_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt, unsigned flags) {
     int rc = bind(c); if (rc) return rc;
-    if (!pts || !sc || !out || (fmt != 97 && fmt != 192) || (flags & ~(unsigned)C12381_F_IN_SUBGROUP)) return C12381_E_ARG;
+    if (!pts || !sc || !out || (fmt != 97 && fmt != 192) || (flags & ~(unsigned)(C12381_F_IN_SUBGROUP | C12381_F_COMPRESSED_IN))) return C12381_E_ARG;
     if (n == 0) return 0;
     if ((rc = ensure(c, c12381_ctx::WS_PROJ, (size_t)6 * NL * round_up(n, 64) * 4))) return rc;
-    if ((rc = g2_mul_dev_strided(c, n, pts, 192, sc, out, fmt, nullptr, true, (flags & C12381_F_IN_SUBGROUP) != 0))) return rc;
+    if ((rc = g2_mul_dev_strided(c, n, pts, (flags & C12381_F_COMPRESSED_IN) ? 97 : 192, sc, out, fmt, nullptr, true, (flags & C12381_F_IN_SUBGROUP) != 0))) return rc;
     return g2_finish(c, n, out, fmt);
 }
 int c12381_g2_mul_batch_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt) {
@@ -651,10 +661,10 @@ static int g2_mul_dev_strided(c12381_ctx* c, size_t n, const uint8_t* pts, size_
 }
 int c12381_g2_mul_batch_flags(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt, unsigned flags) {
     int rc = bind(c); if (rc) return rc;
-    if (!pts || !sc || !out || (fmt != 97 && fmt != 192) || (flags & ~(unsigned)C12381_F_IN_SUBGROUP)) return C12381_E_ARG;
+    if (!pts || !sc || !out || (fmt != 97 && fmt != 192) || (flags & ~(unsigned)(C12381_F_IN_SUBGROUP | C12381_F_COMPRESSED_IN))) return C12381_E_ARG;
     if (n == 0) return 0;
     staged s;
-    if ((rc = stage_in(c, s, pts, 192 * n, sc, 32 * n, (size_t)fmt * n))) return rc;
+    if ((rc = stage_in(c, s, pts, ((flags & C12381_F_COMPRESSED_IN) ? 97 : 192) * n, sc, 32 * n, (size_t)fmt * n))) return rc;
     if ((rc = c12381_g2_mul_batch_flags_dev(c, n, s.in0, s.in1, s.out, fmt, flags))) return rc;
     if ((rc = stage_out(c, s, out, (size_t)fmt * n))) return rc;
     return read_flag(c);
@@ -827,16 +837,34 @@ int c12381_pair_batch_dev(c12381_ctx* c, size_t n, const uint8_t* g1, const uint
     timed tm(c, 3);
     return launch_pair(c, n, g1, g2, gt);
 }
-int c12381_pair_batch(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt) {
+// C12381_F_COMPRESSED_IN: g1 = n x 49, g2 = n x 97 bytes.  The pairing kernels read their inputs once per queue task (up to five times),
+// so the decoding runs as its own two kernels into a workspace (288 B per pairing, against ~280 ns of arithmetic); a rejected
+// encoding becomes an off-curve record there and surfaces exactly like an invalid 96 / 192-byte input: 0xff lane, C12381_E_POINT.
+int c12381_pair_batch_flags_dev(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, unsigned flags) {
     int rc = bind(c); if (rc) return rc;
-    if (!g1 || !g2 || !gt) return C12381_E_ARG;
+    if (!g1 || !g2 || !gt || (flags & ~(unsigned)C12381_F_COMPRESSED_IN)) return C12381_E_ARG;
     if (n == 0) return 0;
+    if (!(flags & C12381_F_COMPRESSED_IN)) return c12381_pair_batch_dev(c, n, g1, g2, gt);
+    if ((rc = ensure(c, c12381_ctx::WS_DEC1, 96 * n))) return rc;
+    if ((rc = ensure(c, c12381_ctx::WS_DEC2, 192 * n))) return rc;
+    uint8_t *d1 = (uint8_t*)c->ws[c12381_ctx::WS_DEC1], *d2 = (uint8_t*)c->ws[c12381_ctx::WS_DEC2];
+    hipLaunchKernelGGL(g1_decompress_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, g1, d1, (uint8_t*)nullptr, 1);
+    hipLaunchKernelGGL(g2_decompress_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, g2, d2, (uint8_t*)nullptr, 1);
+    HIPCK(c, hipGetLastError());
+    return c12381_pair_batch_dev(c, n, d1, d2, gt);
+}
+int c12381_pair_batch_flags(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, unsigned flags) {
+    int rc = bind(c); if (rc) return rc;
+    if (!g1 || !g2 || !gt || (flags & ~(unsigned)C12381_F_COMPRESSED_IN)) return C12381_E_ARG;
+    if (n == 0) return 0;
+    const bool comp = (flags & C12381_F_COMPRESSED_IN) != 0;
     staged s;
-    if ((rc = stage_in(c, s, g1, 96 * n, g2, 192 * n, 576 * n))) return rc;
-    if ((rc = c12381_pair_batch_dev(c, n, s.in0, s.in1, s.out))) return rc;
+    if ((rc = stage_in(c, s, g1, (comp ? 49 : 96) * n, g2, (comp ? 97 : 192) * n, 576 * n))) return rc;
+    if ((rc = c12381_pair_batch_flags_dev(c, n, s.in0, s.in1, s.out, flags))) return rc;
     if ((rc = stage_out(c, s, gt, 576 * n))) return rc;
     return read_flag(c);
 }
+int c12381_pair_batch(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt) { return c12381_pair_batch_flags(c, n, g1, g2, gt, 0u); }
 // Product of k pairings per element with shared squarings (pair3_prod_kernel)
 int c12381_pair_product_batch_dev(c12381_ctx* c, size_t n, int k, const uint8_t* g1s, const uint8_t* g2s, uint8_t* gt, unsigned flags) {
     int rc = bind(c); if (rc) return rc;
@@ -918,7 +946,7 @@ int c12381_g1_decompress_batch_dev(c12381_ctx* c, size_t n, const uint8_t* in49,
     int rc = bind(c); if (rc) return rc;
     if (!in49 || !out96 || !status) return C12381_E_ARG;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(g1_decompress_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, in49, out96, status);
+    hipLaunchKernelGGL(g1_decompress_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, in49, out96, status, 0);
     HIPCK(c, hipGetLastError());
     return 0;
 }
@@ -926,7 +954,7 @@ int c12381_g2_decompress_batch_dev(c12381_ctx* c, size_t n, const uint8_t* in97,
     int rc = bind(c); if (rc) return rc;
     if (!in97 || !out192 || !status) return C12381_E_ARG;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(g2_decompress_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, in97, out192, status);
+    hipLaunchKernelGGL(g2_decompress_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, in97, out192, status, 0);
     HIPCK(c, hipGetLastError());
     return 0;
 }
@@ -936,7 +964,7 @@ int c12381_g1_decompress_batch(c12381_ctx* c, size_t n, const uint8_t* in49, uin
     if (n == 0) return 0;
     staged s;
     if ((rc = stage_in(c, s, in49, 49 * n, nullptr, n, 96 * n))) return rc;
-    hipLaunchKernelGGL(g1_decompress_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, s.in0, s.out, s.in1);
+    hipLaunchKernelGGL(g1_decompress_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, s.in0, s.out, s.in1, 0);
     HIPCK(c, hipGetLastError());
     if ((rc = stage_out(c, s, out96, 96 * n))) return rc;
     HIPCK(c, hipMemcpyAsync(status, s.in1, n, hipMemcpyDeviceToHost, c->stream));
@@ -1066,7 +1094,7 @@ int c12381_g2_decompress_batch(c12381_ctx* c, size_t n, const uint8_t* in97, uin
     if (n == 0) return 0;
     staged s;
     if ((rc = stage_in(c, s, in97, 97 * n, nullptr, n, 192 * n))) return rc;
-    hipLaunchKernelGGL(g2_decompress_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, s.in0, s.out, s.in1);
+    hipLaunchKernelGGL(g2_decompress_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, s.in0, s.out, s.in1, 0);
     HIPCK(c, hipGetLastError());
     if ((rc = stage_out(c, s, out192, 192 * n))) return rc;
     HIPCK(c, hipMemcpyAsync(status, s.in1, n, hipMemcpyDeviceToHost, c->stream));
@@ -1392,11 +1420,11 @@ int c12381_bbs_plus_verify_wire_batch_dev(c12381_ctx* c, size_t n, size_t nh, si
     uint8_t* d = (uint8_t*)c->ws[c12381_ctx::WS_BBS_WIRE];
     hipLaunchKernelGGL(bbs_wire_pub_kernel, dim3(grid_for(49 * npub1 + 2 * 97)), dim3(BLOCK), 0, c->stream, nblk, g1_g2_h0_195, h_49, pk_97, d + o_p49, d + o_p97);
     HIPCK(c, hipGetLastError());
-    hipLaunchKernelGGL(g1_decompress_kernel, dim3(grid_for(npub1)), dim3(BLOCK), 0, c->stream, npub1, d + o_p49, d + o_p96, d + o_st1);
-    hipLaunchKernelGGL(g2_decompress_kernel, dim3(1), dim3(BLOCK), 0, c->stream, (size_t)2, d + o_p97, d + o_p192, d + o_st2);
+    hipLaunchKernelGGL(g1_decompress_kernel, dim3(grid_for(npub1)), dim3(BLOCK), 0, c->stream, npub1, d + o_p49, d + o_p96, d + o_st1, 0);
+    hipLaunchKernelGGL(g2_decompress_kernel, dim3(1), dim3(BLOCK), 0, c->stream, (size_t)2, d + o_p97, d + o_p192, d + o_st2, 0);
     HIPCK(c, hipGetLastError());
     hipLaunchKernelGGL(bbs_wire_prep_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, msg_len, nblk, sig_145, msgs, d + o_a49, d + o_x, d + o_r, d + o_m, d + o_ss);
-    hipLaunchKernelGGL(g1_decompress_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, d + o_a49, d + o_A, d + o_sa);
+    hipLaunchKernelGGL(g1_decompress_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, d + o_a49, d + o_A, d + o_sa, 0);
     HIPCK(c, hipGetLastError());
     if ((rc = c12381_bbs_plus_verify_batch_dev(c, n, nblk, d + o_p96, d + o_p192, d + o_p96 + 96, d + o_p96 + 192, d + o_p192 + 192, d + o_A, d + o_x, d + o_r,
                                                d + o_m, ok))) return rc;

@@ -41,6 +41,20 @@ namespace c12381 { __device__ __forceinline__ int32_t limb_opaque(int32_t v) { a
 #else
 #define C12381_LIMB(x) (x)
 #endif
+// A/B switch, OFF (profiles/r03_ab_acc_fence_g2_inline.txt).  Left alone, LLVM computes every column of a product from zero and adds the carry
+// of the previous column afterwards (one v_lshl_add_u64 per column, ~1 instruction per 15 multiply-adds), and it splits the signed limb
+// products and the non-negative m * p products into two chains.  -DC12381_ACC_FENCE=1 puts an empty asm on the accumulator after every
+// multiply-add, which forces ONE linear chain per column sequence: the adds disappear (g1_mul_kernel: -20 % non-multiply instructions,
+// no spill), but a dependent v_mad_i64_i32 needs a wait state and the compiler pays it with an s_nop per ~2 multiply-adds — measured:
+// G1 -1 %, G2 +5 %, MSM +2 %, pairing kernel 18.1 -> 24.4 ms.  The compiler's two-chain form stays.
+#ifndef C12381_ACC_FENCE
+#define C12381_ACC_FENCE 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && C12381_ACC_FENCE
+#define C12381_FENCE(acc) asm("" : "+v"(acc))
+#else
+#define C12381_FENCE(acc)
+#endif
 
 #include "consts.hpp"
 
@@ -201,19 +215,19 @@ C12381_HD void fp_mul(fp& r, const fp& a, const fp& b) {
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
 #pragma unroll
-        for (int i = 0; i <= k; ++i) acc += (int64_t)a.l[i] * b.l[k - i];
+        for (int i = 0; i <= k; ++i) { acc += (int64_t)a.l[i] * b.l[k - i]; C12381_FENCE(acc); }
 #pragma unroll
-        for (int i = 0; i < k; ++i) acc += (int64_t)m[i] * FP_P[k - i];
+        for (int i = 0; i < k; ++i) { acc += (int64_t)m[i] * FP_P[k - i]; C12381_FENCE(acc); }
         m[k] = (int32_t)(((uint32_t)acc * FP_N0) & LMASK);
-        acc += (int64_t)m[k] * FP_P[0];
+        acc += (int64_t)m[k] * FP_P[0]; C12381_FENCE(acc);
         acc >>= LB;
     }
 #pragma unroll
     for (int k = NL; k < 2 * NL - 1; ++k) {
 #pragma unroll
-        for (int i = k - NL + 1; i < NL; ++i) acc += (int64_t)a.l[i] * b.l[k - i];
+        for (int i = k - NL + 1; i < NL; ++i) { acc += (int64_t)a.l[i] * b.l[k - i]; C12381_FENCE(acc); }
 #pragma unroll
-        for (int i = k - NL + 1; i < NL; ++i) acc += (int64_t)m[i] * FP_P[k - i];
+        for (int i = k - NL + 1; i < NL; ++i) { acc += (int64_t)m[i] * FP_P[k - i]; C12381_FENCE(acc); }
         out[k - NL] = C12381_LIMB((int32_t)((uint32_t)acc & LMASK));
         acc >>= LB;
     }
@@ -238,21 +252,21 @@ C12381_HD void fp_sqr(fp& r, const fp& a) {
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
 #pragma unroll
-        for (int i = 0; 2 * i < k; ++i) acc += (int64_t)a2[i] * a.l[k - i];
-        if ((k & 1) == 0) acc += (int64_t)a.l[k / 2] * a.l[k / 2];
+        for (int i = 0; 2 * i < k; ++i) { acc += (int64_t)a2[i] * a.l[k - i]; C12381_FENCE(acc); }
+        if ((k & 1) == 0) { acc += (int64_t)a.l[k / 2] * a.l[k / 2]; C12381_FENCE(acc); }
 #pragma unroll
-        for (int i = 0; i < k; ++i) acc += (int64_t)m[i] * FP_P[k - i];
+        for (int i = 0; i < k; ++i) { acc += (int64_t)m[i] * FP_P[k - i]; C12381_FENCE(acc); }
         m[k] = (int32_t)(((uint32_t)acc * FP_N0) & LMASK);
-        acc += (int64_t)m[k] * FP_P[0];
+        acc += (int64_t)m[k] * FP_P[0]; C12381_FENCE(acc);
         acc >>= LB;
     }
 #pragma unroll
     for (int k = NL; k < 2 * NL - 1; ++k) {
 #pragma unroll
-        for (int i = k - NL + 1; 2 * i < k; ++i) acc += (int64_t)a2[i] * a.l[k - i];
-        if ((k & 1) == 0) acc += (int64_t)a.l[k / 2] * a.l[k / 2];
+        for (int i = k - NL + 1; 2 * i < k; ++i) { acc += (int64_t)a2[i] * a.l[k - i]; C12381_FENCE(acc); }
+        if ((k & 1) == 0) { acc += (int64_t)a.l[k / 2] * a.l[k / 2]; C12381_FENCE(acc); }
 #pragma unroll
-        for (int i = k - NL + 1; i < NL; ++i) acc += (int64_t)m[i] * FP_P[k - i];
+        for (int i = k - NL + 1; i < NL; ++i) { acc += (int64_t)m[i] * FP_P[k - i]; C12381_FENCE(acc); }
         out[k - NL] = C12381_LIMB((int32_t)((uint32_t)acc & LMASK));
         acc >>= LB;
     }
@@ -277,7 +291,7 @@ C12381_HD void fp_col_acc(int64_t& acc, const fp& a, const fp& b, int k) {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
         const int j = k - i;
-        if (j >= 0 && j < NL) acc += (int64_t)a.l[i] * b.l[j];
+        if (j >= 0 && j < NL) { acc += (int64_t)a.l[i] * b.l[j]; C12381_FENCE(acc); }
     }
 }
 // acc += column k of s * a^2 given a2 = 2 s a and ad = s a  (s = +1 or -1): cross terms once, diagonal term
@@ -286,9 +300,9 @@ C12381_HD void fp_col_sqr_acc(int64_t& acc, const fp& a, const fp& a2, const fp&
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
         const int j = k - i;
-        if (j > i && j < NL) acc += (int64_t)a2.l[i] * a.l[j];
+        if (j > i && j < NL) { acc += (int64_t)a2.l[i] * a.l[j]; C12381_FENCE(acc); }
     }
-    if ((k & 1) == 0 && k / 2 < NL) acc += (int64_t)ad.l[k / 2] * a.l[k / 2];
+    if ((k & 1) == 0 && k / 2 < NL) { acc += (int64_t)ad.l[k / 2] * a.l[k / 2]; C12381_FENCE(acc); }
 }
 // limb-wise -a, 2a, -2a: operands of the column scans only (never normalised, never stored)
 C12381_HD void fp_raw_neg(fp& r, const fp& a) {
@@ -316,16 +330,16 @@ C12381_HD void fp_reduce_cols(fp& r, ColFn col) {
     for (int k = 0; k < NL; ++k) {
         col(k, acc);
 #pragma unroll
-        for (int i = 0; i < k; ++i) acc += (int64_t)m[i] * FP_P[k - i];
+        for (int i = 0; i < k; ++i) { acc += (int64_t)m[i] * FP_P[k - i]; C12381_FENCE(acc); }
         m[k] = (int32_t)(((uint32_t)acc * FP_N0) & LMASK);
-        acc += (int64_t)m[k] * FP_P[0];
+        acc += (int64_t)m[k] * FP_P[0]; C12381_FENCE(acc);
         acc >>= LB;
     }
 #pragma unroll
     for (int k = NL; k < 2 * NL - 1; ++k) {
         col(k, acc);
 #pragma unroll
-        for (int i = k - NL + 1; i < NL; ++i) acc += (int64_t)m[i] * FP_P[k - i];
+        for (int i = k - NL + 1; i < NL; ++i) { acc += (int64_t)m[i] * FP_P[k - i]; C12381_FENCE(acc); }
         out[k - NL] = C12381_LIMB((int32_t)((uint32_t)acc & LMASK));
         acc >>= LB;
     }
@@ -349,16 +363,16 @@ C12381_HD void fp_reduce_cols_static(fp& r, ColFn col) {
         constexpr int k = decltype(kc)::value;
         col(k, acc);
 #pragma unroll
-        for (int i = 0; i < k; ++i) acc += (int64_t)m[i] * FP_P[k - i];
+        for (int i = 0; i < k; ++i) { acc += (int64_t)m[i] * FP_P[k - i]; C12381_FENCE(acc); }
         m[k] = (int32_t)(((uint32_t)acc * FP_N0) & LMASK);
-        acc += (int64_t)m[k] * FP_P[0];
+        acc += (int64_t)m[k] * FP_P[0]; C12381_FENCE(acc);
         acc >>= LB;
     });
     fp_static_for(std::make_integer_sequence<int, NL - 1>{}, [&](auto kc) {
         constexpr int k = NL + decltype(kc)::value;
         col(k, acc);
 #pragma unroll
-        for (int i = k - NL + 1; i < NL; ++i) acc += (int64_t)m[i] * FP_P[k - i];
+        for (int i = k - NL + 1; i < NL; ++i) { acc += (int64_t)m[i] * FP_P[k - i]; C12381_FENCE(acc); }
         out[k - NL] = C12381_LIMB((int32_t)((uint32_t)acc & LMASK));
         acc >>= LB;
     });

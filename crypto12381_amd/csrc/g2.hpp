@@ -27,7 +27,7 @@ template <class F> C12381_HD void fp2_mul_b3(F& r, const F& x) { F t; fp2_mul_sm
 template <class F> C12381_HD void g2_dbl_core(g2pt<F>& p, F& t0, F& t1, F& t2b) {
     F t2, x3, y3, z3, z8, u, s;
     fp2_sqr(t0, p.y);
-    fp2_mul(t1, p.y, p.z);
+    fp2_mul(t1, p.z, p.y);                        // second operands p.y (twice), z8 (twice), u (twice): prepared once each in the two-lane form
     fp2_sqr(t2, p.z);
     fp2_mul_small(z8, t0, 8);
     fp2_mul_b3(t2b, t2);
@@ -37,10 +37,10 @@ template <class F> C12381_HD void g2_dbl_core(g2pt<F>& p, F& t0, F& t1, F& t2b) 
     fp2_dbl(u, t2b); fp2_add(u, u, t2b);          // 9b' Z^2
     fp2_sub(u, t0, u);
     fp2_norm1(u, u);
-    fp2_mul2<false>(y3, u, s, t2b, z8);
+    fp2_mul2<false>(y3, s, u, t2b, z8);
     F xy;
     fp2_mul(xy, p.x, p.y);
-    fp2_mul(x3, u, xy);
+    fp2_mul(x3, xy, u);
     fp2_dbl(x3, x3);
     p.x = x3; p.y = y3; p.z = z3;
 }
@@ -56,7 +56,7 @@ template <class F> C12381_HDN void g2_dbl_n(g2pt<F>& p, int n) {
 
 // ECP2_add :413-502 (complete).  P: X <= 2^29, Y and Z normalised; Q normalised.  The three output coordinates are sums of two
 // products each and are reduced once (fp2_mul2): 9 reductions for 12 products, as g1_add.
-template <class F> C12381_HDN void g2_add(g2pt<F>& p, const g2pt<F>& q) {
+template <class F> C12381_HD void g2_add_core(g2pt<F>& p, const g2pt<F>& q) {
     F t0, t1, t2, t3, t4, x3, y3, z3;
     fp2_mul(t0, p.x, q.x);
     fp2_mul(t1, p.y, q.y);
@@ -72,10 +72,16 @@ template <class F> C12381_HDN void g2_add(g2pt<F>& p, const g2pt<F>& q) {
     fp2_add(z3, t1, t2); fp2_norm1(z3, z3);
     fp2_sub(t1, t1, t2); fp2_norm1(t1, t1);
     fp2_mul_b3(y3, y3);
+    // (second operands t1, t4 | t0, t1 | t4, t0: the two-lane form prepares a second operand once — fp2h_lane_uv — and reuses it)
     fp2_mul2<true>(p.x, t3, t1, y3, t4);           // X3 = t3 t1 - y3 t4
-    fp2_mul2<false>(p.y, y3, t0, t1, z3);          // Y3 = y3 t0 + t1 z3
-    fp2_mul2<false>(p.z, z3, t4, t0, t3);          // Z3 = z3 t4 + t0 t3
+    fp2_mul2<false>(p.y, y3, t0, z3, t1);          // Y3 = y3 t0 + z3 t1
+    fp2_mul2<false>(p.z, z3, t4, t3, t0);          // Z3 = z3 t4 + t3 t0
 }
+template <class F> C12381_HDN void g2_add(g2pt<F>& p, const g2pt<F>& q) { g2_add_core(p, q); }
+// element types whose scalar-multiplication loop keeps the running point in registers: doublings and additions inlined into the
+// window loop (like g1_scalar_mul) instead of out-of-line routines that take the point through private memory.  Pays where the
+// whole addition fits the register file — the two-lane form (fp2h.hpp specialises this to true).
+template <class F> struct g2_inline_loop { static constexpr bool value = false; };
 
 // ------------------------------------------------------------------ SoA access
 C12381_HD void soa_store_fp2(int32_t* base, size_t stride, size_t idx, const fp2& a) {
@@ -223,6 +229,7 @@ C12381_HD void gs_bias(uint32_t (&ub)[3], const uint32_t (&u)[2]) {
 // acc += (-1)^I sign(d) psi^I(T[|d|])
 template <int I, class F>
 C12381_HD void g2_add_digit(g2pt<F>& acc, const int32_t* lane_tab, int d) {
+    constexpr bool INL = g2_inline_loop<F>::value;
     const int mag = d < 0 ? -d : d;
     const int idx = mag == 0 ? 1 : mag;
     g2pt<F> q, e, inf;
@@ -231,7 +238,7 @@ C12381_HD void g2_add_digit(g2pt<F>& acc, const int32_t* lane_tab, int d) {
     g2_set_inf(inf);
     const bool isz = mag == 0;
     fp2_select(e.x, isz, inf.x, e.x); fp2_select(e.y, isz, inf.y, e.y); fp2_select(e.z, isz, inf.z, e.z);
-    g2_add(acc, e);
+    if (INL) g2_add_core(acc, e); else g2_add(acc, e);
 }
 
 template <class F> C12381_HD bool g2_is_inf(const g2pt<F>& p) { return fp2_is_zero(p.z); }
@@ -322,7 +329,12 @@ template <class F> C12381_HDN void g2_scalar_mul(g2pt<F>& acc, const F& qx, cons
     g2_set_inf(acc);
 #pragma unroll 1
     for (int w = G2_WINDOWS - 1; w >= 0; --w) {
-        if (w != G2_WINDOWS - 1) g2_dbl_n(acc, G2_WIN);
+        if (w != G2_WINDOWS - 1) {
+            if (g2_inline_loop<F>::value) {
+#pragma unroll 1
+                for (int i = 0; i < G2_WIN; ++i) { F a, b, c; g2_dbl_core(acc, a, b, c); }
+            } else g2_dbl_n(acc, G2_WIN);
+        }
         g2_add_digit<0>(acc, lane_tab, gs_digit(ub[0], w));
         g2_add_digit<1>(acc, lane_tab, gs_digit(ub[1], w));
         g2_add_digit<2>(acc, lane_tab, gs_digit(ub[2], w));

@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(BLOCK, C12381_G1_OCC) g1_mul_kernel(size_t n, 
     if (i >= n) return;
     fp px, py;
     bool inf, ok;
-    g1_parse96(px, py, inf, ok, pts + pt_stride * i);
+    g1_parse_any(px, py, inf, ok, pts, pt_stride, i);
     uint32_t raw[8], k[8];
     load_raw32(raw, scalars + 32 * i);
     scalar_from_raw32(k, raw);
@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(BLOCK, 2) g1_small_scalar_kernel(size_t n, con
     if (!scalar_below_x2(k)) return;
     g1p base, acc;
     bool inf, ok;
-    g1_parse96(base.x, base.y, inf, ok, pts + pt_stride * i);
+    g1_parse_any(base.x, base.y, inf, ok, pts, pt_stride, i);
     if (inf || !ok) return;
     fp_one(base.z);
     soa_load_g1(acc, proj, proj_stride, proj_off + i);
@@ -268,12 +268,19 @@ __global__ void __launch_bounds__(BLOCK, 2) g1_rsub_kernel(size_t n, int32_t* ac
     soa_store_g1(acc, acc_stride, i, o);
 }
 
-__global__ void __launch_bounds__(BLOCK, 2) msm_prep_kernel(size_t n, const uint8_t* pts, const uint8_t* scalars, int c, int W, int32_t* pts2,
+// in_fmt: 96 = affine records, 49 = compressed records (C12381_F_COMPRESSED_IN: decoded here, one square root per term; a rejected
+// encoding becomes the off-curve record (0, 1), which msm_prep_one reports and leaves out of the product like any invalid point)
+__global__ void __launch_bounds__(BLOCK, 2) msm_prep_kernel(size_t n, const uint8_t* pts, int in_fmt, const uint8_t* scalars, int c, int W, int32_t* pts2,
                                                          uint32_t* keys, uint32_t* vals, int* bad_flag) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     uint32_t rp[24], rs[8];
-    load_raw48(rp, pts + 96 * i); load_raw48(rp + 12, pts + 96 * i + 48);
+    if (in_fmt == 49) {
+        fp x, y; bool inf, ok;
+        g1_parse49(x, y, inf, ok, pts + 49 * i);
+        if (inf || !ok) { for (int j = 0; j < 24; ++j) rp[j] = 0; if (!ok) rp[23] = 0x01000000u; }      // infinity | (0, 1)
+        else { fp_to_raw48(rp, x); fp_to_raw48(rp + 12, y); }
+    } else { load_raw48(rp, pts + 96 * i); load_raw48(rp + 12, pts + 96 * i + 48); }
     load_raw32(rs, scalars + 32 * i);
     if (!msm_prep_one(i, n, rp, rs, c, W, pts2, keys, vals)) *bad_flag = 1;
 }
@@ -408,7 +415,9 @@ __global__ void __launch_bounds__(BLOCK, 2) msm_wreduce_kernel(int W, uint32_t n
 
 // ECP_fromOctet ecp_BLS12381.cpp:495-545 for 49-byte input (tags 02/03; a leading 00 is infinity as in
 // g1_point.hpp:89-93); status 1 ok / 0 reject; rejected and infinity lanes give 96 zero bytes.
-__global__ void __launch_bounds__(BLOCK, 2) g1_decompress_kernel(size_t n, const uint8_t* in, uint8_t* out, uint8_t* status) {
+// mark_invalid != 0 (internal use: compressed inputs of the pairing entry points): a rejected lane becomes the off-curve record (0, 1)
+// instead of zeros, so the kernel that consumes `out` reports it like any point that is not on the curve (0xff lane, C12381_E_POINT)
+__global__ void __launch_bounds__(BLOCK, 2) g1_decompress_kernel(size_t n, const uint8_t* in, uint8_t* out, uint8_t* status, int mark_invalid) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const uint8_t* sp = in + 49 * i;
@@ -425,9 +434,10 @@ __global__ void __launch_bounds__(BLOCK, 2) g1_decompress_kernel(size_t n, const
     if (!ok) {
 #pragma unroll
         for (int j = 0; j < 12; ++j) { rx[j] = 0; ry[j] = 0; }
+        if (mark_invalid && tag != 0) ry[11] = 0x01000000u;
     }
     store_raw48(out + 96 * i, rx); store_raw48(out + 96 * i + 48, ry);
-    status[i] = tag == 0 ? 1 : (ok ? 1 : 0);
+    if (status) status[i] = tag == 0 ? 1 : (ok ? 1 : 0);
 }
 
 // One level of the per-window sums of the MSM, 64 points per wavefront: element index = group * W + w; wavefront (g, w) loads

@@ -17,7 +17,7 @@ __global__ void __launch_bounds__(BLOCK, 2) g2_mul_kernel(size_t n, const uint8_
     if (i >= n) return;
     fp2 qx, qy;
     bool inf, ok;
-    g2_parse192(qx, qy, inf, ok, pts + pt_stride * i);
+    g2_parse_any(qx, qy, inf, ok, pts, pt_stride, i);
     uint32_t raw[8], k[8];
     load_raw32(raw, scalars + 32 * i);
     scalar_from_raw32(k, raw);
@@ -159,7 +159,8 @@ __global__ void __launch_bounds__(BLOCK, 2) pair_eq_kernel(size_t n, const uint8
 #endif  // C12381_EXPERIMENTS
 
 // ECP2_fromOctet ecp2_BLS12381.cpp:225-266 for 97-byte input: any tag other than 04 is "compressed, sign = tag & 1"
-__global__ void __launch_bounds__(BLOCK, 2) g2_decompress_kernel(size_t n, const uint8_t* in, uint8_t* out, uint8_t* status) {
+// mark_invalid: as g1_decompress_kernel — a rejected lane becomes the off-twist record x = 0, y = 1
+__global__ void __launch_bounds__(BLOCK, 2) g2_decompress_kernel(size_t n, const uint8_t* in, uint8_t* out, uint8_t* status, int mark_invalid) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const uint8_t* sp = in + 97 * i;
@@ -172,8 +173,12 @@ __global__ void __launch_bounds__(BLOCK, 2) g2_decompress_kernel(size_t n, const
     const bool ok = g2_set_x(y, x, tag & 1) && tag != 0 && tag != 4;
     uint8_t* o = out + 192 * i;
     if (ok) { fp2_store_raw96(o, x); fp2_store_raw96(o + 96, y); }
-    else { uint4* q = reinterpret_cast<uint4*>(o); for (int j = 0; j < 12; ++j) q[j] = make_uint4(0, 0, 0, 0); }
-    status[i] = tag == 0 ? 1 : (ok ? 1 : 0);
+    else {
+        uint4* q = reinterpret_cast<uint4*>(o);
+        for (int j = 0; j < 12; ++j) q[j] = make_uint4(0, 0, 0, 0);
+        if (mark_invalid && tag != 0) q[11] = make_uint4(0, 0, 0, 0x01000000u);       // y.a = 1 (layout x.b | x.a | y.b | y.a)
+    }
+    if (status) status[i] = tag == 0 ? 1 : (ok ? 1 : 0);
 }
 
 #ifdef C12381_EXPERIMENTS

@@ -18,7 +18,7 @@ __global__ void __launch_bounds__(BLOCK, C12381_G2H_OCC) g2_mul2_kernel(size_t n
     if (i >= n) return;
     fp2 qx, qy;
     bool inf, ok;
-    g2_parse192(qx, qy, inf, ok, pts + pt_stride * i);
+    g2_parse_any(qx, qy, inf, ok, pts, pt_stride, i);
     fp2h hx, hy;
     fp2h_from(hx, qx); fp2h_from(hy, qy);
     uint32_t raw[8], k[8];

@@ -46,6 +46,27 @@ __device__ __forceinline__ void g1_parse96(fp& x, fp& y, bool& inf, bool& ok, co
     fp_from_raw48(x, raw); fp_from_raw48(y, raw + 12);
     ok = inf || g1_on_curve(x, y);
 }
+// The 49-byte form as the header layer reads it (g1_point.hpp:87-111 in front of ECP_fromOctet ecp_BLS12381.cpp:495-545): a leading
+// 0x00 is the point at infinity, 0x02 / 0x03 carry x and the parity of y (ECP_setx: one square root, on-curve by construction, no
+// subgroup check), every other tag is rejected (ok = false: the lane is treated like a point that is not on the curve).
+// Out of line: the square root must not share the register allocation of the caller's main loop.
+__device__ __noinline__ void g1_parse49(fp& x, fp& y, bool& inf, bool& ok, const uint8_t* sp) {
+    const uint8_t tag = sp[0];
+    uint32_t raw[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) raw[j] = (uint32_t)sp[1 + 4 * j] | ((uint32_t)sp[2 + 4 * j] << 8) | ((uint32_t)sp[3 + 4 * j] << 16) | ((uint32_t)sp[4 + 4 * j] << 24);
+    fp_from_raw48(x, raw);
+    inf = tag == 0;
+    const bool root = g1_set_x(y, x, tag & 1);
+    ok = inf || (root && (tag == 2 || tag == 3));
+    if (inf) { fp_zero(x); fp_zero(y); }
+}
+// pt_stride selects the input format of the scalar-multiplication kernels: 96 = affine records, 0 = one affine point for every lane,
+// 49 = compressed records (C12381_F_COMPRESSED_IN)
+__device__ __forceinline__ void g1_parse_any(fp& x, fp& y, bool& inf, bool& ok, const uint8_t* pts, size_t pt_stride, size_t i) {
+    if (pt_stride == 49) g1_parse49(x, y, inf, ok, pts + 49 * i);
+    else g1_parse96(x, y, inf, ok, pts + pt_stride * i);
+}
 __device__ __forceinline__ void fp2_load_raw96(fp2& r, const uint8_t* p) {       // b || a
     uint32_t raw[24];
     load_raw48(raw, p); load_raw48(raw + 12, p + 48);
@@ -74,6 +95,23 @@ __device__ __forceinline__ void g2_parse192(fp2& x, fp2& y, bool& inf, bool& ok,
     inf = o == 0;
     fp2_load_raw96(x, p); fp2_load_raw96(y, p + 96);
     ok = inf || g2_on_curve(x, y);
+}
+// The 97-byte form (g2_point.hpp:73-77 in front of ECP2_fromOctet ecp2_BLS12381.cpp:225-266): leading 0x00 = infinity; any tag other
+// than 0x04 is "compressed, sign = tag & 1" (ECP2_setx: an Fp2 square root); 0x04 announces the 193-byte form and is rejected here.
+__device__ __noinline__ void g2_parse97(fp2& x, fp2& y, bool& inf, bool& ok, const uint8_t* sp) {
+    const uint8_t tag = sp[0];
+    uint32_t raw[24];
+#pragma unroll
+    for (int j = 0; j < 24; ++j) raw[j] = (uint32_t)sp[1 + 4 * j] | ((uint32_t)sp[2 + 4 * j] << 8) | ((uint32_t)sp[3 + 4 * j] << 16) | ((uint32_t)sp[4 + 4 * j] << 24);
+    fp_from_raw48(x.b, raw); fp_from_raw48(x.a, raw + 12);
+    inf = tag == 0;
+    const bool root = g2_set_x(y, x, tag & 1);
+    ok = inf || (root && tag != 4);
+    if (inf) { fp2_zero(x); fp2_zero(y); }
+}
+__device__ __forceinline__ void g2_parse_any(fp2& x, fp2& y, bool& inf, bool& ok, const uint8_t* pts, size_t pt_stride, size_t i) {
+    if (pt_stride == 97) g2_parse97(x, y, inf, ok, pts + 97 * i);
+    else g2_parse192(x, y, inf, ok, pts + pt_stride * i);
 }
 // canonical encoding of one affine G2 point (or the infinity / invalid patterns)
 __device__ __noinline__ void g2_store_xy(uint8_t* o, const fp2& ax, const fp2& ay, int fmt, bool inf, bool invalid) {

@@ -93,6 +93,16 @@ int c12381_g1_mul_batch_dev(c12381_ctx* ctx, size_t n, const uint8_t* pts96, con
  * With the flag the test is skipped: results are identical on subgroup points (tests/test_gpu_g1.py) and are plain
  * [k mod x^2]P - [k div x^2]phi(P) off it. */
 #define C12381_F_IN_SUBGROUP 1u
+/* C12381_F_COMPRESSED_IN: the points arrive in their serialized form — n x 49 bytes (G1) / n x 97 bytes (G2) as the header layer
+ * parses them (g1_point.hpp:87-111, g2_point.hpp:73-77: a leading 0x00 is the point at infinity) in front of from_bytes(point1& /
+ * point2&, bytes_view&) (src/miracl_core_interface.cpp:109-112, 187-190 -> ECP_fromOctet ecp_BLS12381.cpp:495-545 / ECP2_fromOctet
+ * ecp2_BLS12381.cpp:225-266: tags 0x02 / 0x03 (G2: any tag but 0x04), x taken mod p, on-curve by construction, no subgroup check).
+ * from_bytes -> multiply / pair / product is then ONE call: the square root runs in the prologue of the scalar-multiplication and
+ * MSM-preparation kernels (the pairing entry decodes into a workspace first: its kernels read their inputs once per queue task).
+ * A rejected encoding behaves like a point that is not on the curve: its output lane is 0xff (an MSM leaves the term out) and the
+ * call returns C12381_E_POINT — the status semantics of c12381_g1_decompress_batch.  Accepted by c12381_g1_mul_batch_flags,
+ * c12381_g2_mul_batch_flags, c12381_g1_msm_flags, c12381_pair_batch_flags and their _dev forms. */
+#define C12381_F_COMPRESSED_IN 4u
 int c12381_g1_mul_batch_flags(c12381_ctx* ctx, size_t n, const uint8_t* pts96, const uint8_t* scalars32, uint8_t* out, int out_fmt, unsigned flags);
 int c12381_g1_mul_batch_flags_dev(c12381_ctx* ctx, size_t n, const uint8_t* pts96, const uint8_t* scalars32, uint8_t* out, int out_fmt, unsigned flags);
 /* out[i] = a[i] + b[i].  Batched add(point1&, point1&) (:129-132 -> ECP_add). */
@@ -101,6 +111,9 @@ int c12381_g1_add_batch(c12381_ctx* ctx, size_t n, const uint8_t* a96, const uin
  * sum_of_products(point1&, int, point1*, const big*) :134-137 -> ECP_muln). */
 int c12381_g1_msm(c12381_ctx* ctx, size_t n, const uint8_t* pts96, const uint8_t* scalars32, uint8_t* out, int out_fmt);
 int c12381_g1_msm_dev(c12381_ctx* ctx, size_t n, const uint8_t* pts96, const uint8_t* scalars32, uint8_t* out, int out_fmt);
+/* the same with C12381_F_COMPRESSED_IN (pts = n x 49 bytes): parse<G1> + Π in one call */
+int c12381_g1_msm_flags(c12381_ctx* ctx, size_t n, const uint8_t* pts, const uint8_t* scalars32, uint8_t* out, int out_fmt, unsigned flags);
+int c12381_g1_msm_flags_dev(c12381_ctx* ctx, size_t n, const uint8_t* pts, const uint8_t* scalars32, uint8_t* out, int out_fmt, unsigned flags);
 /* The boundary function sum_of_products(point1&, int, point1*, const big*) with the reference's value for EVERY input
  * (src/miracl_core_interface.cpp:134-137 -> ECP_muln ecp_BLS12381.cpp:1112-1148, a plain Pippenger): the sum of the true multiples
  * [k_i mod r]P_i.  For points of G1 this equals c12381_g1_msm, which is the fast path; off the subgroup the two differ because the
@@ -136,6 +149,9 @@ int c12381_g2_add_batch(c12381_ctx* ctx, size_t n, const uint8_t* a192, const ui
  * 276-284, 246-249 -> PAIR_ate, PAIR_fexp, FP12_toOctet). */
 int c12381_pair_batch(c12381_ctx* ctx, size_t n, const uint8_t* g1_96, const uint8_t* g2_192, uint8_t* gt576);
 int c12381_pair_batch_dev(c12381_ctx* ctx, size_t n, const uint8_t* g1_96, const uint8_t* g2_192, uint8_t* gt576);
+/* the same with C12381_F_COMPRESSED_IN (g1 = n x 49, g2 = n x 97 bytes): from_bytes x 2 + pair in one call */
+int c12381_pair_batch_flags(c12381_ctx* ctx, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt576, unsigned flags);
+int c12381_pair_batch_flags_dev(c12381_ctx* ctx, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt576, unsigned flags);
 /* gt[i] = prod_{j < k} e(g1s[j * n + i], g2s[j * n + i]) for k = 1, 2 or 3 (argument-major arrays of k * n points):
  * pair(a, b) * pair(c, d) as the header layer forms it (liner_pair.hpp:291-303) ->
  * pair_double_ate(fp12&, point2&, point1&, point2&, point1&) (miracl_core_interface.hpp:203-204,

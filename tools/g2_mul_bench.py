@@ -48,3 +48,10 @@ dpm, dkm = dev_b(pm), dev_b(sc(8, nm))
 om = torch.empty(96, dtype=torch.uint8, device=dev)
 dt = timeit(lambda: c.g1_msm_dev(nm, dpm.data_ptr(), dkm.data_ptr(), om.data_ptr(), 96))
 print("msm 2^22: %.2f ms" % (dt * 1e3))
+npair = 1 << 16
+pp = (p * ((npair * 96 + len(p) - 1) // len(p)))[: npair * 96]
+qq = (q * ((npair * 192 + len(q) - 1) // len(q)))[: npair * 192]
+dpp, dqq = dev_b(pp), dev_b(qq)
+gt = torch.empty(576 * npair, dtype=torch.uint8, device=dev)
+dt = timeit(lambda: c.pair_dev(npair, dpp.data_ptr(), dqq.data_ptr(), gt.data_ptr()))
+print("pair 2^16: %.2f ms  %.3e /s" % (dt * 1e3, npair / dt))
