@@ -73,7 +73,14 @@ BYTES_PAIRING = 864              # 96 + 192 in, 576 out
 BYTES_MSM_TERM = 128             # 96 + 32
 BYTES_BBS_VERIFY = 96 + 32 + 32 + 32 + 1
 HBM_PEAK_GBS = 8000.0
-VALU_PEAK_MAC32 = 3.10e13        # measured multiply-add lane-ops/s (v_mad_u64_u32 r01; v_mad_i64_i32 rows: profiles/r03_valu_rates.txt)
+# Measured multiply-add issue rates, profiles/r03_valu_rates.txt (csrc/microbench/valu_rates.hip, 16-ms runs, in-kernel clock recorded):
+#   v_mad_i64_i32 — the instruction every limb product compiles to — with 8 wavefronts per SIMD: 3.30e13 lane-ops/s at 2.32 GHz;
+#   with 2 wavefronts per SIMD — the occupancy of every 256-register kernel here — 2.84e13 at 2.40 GHz: a wavefront issues a 64-bit
+#   multiply-add every ~11 cycles, so two of them cannot saturate the pipe (dependent and independent chains alike).
+# Rounds 1-2 used 3.10e13 (v_mad_u64_u32 with vcc carry-out, a 1-ms run); `frac` below is against the higher, sustained figure.
+VALU_PEAK_MAC32 = 3.30e13
+VALU_PEAK_MAC32_2WAVES = 2.84e13
+VALU_PEAK_MAC32_R02 = 3.10e13
 # documented ceiling: a wave64 64-bit multiply-add occupies its SIMD for 4 cycles = 16 lanes per clock and SIMD,
 # 256 CUs x 4 SIMDs, 2.4 GHz maximum clock (MI355X_MICROARCH.md)
 VALU_PEAK_THEORETICAL_MAC32 = 256 * 4 * 16 * 2.4e9
@@ -258,10 +265,28 @@ def main():
         milk_ms, milk_launches = ctx.profile_read(6)
         fexk_ms, fexk_launches = ctx.profile_read(7)
         ctx.profile(False)
+        # The split kernels run on a plain grid of equally long wavefront tasks (21 elements each, 2048 resident): 2^16 elements are
+        # 3121 tasks = 1.52 machine rounds and take two full rounds.  The same kernels on exactly two rounds (86016 elements) show
+        # their rate without that quantisation (the pairing kernel hides it with its work queue).
+        nfr = 2 * 2048 * 21
+        rp = (nfr + npair - 1) // npair
+        fr_p = pair["p1"].repeat(rp)[: nfr * 96].contiguous()
+        fr_q = pair["q2"].repeat(rp)[: nfr * 192].contiguous()
+        fr_m = torch.empty(nfr * 576, dtype=torch.uint8, device=dev)
+        fr_f = torch.empty(nfr * 576, dtype=torch.uint8, device=dev)
+        ctx.miller_dev(nfr, fr_p.data_ptr(), fr_q.data_ptr(), fr_m.data_ptr())
+        ctx.gt_op_dev("fexp", nfr, fr_m.data_ptr(), None, fr_f.data_ptr())
+        torch.cuda.synchronize(dev)
+        fr_mil_el = timed(lambda: ctx.miller_dev(nfr, fr_p.data_ptr(), fr_q.data_ptr(), fr_m.data_ptr()), 2, 0)
+        fr_fex_el = timed(lambda: ctx.gt_op_dev("fexp", nfr, fr_m.data_ptr(), None, fr_f.data_ptr()), 2, 0)
+        if not torch.equal(fr_f[: npair * 576], fex):
+            raise SystemExit("bench: final exponentiations of the two-round batch differ from the 2^16 batch")
+        del fr_p, fr_q, fr_m, fr_f
         if ctx.sync() != 0:
             raise SystemExit("bench: invalid input reported by the split kernels")
         split = {"ng2": ng2, "steps": ssteps, "g2_el": g2_el, "mil_el": mil_el, "fex_el": fex_el, "g2k": (g2k_ms, g2k_launches),
-                 "milk": (milk_ms, milk_launches), "fexk": (fexk_ms, fexk_launches), "g2_in": g2_in, "g2_sc_h": g2_sc_h, "g2_out": g2_out,
+                 "milk": (milk_ms, milk_launches), "fexk": (fexk_ms, fexk_launches), "nfr": nfr, "fr_mil_ms": fr_mil_el / 2 * 1e3,
+                 "fr_fex_ms": fr_fex_el / 2 * 1e3, "g2_in": g2_in, "g2_sc_h": g2_sc_h, "g2_out": g2_out,
                  "mil": mil, "fex": fex}
 
     # ================================================================== configs[3]: MSM, n = 2^22 per GPU (weak) and sharded (strong)
@@ -457,7 +482,9 @@ def main():
             """the binding roofline: algorithmic multiply-adds per launch / average launch time against the measured multiply-add rate"""
             a = mac_per_unit * units / secs
             d = {"bound": "int-valu", "achieved": a / 1e9, "peak": VALU_PEAK_MAC32 / 1e9, "peak_theoretical": VALU_PEAK_THEORETICAL_MAC32 / 1e9,
-                 "unit": "GMAC32/s", "frac": a / VALU_PEAK_MAC32, "frac_of_theoretical": a / VALU_PEAK_THEORETICAL_MAC32, "traffic": tr,
+                 "peak_at_2_waves_per_simd": VALU_PEAK_MAC32_2WAVES / 1e9, "unit": "GMAC32/s", "frac": a / VALU_PEAK_MAC32,
+                 "frac_of_theoretical": a / VALU_PEAK_THEORETICAL_MAC32, "frac_of_2_wave_peak": a / VALU_PEAK_MAC32_2WAVES,
+                 "frac_vs_round2_peak": a / VALU_PEAK_MAC32_R02, "traffic": tr,
                  "algorithmic_mac32_per_unit": mac_per_unit, "avg_launch_ms": secs * 1e3}
             if kernel:
                 d["kernel"] = kernel
@@ -569,10 +596,17 @@ def main():
                                    split["mil_el"], split["milk"], MAC32_MILLER, 96 + 192 + 576, "miller3_kernel",
                                    "PAIR_ate: the 2^%d (P_i, Q_i) of the pairing leg -> 576-B Miller value each" % args.log2_pairings,
                                    {"checked_lanes": ns, "of": npair, "oracle": kind, "bit_exact": True}, mil_s)
+            result["miller"]["two_full_rounds"] = {"n": split["nfr"], "ms": split["fr_mil_ms"], "value": world * split["nfr"] / (split["fr_mil_ms"] * 1e-3),
+                                                   "roofline_frac": MAC32_MILLER * split["nfr"] / (split["fr_mil_ms"] * 1e-3) / VALU_PEAK_MAC32,
+                                                   "note": "2 x 2048 wavefronts x 21: the plain grid without its round quantisation (2^16 = 1.52 rounds runs as 2)"}
             result["fexp"] = leg("final exponentiations/s per MI355X (batch 2^%d per GPU)" % args.log2_pairings, "final exponentiations/s", npair,
                                  split["fex_el"], split["fexk"], MAC32_FEXP, 2 * 576, "gt3_op_kernel",
                                  "PAIR_fexp: the 2^%d Miller values above -> canonical GT" % args.log2_pairings,
                                  {"checked_lanes": npair, "of": npair, "oracle": "%s on %d lanes + every lane equal to the pairing leg's output" % (kind, ns), "bit_exact": True}, fx_s)
+
+            result["fexp"]["two_full_rounds"] = {"n": split["nfr"], "ms": split["fr_fex_ms"], "value": world * split["nfr"] / (split["fr_fex_ms"] * 1e-3),
+                                                 "roofline_frac": MAC32_FEXP * split["nfr"] / (split["fr_fex_ms"] * 1e-3) / VALU_PEAK_MAC32,
+                                                 "note": "as miller.two_full_rounds"}
 
         # ---------------------------------------------------------------- MSM
         if msm is not None:
