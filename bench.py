@@ -334,8 +334,7 @@ def main():
 
             def sharded_step():
                 if backend == "nccl":
-                    with torch.cuda.stream(stream):
-                        res[0] = msm_sharded_tensors(local_t, sp_, ss_, 96)
+                    res[0] = msm_sharded_tensors(local_t, sp_, ss_, 96, stream=stream)
                 else:
                     part = local_t(sp_, ss_, 96)
                     stream.synchronize()
@@ -493,7 +492,7 @@ def main():
         result = {
             "metric": "G1 scalar-muls/s per MI355X (batch 2^%d per GPU), bit-exact vs CPU" % args.log2_batch,
             "value": value, "unit": "scalar-muls/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "rccl_ranks": (dist.get_world_size() if dist else 1),
             "vs_baseline": None, "dtype": "int64 accumulate over 14x28-bit signed limbs", "data": "synthetic",
             "config": {"workload": "configs[1]: batch of 2^%d random G1 scalar-muls (96-B affine in, 32-B scalar, 96-B affine out) per GPU"
                                    % args.log2_batch, "batch_per_gpu": n, "parallelism": "independent shards x%d" % world},

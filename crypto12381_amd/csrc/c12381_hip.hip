@@ -33,6 +33,7 @@ inline const char* tuning_env(const char*) { return nullptr; }
 #endif
 // elements per scalar-mul launch: G1 = the lanes resident at the kernel's occupancy (256 CUs x 4 SIMDs x 64 lanes x waves per SIMD),
 // one machine-filling round per launch; G2 (two lanes per point) = two rounds.  Table slabs: 2816 B per lane (G1 352 MiB, G2 704 MiB at 2 waves)
+int g_queue_groups_host = 0;                    // experiments builds: C12381_QUEUE_GROUPS (the device copy is set alongside, k_pair3.hip)
 constexpr size_t G1_CHUNK = (size_t)65536 * C12381_G1_OCC;
 constexpr size_t G2_CHUNK = (size_t)65536 * C12381_G2H_OCC;
 constexpr int FLAG_WORDS = 4;                    // device status words (read_flag)
@@ -200,7 +201,7 @@ int g1_msm_pippenger(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t*
     // nbk digit buckets + ONE more (index nbk, key W << cb): the points whose scalar is below x^2 (msm.hpp)
     const size_t E = msm_entries(n, W), nb = (size_t)1 << cb, nbk = nb * W, nbx = nbk + 1;
     int rc;
-    if ((rc = ensure(c, c12381_ctx::WS_MSM_PTS, (size_t)2 * n * MSM_PT_DWORDS * 4))) return rc;
+    if ((rc = ensure(c, c12381_ctx::WS_MSM_PTS, (size_t)2 * n * MSM_PT_STRIDE * 4))) return rc;
     if ((rc = ensure(c, c12381_ctx::WS_MSM_K0, E * 4))) return rc;
     if ((rc = ensure(c, c12381_ctx::WS_MSM_K1, E * 4))) return rc;
     if ((rc = ensure(c, c12381_ctx::WS_MSM_V0, E * 4))) return rc;
@@ -358,7 +359,7 @@ int c12381_create(int device, c12381_ctx** out) {
         hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming) != hipSuccess) { c12381_destroy(c); return C12381_E_HIP; }
     if (hipMalloc((void**)&c->d_flag, FLAG_WORDS * sizeof(int)) != hipSuccess || hipHostMalloc((void**)&c->h_flag, FLAG_WORDS * sizeof(int)) != hipSuccess ||
         hipMemset(c->d_flag, 0, FLAG_WORDS * sizeof(int)) != hipSuccess) { c12381_destroy(c); return C12381_E_HIP; }
-    if (const char* e = tuning_env("C12381_QUEUE_GROUPS")) set_queue_groups_override(std::atoi(e));      // tuning runs only
+    if (const char* e = tuning_env("C12381_QUEUE_GROUPS")) { g_queue_groups_host = std::atoi(e); set_queue_groups_override(g_queue_groups_host); }      // tuning runs only
     *out = c;
     return 0;
 }
@@ -398,6 +399,18 @@ int c12381_sync(c12381_ctx* c) {
     return rc;
 }
 
+#ifdef C12381_EXPERIMENTS
+// experiments builds only (not declared in include/c12381_hip.h): start the clock probe on a stream of its own; `out` = 2 n device words
+extern "C" int c12381_exp_clock_probe(c12381_ctx* c, unsigned long long* out, int n, int gap) {
+    int rc = bind(c); if (rc) return rc;
+    if (!out || n <= 0 || gap < 0) return C12381_E_ARG;
+    static hipStream_t probe_stream = nullptr;          // its own stream: G1 / MSM work waits for the context's side stream
+    if (!probe_stream) HIPCK(c, hipStreamCreateWithFlags(&probe_stream, hipStreamNonBlocking));
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(BLOCK), 0, probe_stream, out, n, gap);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+#endif
 int c12381_profile(c12381_ctx* c, int enable) {
     int rc = bind(c); if (rc) return rc;
     HIPCK(c, hipStreamSynchronize(c->stream));
@@ -782,19 +795,31 @@ static bool pair_use_queue(size_t n) {
     if (m >= 0) return m == 1;
     return (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE > PAIR_QUEUE_WAVES;
 }
-// state slab: [flags: one word per group][task counter][whole-group counter][pad to 256 B][42 x 1 KiB per group]
+// the kernels' rule for how many groups bypass the queue (k_pair3.hip queue_direct_groups), mirrored for the slab size
+static size_t queue_direct_groups_host(size_t ngroups, size_t nwaves) {
+    if (ngroups <= nwaves) return 0;
+    size_t queued = ngroups / 3;
+    if (queued < nwaves / 2) queued = nwaves / 2;
+    if (queued > 2 * nwaves) queued = 2 * nwaves;
+    if (g_queue_groups_host > 0) queued = (size_t)g_queue_groups_host < ngroups ? (size_t)g_queue_groups_host : ngroups;
+    return ngroups - queued;
+}
+// state slab: [flags: one word per group][task counter][whole-group counter][pad to 256 B][42 x 1 KiB per QUEUED group] — whole
+// groups keep their state in registers and the LDS slot; 2^18 BBS+ verifications: 4096 blocks (172 MB) instead of 12484 (0.5 GB)
 static int pair_queue_setup(c12381_ctx* c, size_t n, uint4*& state, unsigned int*& flags, unsigned int*& counter, unsigned& blocks) {
     const size_t groups = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE;
     const size_t head = round_up((groups + 2) * 4, 256);          // flags | task counter | whole-group counter
+    const size_t waves = groups < PAIR_QUEUE_WAVES ? groups : PAIR_QUEUE_WAVES;
+    blocks = (unsigned)((waves * 64 + BLOCK - 1) / BLOCK);
+    const size_t nwaves = (size_t)blocks * (BLOCK / 64);
+    const size_t nq = groups - queue_direct_groups_host(groups, nwaves);
     int rc;
-    if ((rc = ensure(c, c12381_ctx::WS_PAIR_ST, head + groups * (size_t)PAIR_QUEUE_STATE_ROWS * 1024))) return rc;
+    if ((rc = ensure(c, c12381_ctx::WS_PAIR_ST, head + nq * (size_t)PAIR_QUEUE_STATE_ROWS * 1024))) return rc;
     uint8_t* base = (uint8_t*)c->ws[c12381_ctx::WS_PAIR_ST];
     flags = (unsigned int*)base;
     counter = flags + groups;
     state = (uint4*)(base + head);
     HIPCK(c, hipMemsetAsync(base, 0, (groups + 2) * 4, c->stream));
-    const size_t waves = groups < PAIR_QUEUE_WAVES ? groups : PAIR_QUEUE_WAVES;
-    blocks = (unsigned)((waves * 64 + BLOCK - 1) / BLOCK);
     return 0;
 }
 static int launch_pair(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt) {

@@ -326,20 +326,25 @@ template <class F> C12381_HDN void g2_scalar_mul(g2pt<F>& acc, const F& qx, cons
         tab_store_g2(lane_tab + (j - 1) * g2_ent_dwords(n), n);
         t = n;
     }
-    g2_set_inf(acc);
+    // the running point is a LOCAL of this loop: `acc` is a reference into the caller's memory, and a table load may alias it as far as
+    // the compiler knows — through the reference every doubling and addition stored the point back (19 KB of private-memory writes per
+    // lane and scalar multiplication, 6 GB per launch: profiles/r03_pmc_summary.json)
+    g2pt<F> run;
+    g2_set_inf(run);
 #pragma unroll 1
     for (int w = G2_WINDOWS - 1; w >= 0; --w) {
         if (w != G2_WINDOWS - 1) {
             if (g2_inline_loop<F>::value) {
 #pragma unroll 1
-                for (int i = 0; i < G2_WIN; ++i) { F a, b, c; g2_dbl_core(acc, a, b, c); }
-            } else g2_dbl_n(acc, G2_WIN);
+                for (int i = 0; i < G2_WIN; ++i) { F a, b, c; g2_dbl_core(run, a, b, c); }
+            } else g2_dbl_n(run, G2_WIN);
         }
-        g2_add_digit<0>(acc, lane_tab, gs_digit(ub[0], w));
-        g2_add_digit<1>(acc, lane_tab, gs_digit(ub[1], w));
-        g2_add_digit<2>(acc, lane_tab, gs_digit(ub[2], w));
-        g2_add_digit<3>(acc, lane_tab, gs_digit(ub[3], w));
+        g2_add_digit<0>(run, lane_tab, gs_digit(ub[0], w));
+        g2_add_digit<1>(run, lane_tab, gs_digit(ub[1], w));
+        g2_add_digit<2>(run, lane_tab, gs_digit(ub[2], w));
+        g2_add_digit<3>(run, lane_tab, gs_digit(ub[3], w));
     }
+    acc = run;
     const bool z1 = (u[1][0] | u[1][1]) == 0u, z3 = (u[3][0] | u[3][1]) == 0u;
     if ((z1 || z3) && !in_g2) g2_gs_zero_digit_terms(acc, base, z1, z3);
 }

@@ -122,6 +122,18 @@ __global__ void __launch_bounds__(BLOCK, 2) g2_add_kernel(size_t n, const uint8_
 }
 
 #ifdef C12381_EXPERIMENTS
+// Diagnostic: the clock the chip holds while another kernel runs.  ONE lane samples (s_memtime = shader cycles, s_memrealtime = 100 MHz)
+// every `gap` sleeps of 127 x 64 cycles and is launched on the context's side stream beside the kernel under study
+// (c12381_exp_clock_probe, tools/clock_probe.py): clock = d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS item 6).
+__global__ void __launch_bounds__(BLOCK, 2) clock_probe_kernel(unsigned long long* out, int n, int gap) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int i = 0; i < n; ++i) {
+        out[2 * i] = __builtin_amdgcn_s_memtime();
+        out[2 * i + 1] = __builtin_amdgcn_s_memrealtime();
+        for (int j = 0; j < gap; ++j) __builtin_amdgcn_s_sleep(127);
+    }
+}
+
 // The first design — one pairing per lane (pairing.hpp) — superseded by the three-lane kernels of k_pair3.hip; kept in experiments
 // builds as an independent implementation for whole-batch cross-checks (tests/test_gpu_variants.py, C12381_PAIR_LANES=1).
 __global__ void __launch_bounds__(BLOCK, 2) pair_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag) {

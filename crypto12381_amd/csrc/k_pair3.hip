@@ -263,7 +263,7 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
         if (stamps) ts_claim = __builtin_amdgcn_s_memtime();
         const bool poisoned = queue_wait(flags, g, p, spin_limit);
         if (stamps) ts_start = __builtin_amdgcn_s_memtime();
-        uint4* st = state + g * (size_t)ROWS * 64;
+        uint4* st = state + (g - ndirect) * (size_t)ROWS * 64;        // only the queued groups own a state block (pair_queue_setup)
         if (poisoned) {
             if (p == TASKS - 1 && active) {
                 bad_flag[1] = 1;
@@ -460,7 +460,7 @@ __device__ __forceinline__ void pair3_fixed_queue_body(size_t n, const uint8_t* 
         const bool active = lane < 63u && e < n;
         const size_t i = e < n ? e : n - 1;
         const bool poisoned = queue_wait(flags, g, p, spin_limit);
-        uint4* st = state + g * (size_t)ROWS * 64;
+        uint4* st = state + (g - ndirect) * (size_t)ROWS * 64;        // only the queued groups own a state block (pair_queue_setup)
         fp ax, ay, cx, cy; bool ainf, cinf = true, oka, okc = true;
         if (!poisoned && (p < MILLER_TASKS || p == TASKS - 1)) {
             g1_parse96(ax, ay, ainf, oka, a96 + 96 * i);

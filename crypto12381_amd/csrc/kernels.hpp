@@ -66,6 +66,7 @@ __global__ void __launch_bounds__(BLOCK, 2) g2_lift_kernel(size_t n, const uint8
 __global__ void __launch_bounds__(BLOCK, 2) g2_reduce_kernel(size_t n, const int32_t* in, size_t in_stride, size_t m, int32_t* outp, size_t out_stride);
 __global__ void __launch_bounds__(BLOCK, 2) g2_add_kernel(size_t n, const uint8_t* a, size_t a_stride, const uint8_t* b, uint8_t* out, int fmt, int* bad_flag, const int32_t* skip_if);
 #ifdef C12381_EXPERIMENTS      // the superseded one-lane pairing kernels (k_g2gt.hip): experiments builds only
+__global__ void __launch_bounds__(BLOCK, 2) clock_probe_kernel(unsigned long long* out, int n, int gap);
 __global__ void __launch_bounds__(BLOCK, 2) pair_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) pair_eq_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, size_t b2_stride, uint8_t* out, int* bad_flag);
 #endif

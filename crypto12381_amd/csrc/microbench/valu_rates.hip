@@ -354,6 +354,10 @@ int main(int argc, char** argv) {
     // and the instruction mix of one fp_mul column
     if (run_rate<16>("v_mad_i64_i32", 16, fo)) return 1;
     if (run_rate<16>("v_mad_i64_i32", 16, fo, 256 * 2)) return 1;
+    if (run_rate<16>("v_mad_i64_i32", 16, fo, 256 * 2, ITERS * 64)) return 1;      // the same, 4 x longer: the clock a 20-ms kernel holds
+    if (run_rate<16>("v_mad_i64_i32", 16, fo, 256 * 3)) return 1;
+    if (run_rate<16>("v_mad_i64_i32", 16, fo, 256 * 4)) return 1;
+    if (run_rate<16>("v_mad_i64_i32", 16, fo, 256 * 1)) return 1;
     if (run_rate<17>("v_mad_i64_i32_dependent", 16, fo)) return 1;
     if (run_rate<17>("v_mad_i64_i32_dependent", 16, fo, 256 * 2)) return 1;
     if (run_rate<18>("fp_mul_column_mix(12mad+4)", 16, fo)) return 1;

@@ -23,6 +23,13 @@
 namespace c12381 {
 
 constexpr int MSM_PT_DWORDS = 2 * NL;          // affine (x, y) in Montgomery form, normalised limbs: 112 B, seven 16-byte words
+// stride of the records in the MSM's point array: 128 B, one cache line per gathered point.  Packed 112-byte records straddle two
+// lines more often than not — the bucket kernel's gathers then fetched 16.6 GB per 2^22-term product for 7.5 GB of records
+// (profiles/r03_pmc_summary.json).  -DC12381_MSM_PT_STRIDE=28 restores the packed layout (A/B).
+#ifndef C12381_MSM_PT_STRIDE
+#define C12381_MSM_PT_STRIDE 32
+#endif
+constexpr int MSM_PT_STRIDE = C12381_MSM_PT_STRIDE;
 constexpr int MSM_CHUNK = 16;                  // buckets per lane in the window reduction
 // entries a bucket lane sums at most: twice the mean run + 32 (uniform scalars: mean + 11 sigma or more, so nothing is
 // cut); the rest of a longer run is cut into overflow segments of half that length, one lane each (k_g1.hip).  A lane
@@ -106,8 +113,8 @@ C12381_HD bool msm_prep_one(size_t i, size_t n, const uint32_t* raw_pt /*24 word
     fp_mul(bx, px, beta);
     fp_neg(ny, py);
     fp_norm1(nyn, ny);
-    msm_store_pt(pts2 + (2 * i) * MSM_PT_DWORDS, px, py);
-    msm_store_pt(pts2 + (2 * i + 1) * MSM_PT_DWORDS, bx, nyn);
+    msm_store_pt(pts2 + (2 * i) * MSM_PT_STRIDE, px, py);
+    msm_store_pt(pts2 + (2 * i + 1) * MSM_PT_STRIDE, bx, nyn);
     uint32_t k[8];
     scalar_from_raw32(k, raw_sc);
     scalar_mod_r(k);
@@ -143,13 +150,13 @@ C12381_HD void msm_bucket_one(g1p& acc, size_t lo, size_t hi, const uint32_t* va
     g1_set_inf(acc);
     if (lo >= hi) return;
     fp xn, yn;
-    msm_load_pt(xn, yn, pts2 + (size_t)vals_sorted[lo] * MSM_PT_DWORDS);
+    msm_load_pt(xn, yn, pts2 + (size_t)vals_sorted[lo] * MSM_PT_STRIDE);
     uint32_t idx_next = lo + 1 < hi ? vals_sorted[lo + 1] : 0u;
 #pragma unroll 1
     for (size_t j = lo; j < hi; ++j) {
         const fp x = xn, y = yn;
         if (j + 1 < hi) {
-            msm_load_pt(xn, yn, pts2 + (size_t)idx_next * MSM_PT_DWORDS);
+            msm_load_pt(xn, yn, pts2 + (size_t)idx_next * MSM_PT_STRIDE);
             idx_next = j + 2 < hi ? vals_sorted[j + 2] : 0u;
         }
         g1_add_affine(acc, x, y);

@@ -47,14 +47,32 @@ def msm_sharded(local_msm: Callable[[bytes, bytes, int], bytes], pts_shard: byte
 
 
 def msm_sharded_tensors(local_msm_t: Callable[[torch.Tensor, torch.Tensor, int], torch.Tensor], pts_shard: torch.Tensor,
-                        scalars_shard: torch.Tensor, out_fmt: int = 49, group=None) -> torch.Tensor:
+                        scalars_shard: torch.Tensor, out_fmt: int = 49, group=None, stream=None) -> torch.Tensor:
     """Device-resident form of msm_sharded: the partial point never visits the host.
 
     local_msm_t(points96 uint8 tensor, scalars32 uint8 tensor, fmt) -> uint8 tensor of fmt bytes on the same device
     (on the GPU box: c12381_g1_msm_dev on the context's stream; the CPU tests inject the oracle on CPU tensors).
     The exchange is ONE all_gather_into_tensor of 96 B per rank on the tensors' own device — RCCL over xGMI when the
     process group is "nccl" —, the combine is the local product of the N partial points with unit scalars, again
-    through local_msm_t, so every rank ends with the same bytes."""
+    through local_msm_t, so every rank ends with the same bytes.
+
+    Stream ordering (device tensors): `stream` is the torch.cuda.Stream the library context enqueues on
+    (Context.set_stream(stream.cuda_stream)).  The function makes that stream wait for the caller's current stream (the
+    inputs), runs the local products, the allocation of the gather buffer, the collective and the fill of the unit scalars
+    under `torch.cuda.stream(stream)` — so all of them are ordered with the library's kernels — and makes the caller's stream
+    wait for the result.  Without `stream` the caller vouches that local_msm_t enqueues on torch's current stream."""
+    dev = pts_shard.device
+    if stream is not None and dev.type == "cuda":
+        caller = torch.cuda.current_stream(dev)
+        stream.wait_stream(caller)
+        with torch.cuda.stream(stream):
+            out = _msm_sharded_tensors(local_msm_t, pts_shard, scalars_shard, out_fmt, group)
+        caller.wait_stream(stream)
+        return out
+    return _msm_sharded_tensors(local_msm_t, pts_shard, scalars_shard, out_fmt, group)
+
+
+def _msm_sharded_tensors(local_msm_t, pts_shard, scalars_shard, out_fmt, group):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     dev = pts_shard.device
     if pts_shard.numel():

@@ -404,7 +404,7 @@ extern "C" int sim_g1_msm_pippenger(size_t n, const uint8_t* pts96, const uint8_
     const int c = force_c > 0 ? force_c : msm_window_bits(n);
     const int W = msm_windows(c);
     const size_t E = msm_entries(n, W);
-    std::vector<int32_t> pts2v((size_t)2 * n * MSM_PT_DWORDS + 4);
+    std::vector<int32_t> pts2v((size_t)2 * n * MSM_PT_STRIDE + 4);
     int32_t* pts2 = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(pts2v.data()) + 15) & ~(uintptr_t)15);
     std::vector<uint32_t> keys(E), vals(E);
     for (size_t i = 0; i < n; ++i) {

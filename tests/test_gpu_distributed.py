@@ -135,11 +135,12 @@ tp = torch.frombuffer(bytearray(pts), dtype=torch.uint8).to(dev)
 ts = torch.frombuffer(bytearray(sc), dtype=torch.uint8).to(dev)
 def local_t(p, s, fmt):
     o = torch.empty(fmt, dtype=torch.uint8, device=dev)
-    with torch.cuda.stream(stream):
-        ctx.g1_msm_dev(p.numel() // 96, p.data_ptr(), s.data_ptr(), o.data_ptr(), fmt)
+    ctx.g1_msm_dev(p.numel() // 96, p.data_ptr(), s.data_ptr(), o.data_ptr(), fmt)
     return o
-with torch.cuda.stream(stream):
-    res = msm_sharded_tensors(local_t, tp, ts, 49)
+# the caller stays on torch's default stream; the function orders the context's stream against it (stream=...)
+tp2 = tp.clone() ^ 0                       # produced on the default stream just before the call
+res = msm_sharded_tensors(local_t, tp2, ts, 49, stream=stream)
+res = res.clone()                          # consumed on the default stream right after
 ctx.sync()
 print('RESULT', bytes(res.cpu().numpy().tobytes()).hex())
 print('EXPECT', ctx.g1_msm(pts, sc, 49).hex())
@@ -156,3 +157,31 @@ def test_rccl_exchange_on_device_tensors_single_rank():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = dict(l.split(" ", 1) for l in r.stdout.splitlines() if l.startswith(("RESULT", "EXPECT")))
     assert lines["RESULT"] == lines["EXPECT"]
+
+
+def test_bench_two_ranks_on_one_gpu_dry_run():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per process), rehearsed on the ONE GPU of the test
+    box with the gloo backend and small batches: the strong-scaled legs exist, the sharded MSM equals the single-GPU value on every rank,
+    both ranks took part, and the rank-local preparation (exponent sum over all terms in Python, signature generation) stays small."""
+    import json
+    import subprocess
+    import sys
+    import time
+    env = dict(os.environ)
+    env["C12381_BENCH_BACKEND"] = "gloo"
+    env.pop("C12381_LIB", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547",
+           "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--log2-batch", "14", "--log2-pairings", "10", "--log2-g2", "12", "--log2-msm", "14",
+           "--log2-bbs", "12", "--no-cpu-baseline", "--sampled-parity"]
+    t0 = time.perf_counter()
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    wall = time.perf_counter() - t0
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "weak"
+    assert d["msm_sharded"]["equals_single_gpu"] is True and d["msm_sharded"]["same_on_every_rank"] is True and d["msm_sharded"]["rccl_ranks"] == 2
+    assert d["bbs_plus_sharded"]["accepted"] > 0
+    for leg in ("pairing", "g2_mul", "miller", "fexp", "msm", "bbs_plus"):
+        assert leg in d and d[leg]["value"] > 0, leg
+    assert wall < 600, "the two-rank dry run took %.0f s" % wall
