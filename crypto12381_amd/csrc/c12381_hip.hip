@@ -294,7 +294,7 @@ int g1_msm_pippenger(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t*
     hipLaunchKernelGGL(msm_overflow_combine_kernel, dim3(ovf_cap < 4096 ? (unsigned)((ovf_cap + 3) / 4) : 1024u), dim3(BLOCK), 0, c->stream,
                        (const uint32_t*)ovf_cnt, (const uint4*)ovf_big, (const int32_t*)ovf_part, bk);
     HIPCK(c, hipGetLastError());
-    // the [r]phi(S) owed by scalars below x^2 (record in the counters' page): one lane, ~1.3 ms when any scalar was small —
+    // the [r]phi(S) owed by scalars below x^2 (record in the counters' page): one quad, ~0.5 ms when any scalar was small —
     // on the side stream, behind the window reductions that the Horner lane has to wait for anyway
     int32_t* small_term = (int32_t*)(ovf + 64);
     if (c->ev_chunk.empty()) {

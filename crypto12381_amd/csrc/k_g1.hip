@@ -465,17 +465,6 @@ __global__ void __launch_bounds__(BLOCK, 2) g1_wave_reduce_kernel(size_t groups,
     if (lane == 0) soa_store_g1(outp, out_stride, g * (size_t)W + w, acc);
 }
 
-// term = [r]phi(S) for S = bucket `sbucket`, the sum of the points whose scalar is below x^2 (msm.hpp: msm_small_term — a
-// membership test of 128 doublings in one lane when any scalar was small, an immediate return otherwise)
-__global__ void __launch_bounds__(BLOCK, 2) msm_small_term_kernel(const int32_t* sbucket, int32_t* term_out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    g1p S, term, nn;
-    tab_load_g1(S, sbucket);
-    msm_small_term(term, S);
-    g1_norm1(nn, term);
-    tab_store_g1(term_out, nn);
-}
-
 // A doubling spread over FOUR lanes (the Horner chain is 112 dependent doublings in a single lane otherwise: ~1.1 ms of an
 // MSM, a third of a small one).  The point is replicated in the lanes of a quad; the eight products of g1_dbl form two rounds
 // of four independent ones — Y^2, YZ, Z^2, XY, then t1*z8, u*y3, t2*z8, u*xy — so lane r of the quad computes product r
@@ -516,6 +505,58 @@ __device__ __forceinline__ void g1_dbl_quad(g1p& p, int r) {
     fp_add(p.y, ya, yb);
     fp_dbl(p.x, xh);
 }
+// p <- [|x|]p on a quad (the point replicated in its four lanes): the 63 doublings of the double-and-add chain run as g1_dbl_quad,
+// the 5 additions are replicated
+__device__ __forceinline__ void g1_mul_absx_quad(g1p& p, int r) {
+    g1p base, acc, nn;
+    g1_norm1(base, p);
+    acc = base;
+#pragma unroll 1
+    for (int i = 62; i >= 0; --i) {
+        g1_dbl_quad(acc, r);
+        if ((BLS_X_W[i >> 5] >> (i & 31)) & 1u) { g1_norm1(nn, acc); g1_add(nn, base); acc = nn; }
+    }
+    p = acc;
+}
+// term = [r]phi(S) for S = bucket `sbucket`, the sum of the points whose scalar is below x^2 (msm.hpp) — g1_glv_small_scalar_term's
+// sequence on ONE QUAD: a membership test of 126 doublings (phi(phi(S)) = [-x^2]phi(S) iff S is in G1) when any scalar was small,
+// the 255-bit multiple only for S outside G1, an immediate return for an empty bucket.  A single lane took 1.57 ms for the test —
+// longer than the window reductions it hides behind on the side stream; the quad takes a third of that.
+__global__ void __launch_bounds__(BLOCK, 2) msm_small_term_kernel(const int32_t* sbucket, int32_t* term_out) {
+    if (threadIdx.x >= 4 || blockIdx.x != 0) return;
+    const int r = (int)(threadIdx.x & 3u);
+    g1p S, term, nn;
+    tab_load_g1(S, sbucket);
+    g1_set_inf(term);
+    if (!g1_is_inf(S)) {                                       // quad-uniform
+        fp beta;
+        fp_set_const(beta, FP_BETA_A);
+        g1p q, s1, t;
+        fp_mul(q.x, S.x, beta); q.y = S.y; q.z = S.z;          // phi(S)
+        g1_norm1(q, q);
+        s1 = q;
+        g1_mul_absx_quad(s1, r); g1_mul_absx_quad(s1, r);      // [x^2]phi(S)
+        g1_norm1(s1, s1);
+        fp_mul(t.x, q.x, beta); t.y = q.y; t.z = q.z;          // phi(phi(S))
+        g1_norm1(t, t);
+        g1p u = s1;
+        g1_add(u, t);
+        if (!g1_is_inf(u)) {                                   // S outside G1: [r]Q = [x^4]Q - [x^2]Q + Q for Q = phi(S)
+            g1p s2 = s1;
+            g1_mul_absx_quad(s2, r); g1_mul_absx_quad(s2, r);
+            fp_neg(t.y, s1.y); t.x = s1.x; t.z = s1.z;
+            g1_norm1(t, t);
+            g1_norm1(s2, s2);
+            g1_add(s2, t);
+            g1_norm1(s2, s2);
+            g1_add(s2, q);
+            term = s2;
+        }
+    }
+    g1_norm1(nn, term);
+    if (r == 0) tab_store_g1(term_out, nn);
+}
+
 // R = sum_w 2^(c w) R_w + term: the Horner chain on one quad (lanes 0..3 of a wavefront), doublings spread over its lanes
 __global__ void __launch_bounds__(64, 1) msm_horner_kernel(const int32_t* rw, size_t stride, int W, int c, int32_t* out, size_t out_stride,
                                                         const int32_t* term_in) {
