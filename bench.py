@@ -459,7 +459,7 @@ def main():
         launches_per_step = mul_launches / max(args.steps, 1)
         units_per_launch = n / max(launches_per_step, 1)
         avg_launch_s = (mul_ms / max(mul_launches, 1)) * 1e-3
-        traffic = pair_traffic = msm_traffic = bbs_traffic = None
+        traffic = pair_traffic = msm_traffic = bbs_traffic = g2_traffic = None
         tr_path = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tr_path):
             try:
@@ -468,7 +468,7 @@ def main():
                 if pair is not None:
                     pair_traffic = tj["pair_kernel"]["hbm_bytes_per_launch"] * pair["npair"] / tj["pair_kernel"]["units_per_launch"]
             except Exception:
-                traffic = pair_traffic = msm_traffic = bbs_traffic = None
+                traffic = pair_traffic = msm_traffic = bbs_traffic = g2_traffic = None
 
         def hbm(bytes_per_unit, units, secs, kernel, tr=None, **more):
             a = bytes_per_unit * units / secs / 1e9
@@ -577,20 +577,20 @@ def main():
             if f_cpu != fex_h[:ns].tobytes() or not (fex_h == gt_h).all():
                 raise SystemExit("bench: GPU final exponentiations differ from the CPU oracle / the pairing outputs — number withheld")
 
-            def leg(metric, unit, units, el, kprof, mac, nbytes, kernel, workload, parity, cpu_s):
+            def leg(metric, unit, units, el, kprof, mac, nbytes, kernel, workload, parity, cpu_s, tr=None):
                 k_s = kprof[0] / max(kprof[1], 1) * 1e-3
                 launches_per_step = kprof[1] / max(st, 1)
                 d = {"metric": metric, "value": world * units * st / el, "unit": unit, "steps": st, "ms_per_step": el / st * 1e3,
                      "config": {"workload": workload}, "parity": parity,
-                     "roofline": valu(mac, units / max(launches_per_step, 1), k_s, kernel, None, launches_per_step=launches_per_step),
-                     "hbm_roofline": hbm(nbytes, units / max(launches_per_step, 1), k_s, kernel)}
+                     "roofline": valu(mac, units / max(launches_per_step, 1), k_s, kernel, tr, launches_per_step=launches_per_step),
+                     "hbm_roofline": hbm(nbytes, units / max(launches_per_step, 1), k_s, kernel, tr)}
                 if do_cpu:
                     d["cpu_baseline"] = {"value": ns / cpu_s, "unit": unit, "cores": cores, "kind": kind, "sample": "first %d lanes of the same batch, %d threads" % (ns, cores)}
                 return d
             result["g2_mul"] = leg("G2 scalar-muls/s per MI355X (batch 2^%d per GPU), bit-exact vs CPU" % args.log2_g2, "scalar-muls/s", ng2, split["g2_el"],
                                    split["g2k"], MAC32_G2_MUL, BYTES_G2_MUL, "g2_mul2_kernel",
                                    "PAIR_G2mul: 2^%d random (point, scalar) pairs, 192-B affine in / out, 32-B scalars (edge scalars in lanes 0..4)" % args.log2_g2,
-                                   {"checked_lanes": ns, "of": ng2, "oracle": kind, "bit_exact": True}, g2_s)
+                                   {"checked_lanes": ns, "of": ng2, "oracle": kind, "bit_exact": True}, g2_s, g2_traffic)
             result["miller"] = leg("Miller loops/s per MI355X (batch 2^%d per GPU), the reference's field element" % args.log2_pairings, "Miller loops/s", npair,
                                    split["mil_el"], split["milk"], MAC32_MILLER, 96 + 192 + 576, "miller3_kernel",
                                    "PAIR_ate: the 2^%d (P_i, Q_i) of the pairing leg -> 576-B Miller value each" % args.log2_pairings,

@@ -7,7 +7,9 @@
 //   * limbs are carried lazily: add/sub/neg are 14 independent v_add/v_sub with no carry
 //     chain and no conditional subtraction; values may be negative or exceed p.
 //   * a product is scanned column by column into ONE 64-bit accumulator with
-//     v_mad_i64_i32 (measured on MI355X at ~the v_add rate, profiles/r01_valu_rates.txt),
+//     v_mad_i64_i32 (measured on MI355X, profiles/r03_valu_rates.txt: HALF the v_add_u32 rate — 56 against 110 lanes per
+//     clock and CU with eight wavefronts per SIMD, 46 with the two that a 256-register kernel has; the same rate as
+//     v_mul_lo_u32, a 64-bit shift or an add-with-carry pair),
 //     Montgomery reduction interleaved in the same columns — no carry flags anywhere.
 //   * invariants are tracked as two bounds per element: LB = max |limb| and VB = |value|/p.
 //     fp_mul needs 14*LBa*LBb + 14*2^56 + 2^40 < 2^63 and returns limbs 0..12 in [0,2^28) with

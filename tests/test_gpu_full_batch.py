@@ -91,3 +91,37 @@ def test_every_lane_of_2_20_g1_multiplications_vs_oracle(ctx, orc):
     # compressed output: tag = 02 | parity(y), x as in the affine form (ECP_toOctet ecp_BLS12381.cpp:478-488)
     inf = ~out.any(axis=1)
     assert (comp[~inf, 1:] == out[~inf, :48]).all() and (comp[~inf, 0] == (2 | (out[~inf, 95] & 1))).all() and not comp[inf].any()
+
+
+def test_every_lane_of_2_16_g2_multiplications_vs_oracle(ctx, orc):
+    """multiply(point2&, big) src/miracl_core_interface.cpp:202-205 -> PAIR_G2mul pair_BLS12381.cpp:927-983 (gs() :814-873): every lane of
+    a 2^16 batch on the two-lane kernel (signed 5-bit windows, shared reductions) against the compiled reference — random points of G2,
+    256-bit scalars, the edge scalars incl. zero odd base-|x| digits, infinity, and the golden points OUTSIDE G2 (where the reference's
+    endomorphism-based result is not [k]Q) spliced into the batch."""
+    n = 1 << 16
+    g2 = bytes.fromhex(golden("g2")["generator"])
+    pts = bytearray(ctx.g2_mul_fixed(g2, _rand_scalars(9301, n, True).tobytes(), 192))
+    sc = _rand_scalars(9302, n)
+    X = 0xd201000000010000
+    edges = [0, 1, R - 1, R, R + 1, (1 << 256) - 1, X, X * X, X ** 3, 5 + 7 * X * X, 11 * X + 13 * X ** 3, (1 << 64) - 1]      # u1 = 0 / u3 = 0 lanes
+    for j, k in enumerate(edges):
+        sc[j] = np.frombuffer((k % (1 << 256)).to_bytes(32, "big"), dtype=np.uint8)
+    pts[192 * 20:192 * 21] = bytes(192)                        # infinity input
+    g = golden("g2")
+    from util import cat
+    off, offs = cat(g["offsubgroup_points"]), cat(g["offsubgroup_scalars"])
+    small, smalls = cat(g["offsubgroup_small_points"]), cat(g["offsubgroup_small_scalars"])
+    k1, k2 = len(offs) // 32, len(smalls) // 32
+    pts[192 * 100:192 * (100 + k1)] = off
+    sc[100:100 + k1] = np.frombuffer(offs, dtype=np.uint8).reshape(k1, 32)
+    pts[192 * 200:192 * (200 + k2)] = small
+    sc[200:200 + k2] = np.frombuffer(smalls, dtype=np.uint8).reshape(k2, 32)
+    pts, scb = bytes(pts), sc.tobytes()
+    out = np.frombuffer(ctx.g2_mul(pts, scb, 192), dtype=np.uint8).reshape(n, 192)
+    exp = np.frombuffer(orc.g2_mul(pts, scb, 192, THREADS), dtype=np.uint8).reshape(n, 192)
+    bad = np.nonzero((out != exp).any(axis=1))[0]
+    assert len(bad) == 0, _describe(bad, 32)
+    assert out[100:100 + k1].tobytes() == cat(g["offsubgroup_mul192"]) and out[200:200 + k2].tobytes() == cat(g["offsubgroup_small_mul192"])
+    comp = np.frombuffer(ctx.g2_mul(pts, scb, 97), dtype=np.uint8).reshape(n, 97)
+    expc = np.frombuffer(orc.g2_mul(pts, scb, 97, THREADS), dtype=np.uint8).reshape(n, 97)
+    assert (comp == expc).all()
