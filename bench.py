@@ -265,28 +265,10 @@ def main():
         milk_ms, milk_launches = ctx.profile_read(6)
         fexk_ms, fexk_launches = ctx.profile_read(7)
         ctx.profile(False)
-        # The split kernels run on a plain grid of equally long wavefront tasks (21 elements each, 2048 resident): 2^16 elements are
-        # 3121 tasks = 1.52 machine rounds and take two full rounds.  The same kernels on exactly two rounds (86016 elements) show
-        # their rate without that quantisation (the pairing kernel hides it with its work queue).
-        nfr = 2 * 2048 * 21
-        rp = (nfr + npair - 1) // npair
-        fr_p = pair["p1"].repeat(rp)[: nfr * 96].contiguous()
-        fr_q = pair["q2"].repeat(rp)[: nfr * 192].contiguous()
-        fr_m = torch.empty(nfr * 576, dtype=torch.uint8, device=dev)
-        fr_f = torch.empty(nfr * 576, dtype=torch.uint8, device=dev)
-        ctx.miller_dev(nfr, fr_p.data_ptr(), fr_q.data_ptr(), fr_m.data_ptr())
-        ctx.gt_op_dev("fexp", nfr, fr_m.data_ptr(), None, fr_f.data_ptr())
-        torch.cuda.synchronize(dev)
-        fr_mil_el = timed(lambda: ctx.miller_dev(nfr, fr_p.data_ptr(), fr_q.data_ptr(), fr_m.data_ptr()), 2, 0)
-        fr_fex_el = timed(lambda: ctx.gt_op_dev("fexp", nfr, fr_m.data_ptr(), None, fr_f.data_ptr()), 2, 0)
-        if not torch.equal(fr_f[: npair * 576], fex):
-            raise SystemExit("bench: final exponentiations of the two-round batch differ from the 2^16 batch")
-        del fr_p, fr_q, fr_m, fr_f
         if ctx.sync() != 0:
             raise SystemExit("bench: invalid input reported by the split kernels")
         split = {"ng2": ng2, "steps": ssteps, "g2_el": g2_el, "mil_el": mil_el, "fex_el": fex_el, "g2k": (g2k_ms, g2k_launches),
-                 "milk": (milk_ms, milk_launches), "fexk": (fexk_ms, fexk_launches), "nfr": nfr, "fr_mil_ms": fr_mil_el / 2 * 1e3,
-                 "fr_fex_ms": fr_fex_el / 2 * 1e3, "g2_in": g2_in, "g2_sc_h": g2_sc_h, "g2_out": g2_out,
+                 "milk": (milk_ms, milk_launches), "fexk": (fexk_ms, fexk_launches), "g2_in": g2_in, "g2_sc_h": g2_sc_h, "g2_out": g2_out,
                  "mil": mil, "fex": fex}
 
     # ================================================================== configs[3]: MSM, n = 2^22 per GPU (weak) and sharded (strong)
@@ -326,22 +308,23 @@ def main():
                     ctx.g1_msm_dev(p.numel() // 96, p.data_ptr(), s.data_ptr(), o.data_ptr(), fmt)
                 return o
 
-            def local_comm(p, s, fmt):                                 # gloo rehearsal: the exchange runs on CPU tensors
-                if p.device.type == "cpu":
-                    return local_t(p.to(dev), s.to(dev), fmt).cpu()
-                return local_t(p, s, fmt)
+            def sum_t(p, fmt):                                         # the combine: plain sum of the N partial points
+                o = torch.empty(fmt, dtype=torch.uint8, device=dev)
+                with torch.cuda.stream(stream):
+                    ctx.g1_sum_dev(p.numel() // 96, p.data_ptr(), o.data_ptr(), fmt)
+                return o
+
             res = [None]
 
             def sharded_step():
                 if backend == "nccl":
-                    res[0] = msm_sharded_tensors(local_t, sp_, ss_, 96, stream=stream)
+                    res[0] = msm_sharded_tensors(local_t, sp_, ss_, 96, stream=stream, combine_t=sum_t)
                 else:
                     part = local_t(sp_, ss_, 96)
                     stream.synchronize()
                     g = torch.empty(96 * world, dtype=torch.uint8)
                     dist.all_gather_into_tensor(g, part.cpu())
-                    ones = torch.zeros(world, 32, dtype=torch.uint8); ones[:, 31] = 1
-                    res[0] = local_t(g.to(dev), ones.reshape(-1).to(dev), 96)
+                    res[0] = sum_t(g.to(dev), 96)
             sel = timed(sharded_step, msteps, 1)
             mine = res[0].to(comm_dev)
             allres = torch.empty(96 * world, dtype=torch.uint8, device=comm_dev)
@@ -592,20 +575,14 @@ def main():
                                    "PAIR_G2mul: 2^%d random (point, scalar) pairs, 192-B affine in / out, 32-B scalars (edge scalars in lanes 0..4)" % args.log2_g2,
                                    {"checked_lanes": ns, "of": ng2, "oracle": kind, "bit_exact": True}, g2_s, g2_traffic)
             result["miller"] = leg("Miller loops/s per MI355X (batch 2^%d per GPU), the reference's field element" % args.log2_pairings, "Miller loops/s", npair,
-                                   split["mil_el"], split["milk"], MAC32_MILLER, 96 + 192 + 576, "miller3_kernel",
+                                   split["mil_el"], split["milk"], MAC32_MILLER, 96 + 192 + 576, "miller3_queue_kernel" if (npair + 20) // 21 > 2048 else "miller3_kernel",
                                    "PAIR_ate: the 2^%d (P_i, Q_i) of the pairing leg -> 576-B Miller value each" % args.log2_pairings,
                                    {"checked_lanes": ns, "of": npair, "oracle": kind, "bit_exact": True}, mil_s)
-            result["miller"]["two_full_rounds"] = {"n": split["nfr"], "ms": split["fr_mil_ms"], "value": world * split["nfr"] / (split["fr_mil_ms"] * 1e-3),
-                                                   "roofline_frac": MAC32_MILLER * split["nfr"] / (split["fr_mil_ms"] * 1e-3) / VALU_PEAK_MAC32,
-                                                   "note": "2 x 2048 wavefronts x 21: the plain grid without its round quantisation (2^16 = 1.52 rounds runs as 2)"}
             result["fexp"] = leg("final exponentiations/s per MI355X (batch 2^%d per GPU)" % args.log2_pairings, "final exponentiations/s", npair,
-                                 split["fex_el"], split["fexk"], MAC32_FEXP, 2 * 576, "gt3_op_kernel",
+                                 split["fex_el"], split["fexk"], MAC32_FEXP, 2 * 576, "fexp3_queue_kernel" if (npair + 20) // 21 > 2048 else "gt3_op_kernel",
                                  "PAIR_fexp: the 2^%d Miller values above -> canonical GT" % args.log2_pairings,
                                  {"checked_lanes": npair, "of": npair, "oracle": "%s on %d lanes + every lane equal to the pairing leg's output" % (kind, ns), "bit_exact": True}, fx_s)
 
-            result["fexp"]["two_full_rounds"] = {"n": split["nfr"], "ms": split["fr_fex_ms"], "value": world * split["nfr"] / (split["fr_fex_ms"] * 1e-3),
-                                                 "roofline_frac": MAC32_FEXP * split["nfr"] / (split["fr_fex_ms"] * 1e-3) / VALU_PEAK_MAC32,
-                                                 "note": "as miller.two_full_rounds"}
 
         # ---------------------------------------------------------------- MSM
         if msm is not None:
@@ -646,7 +623,7 @@ def main():
                 result["msm_sharded"] = {"metric": "G1 multi-scalar product terms/s, ONE product of 2^%d terms over %d GPUs" % (args.log2_msm, world),
                                          "value": nm * sh["steps"] / sh["elapsed"], "unit": "terms/s", "scaling": "strong", "steps": sh["steps"],
                                          "ms_per_step": sh["elapsed"] / sh["steps"] * 1e3, "rccl_ranks": sh["rccl_ranks"], "backend": sh["backend"],
-                                         "exchange": "all_gather of 96 B per rank (device tensors) + local %d-term sum on every rank" % world,
+                                         "exchange": "all_gather of 96 B per rank (device tensors) + local sum of the %d partial points on every rank (c12381_g1_sum_dev)" % world,
                                          "same_on_every_rank": True, "equals_single_gpu": sh["equals_single_gpu"]}
 
         # ---------------------------------------------------------------- BBS+

@@ -53,6 +53,8 @@ def load_library() -> ctypes.CDLL:
             getattr(lib, name).argtypes = [vp, sz, vp, vp, vp, ci]
         for name in ("c12381_g2_mul_batch", "c12381_g2_mul_batch_dev", "c12381_g2_add_batch"):
             getattr(lib, name).argtypes = [vp, sz, vp, vp, vp, ci]
+        for name in ("c12381_g1_sum", "c12381_g1_sum_dev"):
+            getattr(lib, name).argtypes = [vp, sz, vp, vp, ci]
         for name in ("c12381_g1_sum_of_products", "c12381_g1_sum_of_products_dev"):
             getattr(lib, name).argtypes = [vp, sz, vp, vp, vp, ci]
         for name in ("c12381_g2_msm", "c12381_g2_msm_dev"):
@@ -182,6 +184,15 @@ class Context:
         out = ctypes.create_string_buffer(max(fmt * n, 1))
         self._ck(self.lib.c12381_g2_mul_batch_flags(self.h, n, _p(pts), _p(scalars), _p(out), fmt, flags), allow_point=not strict)
         return out.raw[:fmt * n]
+
+    def g1_sum(self, pts: bytes, fmt: int = 49) -> bytes:
+        n = len(pts) // 96
+        out = ctypes.create_string_buffer(fmt)
+        self._ck(self.lib.c12381_g1_sum(self.h, n, _p(pts), _p(out), fmt))
+        return out.raw[:fmt]
+
+    def g1_sum_dev(self, n, pts_ptr, out_ptr, fmt=49):
+        self._ck(self.lib.c12381_g1_sum_dev(self.h, n, _p(pts_ptr), _p(out_ptr), fmt))
 
     def g1_msm_flags(self, pts: bytes, scalars: bytes, fmt: int = 49, flags: int = 0, strict: bool = True) -> bytes:
         n = len(scalars) // 32

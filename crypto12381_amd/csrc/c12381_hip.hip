@@ -508,6 +508,41 @@ int c12381_g1_add_batch(c12381_ctx* c, size_t n, const uint8_t* a, const uint8_t
 // MSM: the bucket method (g1_msm_pippenger); a single term (or C12381_MSM=naive) takes n independent GLV scalar
 // multiplications followed by a tree sum of the projective results (the reference's Π is also n full scalar-muls,
 // g1_point.hpp:389-401).  Both equal the reference's chain for every input.  Only the final point is canonical.
+// out = sum of n affine points (no scalars): the header's product over G1Point values (a chain of add(point1&, point1&),
+// src/miracl_core_interface.cpp:129-132 -> ECP_add) and the combine step of a product that was sharded over GPUs:
+// lift + tree sum + one affine conversion — tens of microseconds for the 8 partial points of a node, where the bucket method's
+// fixed stages cost 2.3 ms.
+int c12381_g1_sum_dev(c12381_ctx* c, size_t n, const uint8_t* pts, uint8_t* out, int fmt) {
+    int rc = bind(c); if (rc) return rc;
+    if (!out || (n && !pts) || (fmt != 49 && fmt != 96)) return C12381_E_ARG;
+    if (n == 0) { HIPCK(c, hipMemsetAsync(out, 0, fmt, c->stream)); return 0; }
+    const size_t stride = round_up(n, 64);
+    if ((rc = ensure(c, c12381_ctx::WS_PROJ, (size_t)3 * NL * stride * 4))) return rc;
+    hipLaunchKernelGGL(g1_lift_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, pts, (int32_t*)c->ws[c12381_ctx::WS_PROJ], stride, c->d_flag);
+    HIPCK(c, hipGetLastError());
+    const int32_t* cur = (const int32_t*)c->ws[c12381_ctx::WS_PROJ];
+    size_t cur_n = n, cur_stride = stride;
+    int slot = c12381_ctx::WS_RED0;
+    while (cur_n > 1) {
+        const size_t m = cur_n > 4096 ? round_up(cur_n / 32, 64) : (cur_n > 64 ? 64 : 1);
+        const size_t m_stride = round_up(m, 64);
+        if ((rc = ensure(c, slot, (size_t)3 * NL * m_stride * 4))) return rc;
+        hipLaunchKernelGGL(g1_reduce_kernel, dim3(grid_for(m)), dim3(BLOCK), 0, c->stream, cur_n, cur, cur_stride, m, (int32_t*)c->ws[slot], m_stride);
+        HIPCK(c, hipGetLastError());
+        cur = (const int32_t*)c->ws[slot]; cur_n = m; cur_stride = m_stride;
+        slot = slot == c12381_ctx::WS_RED0 ? c12381_ctx::WS_RED1 : c12381_ctx::WS_RED0;
+    }
+    return g1_finish(c, 1, cur, cur_stride, out, fmt);
+}
+int c12381_g1_sum(c12381_ctx* c, size_t n, const uint8_t* pts, uint8_t* out, int fmt) {
+    int rc = bind(c); if (rc) return rc;
+    if (!out || (n && !pts) || (fmt != 49 && fmt != 96)) return C12381_E_ARG;
+    staged s;
+    if ((rc = stage_in(c, s, pts, 96 * n, nullptr, 0, (size_t)fmt))) return rc;
+    if ((rc = c12381_g1_sum_dev(c, n, s.in0, s.out, fmt))) return rc;
+    if ((rc = stage_out(c, s, out, (size_t)fmt))) return rc;
+    return read_flag(c);
+}
 int c12381_g1_msm_flags_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt, unsigned flags) {
     int rc = bind(c); if (rc) return rc;
     if (!out || (n && (!pts || !sc)) || (fmt != 49 && fmt != 96) || (flags & ~(unsigned)C12381_F_COMPRESSED_IN)) return C12381_E_ARG;
@@ -515,20 +550,15 @@ int c12381_g1_msm_flags_dev(c12381_ctx* c, size_t n, const uint8_t* pts, const u
     if (n == 0) { HIPCK(c, hipMemsetAsync(out, 0, fmt, c->stream)); return 0; }
     if (n > MSM_MAX_TERMS) {
         // the sort works on 32-bit item counts and (term, half) values: larger products are cut into parts whose
-        // partial points (affine, WS_BBS_B as a small staging slot) are summed by a second, tiny product with unit scalars
+        // partial points (affine, WS_BBS_B as a small staging slot) are summed by c12381_g1_sum_dev
         const size_t parts = (n + MSM_MAX_TERMS - 1) / MSM_MAX_TERMS;
-        if ((rc = ensure(c, c12381_ctx::WS_BBS_B, round_up(parts * 128, 256)))) return rc;
+        if ((rc = ensure(c, c12381_ctx::WS_BBS_B, round_up(parts * 96, 256)))) return rc;
         uint8_t* pp = (uint8_t*)c->ws[c12381_ctx::WS_BBS_B];
-        uint8_t* ones = pp + round_up(parts * 96, 32);
-        std::vector<uint8_t> h1(parts * 32, 0);
-        for (size_t p = 0; p < parts; ++p) h1[32 * p + 31] = 1;
-        HIPCK(c, hipMemcpyAsync(ones, h1.data(), h1.size(), hipMemcpyHostToDevice, c->stream));
-        HIPCK(c, hipStreamSynchronize(c->stream));              // h1 goes out of scope below
         for (size_t p = 0; p < parts; ++p) {
             const size_t lo = p * MSM_MAX_TERMS, m = n - lo < MSM_MAX_TERMS ? n - lo : MSM_MAX_TERMS;
             if ((rc = g1_msm_pippenger(c, m, pts + (size_t)in_fmt * lo, sc + 32 * lo, pp + 96 * p, 96, in_fmt))) return rc;
         }
-        return c12381_g1_msm_flags_dev(c, parts, pp, ones, out, fmt, 0u);
+        return c12381_g1_sum_dev(c, parts, pp, out, fmt);
     }
     if (msm_use_buckets(n)) return g1_msm_pippenger(c, n, pts, sc, out, fmt, in_fmt);
     const size_t stride = round_up(n, 64);
@@ -604,17 +634,16 @@ int c12381_g1_msm_multi(c12381_ctx** ctxs, int ngpu, size_t n, const uint8_t* pt
     if (!ctxs || ngpu <= 0 || !out || (n && (!pts || !sc)) || (fmt != 49 && fmt != 96)) return C12381_E_ARG;
     for (int g = 0; g < ngpu; ++g) if (!ctxs[g]) return C12381_E_ARG;
     if (ngpu == 1) return c12381_g1_msm(ctxs[0], n, pts, sc, out, fmt);
-    std::vector<uint8_t> partial((size_t)96 * ngpu, 0), ones((size_t)32 * ngpu, 0);
+    std::vector<uint8_t> partial((size_t)96 * ngpu, 0);
     std::vector<int> rcs(ngpu, 0);
     std::vector<std::thread> th;
     for (int g = 0; g < ngpu; ++g) {
         const size_t lo = n * (size_t)g / (size_t)ngpu, hi = n * (size_t)(g + 1) / (size_t)ngpu;
-        ones[(size_t)32 * g + 31] = 1;
         th.emplace_back([=, &partial, &rcs] { rcs[g] = c12381_g1_msm(ctxs[g], hi - lo, pts + 96 * lo, sc + 32 * lo, &partial[(size_t)96 * g], 96); });
     }
     for (auto& t : th) t.join();
     for (int g = 0; g < ngpu; ++g) if (rcs[g]) return rcs[g];
-    return c12381_g1_msm(ctxs[0], (size_t)ngpu, partial.data(), ones.data(), out, fmt);
+    return c12381_g1_sum(ctxs[0], (size_t)ngpu, partial.data(), out, fmt);
 }
 
 // ---------------------------------------------------------------- G2
@@ -1129,7 +1158,11 @@ static int launch_miller(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8
 #ifdef C12381_EXPERIMENTS
     if (pair_lanes() == 1) { hipLaunchKernelGGL(miller_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, g1, g2, out, c->d_flag); HIPCK(c, hipGetLastError()); return 0; }
 #endif
-    hipLaunchKernelGGL(miller3_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, g1, g2, out, c->d_flag);
+    if (pair_use_queue(n)) {              // more than one machine round of wavefront tasks: quarter-loop tasks from the work queue
+        uint4* st; unsigned int *fl, *ct; unsigned blocks; int rc;
+        if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
+        hipLaunchKernelGGL(miller3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, g1, g2, out, c->d_flag, st, fl, ct, pair_spin_limit());
+    } else hipLaunchKernelGGL(miller3_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, g1, g2, out, c->d_flag);
     HIPCK(c, hipGetLastError());
     return 0;
 }
@@ -1137,7 +1170,11 @@ static int launch_gt_op(c12381_ctx* c, int op, size_t n, const uint8_t* a, const
 #ifdef C12381_EXPERIMENTS
     if (pair_lanes() == 1) { hipLaunchKernelGGL(gt_op_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, op, n, a, b, out); HIPCK(c, hipGetLastError()); return 0; }
 #endif
-    hipLaunchKernelGGL(gt3_op_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, op, n, a, b, out);
+    if (op == 3 && pair_use_queue(n)) {   // final exponentiations alone, more than one machine round: its six steps as queue tasks
+        uint4* st; unsigned int *fl, *ct; unsigned blocks; int rc;
+        if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
+        hipLaunchKernelGGL(fexp3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, a, out, c->d_flag, st, fl, ct, pair_spin_limit());
+    } else hipLaunchKernelGGL(gt3_op_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, op, n, a, b, out);
     HIPCK(c, hipGetLastError());
     return 0;
 }

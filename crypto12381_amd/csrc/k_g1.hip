@@ -202,6 +202,23 @@ __global__ void __launch_bounds__(BLOCK, 2) g1_reduce_kernel(size_t n, const int
     soa_store_g1(outp, out_stride, j, acc);
 }
 
+// affine inputs -> the projective SoA of the reductions (the plain sum of points: product(type_identity<G1Point>, r) g1_point.hpp — a chain
+// of add(point1&, point1&) — and the combine step of a sharded product).  A point that is not on the curve is reported and left out.
+__global__ void __launch_bounds__(BLOCK, 2) g1_lift_kernel(size_t n, const uint8_t* pts, int32_t* proj, size_t stride, int* bad_flag) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    g1p p, inf_pt, o;
+    bool inf, ok;
+    g1_parse96(p.x, p.y, inf, ok, pts + 96 * i);
+    fp_one(p.z);
+    g1_set_inf(inf_pt);
+    const bool drop = inf || !ok;
+    fp_select(p.x, drop, inf_pt.x, p.x); fp_select(p.y, drop, inf_pt.y, p.y); fp_select(p.z, drop, inf_pt.z, p.z);
+    if (!ok) *bad_flag = 1;
+    g1_norm1(o, p);
+    soa_store_g1(proj, stride, i, o);
+}
+
 // [k mod r]P by plain double-and-add on the complete formulas, no endomorphism: the TRUE multiple for every curve point — the term
 // of the boundary's sum_of_products (-> ECP_muln ecp_BLS12381.cpp:1112-1148), which multiply()'s GLV form equals only on G1.
 // Uniform schedule: 255 doublings, every addition executed with the point or infinity selected by the bit.

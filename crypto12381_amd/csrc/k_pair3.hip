@@ -366,6 +366,122 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_queue_kernel(size_t n, cons
     pair3_queue_body<true>(n, a1, a2, b1, b2, b2_stride, out, bad_flag, state, flags, counter, spin_limit, slots[threadIdx.x].v);
 }
 
+// ------------------------------------------------------------------ the split forms through the same queue
+// pair_ate alone (MILLER = true: four quarter-loop tasks per group, output = the Miller value) and the final exponentiation alone
+// (MILLER = false: its six steps, input = 576-byte Fp12 values) for batches of more than one machine round: the plain grids of
+// miller3_kernel / gt3_op_kernel run 2^16 elements (1.52 rounds of equally long wavefront tasks) as two full rounds.  Same hybrid
+// schedule and hand-over protocol as pair3_queue_body; a separate body, so that the pairing kernels' code is untouched.
+template <bool MILLER>
+__device__ __forceinline__ void split3_queue_body(size_t n, const uint8_t* in1, const uint8_t* in2, uint8_t* out, int* bad_flag, uint4* state,
+                                                  unsigned int* flags, unsigned int* counter, int spin_limit, fp4& H) {
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned trip = lane / 3u;
+    tri t;
+    t.role = lane == 63u ? 0 : (int)(lane - 3u * trip);
+    t.base = lane == 63u ? 63 : (int)(3u * trip);
+    const size_t ngroups = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE;
+    constexpr unsigned int TASKS = MILLER ? 4u : 6u;
+    constexpr int ROWS = ST_Y1 + ST_ROWS_F;
+    const size_t nwaves = (size_t)gridDim.x * (BLOCK / 64);
+    const size_t ndirect = queue_direct_groups(ngroups, nwaves);
+    for (;;) {                                                 // whole groups first
+        const unsigned int gc = atomicAdd(counter + 1, lane == 0 ? 1u : 0u);
+        const size_t g = (size_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)gc);
+        if (g >= ndirect) break;
+        const size_t e = g * TRI_PER_WAVE + (lane == 63u ? TRI_PER_WAVE - 1 : trip);
+        const bool active = lane < 63u && e < n;
+        const size_t i = e < n ? e : n - 1;
+        if (MILLER) {
+            fp px, py; fp2 qx, qy; bool pinf, qinf, ok;
+            pair_inputs(px, py, pinf, qx, qy, qinf, ok, in1 + 96 * i, in2 + 192 * i);
+            if (!ok) { pinf = true; qinf = true; }
+            miller3_loop(H, px, py, pinf, qx, qy, qinf, t);
+            if (active) {
+                if (!ok) { *bad_flag = 1; gt_poison(out + 576 * i, t.role); }
+                else { fp4 F; slot_load(F, H); gt_store_coeff(out + 576 * i, F, t.role); }
+            }
+        } else {
+            fp4 r;
+            gt_load_coeff(r, in1 + 576 * i, t.role);
+            f12t_final_exp_ws(r, H, t);
+            if (active) gt_store_coeff(out + 576 * i, r, t.role);
+        }
+    }
+    const size_t nq = ngroups - ndirect;
+    const size_t ntasks = nq * TASKS;
+    for (;;) {
+        const unsigned int claimed = atomicAdd(counter, lane == 0 ? 1u : 0u);
+        const unsigned int task = (unsigned int)__builtin_amdgcn_readfirstlane((int)claimed);
+        if ((size_t)task >= ntasks) break;
+        const unsigned int p = (unsigned int)(task / nq);
+        const size_t g = ndirect + task % nq;
+        const size_t e = g * TRI_PER_WAVE + (lane == 63u ? TRI_PER_WAVE - 1 : trip);
+        const bool active = lane < 63u && e < n;
+        const size_t i = e < n ? e : n - 1;
+        const bool poisoned = queue_wait(flags, g, p, spin_limit);
+        uint4* st = state + (g - ndirect) * (size_t)ROWS * 64;
+        if (poisoned) {
+            if (p == TASKS - 1 && active) { bad_flag[1] = 1; gt_poison(out + 576 * e, t.role); }
+        } else if (MILLER) {
+            fp px, py; fp2 qx, qy; bool pinf, qinf, ok;
+            pair_inputs(px, py, pinf, qx, qy, qinf, ok, in1 + 96 * i, in2 + 192 * i);
+            if (!ok) { pinf = true; qinf = true; }
+            g2p Q;
+            fp2 tc;
+            miller3_q(Q, qx, qy, qinf);
+            if (p == 0) {
+                miller3_tc(tc, Q, t);
+                fp4 one;
+                f12t_one(one, t);
+                slot_store(H, one);
+            } else {
+                fp4 f;
+                st_load<fp4, ST_ROWS_F>(f, st + ST_F * 64, lane);
+                slot_store(H, f);
+                st_load<fp2, ST_ROWS_TC>(tc, st + ST_TC1 * 64, lane);
+            }
+            const int hi = 64 - 16 * (int)p, lo = hi - 15;
+            miller3_range(H, tc, px, py, pinf, Q, hi, lo, t);
+            if (p == TASKS - 1) {
+                f12t_conj_h(H, t);
+                if (active) {
+                    if (!ok) { *bad_flag = 1; gt_poison(out + 576 * e, t.role); }
+                    else { fp4 F; slot_load(F, H); gt_store_coeff(out + 576 * e, F, t.role); }
+                }
+            } else {
+                fp4 f;
+                slot_load(f, H);
+                st_store<fp4, ST_ROWS_F>(st + ST_F * 64, lane, f);
+                st_store<fp2, ST_ROWS_TC>(st + ST_TC1 * 64, lane, tc);
+            }
+        } else {
+            const int step = (int)p;
+            fp4 r, y1, aux;
+            if (step == 0) gt_load_coeff(r, in1 + 576 * i, t.role);
+            else st_load<fp4, ST_ROWS_F>(r, st + ST_F * 64, lane);
+            if (step >= 1) st_load<fp4, ST_ROWS_F>(y1, st + ST_Y1 * 64, lane);
+            if (step == 5) st_load<fp4, ST_ROWS_F>(aux, st + ST_TC1 * 64, lane);
+            f12t_final_exp_step(step, r, y1, aux, H, t);
+            if (step < 5) {
+                st_store<fp4, ST_ROWS_F>(st + ST_F * 64, lane, r);
+                if (step == 0) st_store<fp4, ST_ROWS_F>(st + ST_Y1 * 64, lane, y1);
+                if (step == 4) st_store<fp4, ST_ROWS_F>(st + ST_TC1 * 64, lane, aux);
+            } else if (active) gt_store_coeff(out + 576 * e, r, t.role);
+        }
+        queue_publish(flags, g, p, poisoned, lane);
+    }
+}
+__global__ void __launch_bounds__(BLOCK, 2) miller3_queue_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* out, int* bad_flag, uint4* state,
+                                                              unsigned int* flags, unsigned int* counter, int spin_limit) {
+    __shared__ fp4_slot slots[BLOCK];
+    split3_queue_body<true>(n, g1, g2, out, bad_flag, state, flags, counter, spin_limit, slots[threadIdx.x].v);
+}
+__global__ void __launch_bounds__(BLOCK, 2) fexp3_queue_kernel(size_t n, const uint8_t* in576, uint8_t* out, int* bad_flag, uint4* state,
+                                                            unsigned int* flags, unsigned int* counter, int spin_limit) {
+    __shared__ fp4_slot slots[BLOCK];
+    split3_queue_body<false>(n, in576, nullptr, out, bad_flag, state, flags, counter, spin_limit, slots[threadIdx.x].v);
+}
+
 // ------------------------------------------------------------------ both G2 arguments fixed for the batch
 // Coefficient table of one G2 point (pairing3.hpp, 69 lines) with the header of the fixed-base tables (k_fixed.hip):
 // header[HDR_VALID] = valid (on the twist, not infinity, in G2), header[HDR_REBUILD] = rebuild requested by fixed_cache_check_kernel.

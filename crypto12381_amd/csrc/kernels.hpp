@@ -45,6 +45,7 @@ __global__ void __launch_bounds__(BLOCK, 2) g1_small_scalar_kernel(size_t n, con
 __global__ void __launch_bounds__(BLOCK, 2) g1_rsub_kernel(size_t n, int32_t* acc, size_t acc_stride, const int32_t* other, size_t other_stride, size_t other_off, const int32_t* run_if);
 __global__ void __launch_bounds__(BLOCK, 2) g1_add_kernel(size_t n, const uint8_t* a, const uint8_t* b, int32_t* proj, size_t proj_stride, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) g1_finish_kernel(size_t n, const int32_t* proj, size_t stride, int32_t* pref, uint8_t* out, int fmt, size_t T);
+__global__ void __launch_bounds__(BLOCK, 2) g1_lift_kernel(size_t n, const uint8_t* pts, int32_t* proj, size_t stride, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) g1_reduce_kernel(size_t n, const int32_t* in, size_t in_stride, size_t m, int32_t* outp, size_t out_stride);
 __global__ void __launch_bounds__(BLOCK, 2) g1_mul_plain_kernel(size_t n, const uint8_t* pts, const uint8_t* scalars, int32_t* proj, size_t proj_stride, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) g1_add_const_kernel(size_t n, int32_t* proj, size_t stride, const uint8_t* pt96, int* bad_flag);
@@ -79,6 +80,8 @@ __global__ void __launch_bounds__(BLOCK, 2) gt_is_unity_kernel(size_t n, const u
 __global__ void __launch_bounds__(BLOCK, 2) pair3_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) pair3_prod_kernel(size_t n, int k, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag, int miller_only);
 __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, size_t b2_stride, uint8_t* out, int* bad_flag, const int32_t* skip_if);
+__global__ void __launch_bounds__(BLOCK, 2) miller3_queue_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit);
+__global__ void __launch_bounds__(BLOCK, 2) fexp3_queue_kernel(size_t n, const uint8_t* in576, uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit);
 __global__ void __launch_bounds__(BLOCK, 2) pair3_queue_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit, unsigned long long* stamps);
 __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_queue_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, size_t b2_stride, uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, const int32_t* skip_if, int spin_limit);
 __global__ void __launch_bounds__(BLOCK, 2) g2_lines_table_kernel(const uint8_t* q192, int32_t* buf, int need_g2);

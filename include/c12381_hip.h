@@ -114,6 +114,12 @@ int c12381_g1_msm_dev(c12381_ctx* ctx, size_t n, const uint8_t* pts96, const uin
 /* the same with C12381_F_COMPRESSED_IN (pts = n x 49 bytes): parse<G1> + Π in one call */
 int c12381_g1_msm_flags(c12381_ctx* ctx, size_t n, const uint8_t* pts, const uint8_t* scalars32, uint8_t* out, int out_fmt, unsigned flags);
 int c12381_g1_msm_flags_dev(c12381_ctx* ctx, size_t n, const uint8_t* pts, const uint8_t* scalars32, uint8_t* out, int out_fmt, unsigned flags);
+/* out = sum_i pts[i] (no scalars): the header layer's product over G1Point values — a chain of add(point1&, point1&)
+ * (miracl_core_interface.hpp:101, src/miracl_core_interface.cpp:129-132 -> ECP_add) — and the combine step of a product sharded
+ * over GPUs (N partial points of 96 B).  n = 0 gives infinity; a point that is not on the curve is left out and
+ * reported (C12381_E_POINT). */
+int c12381_g1_sum(c12381_ctx* ctx, size_t n, const uint8_t* pts96, uint8_t* out, int out_fmt);
+int c12381_g1_sum_dev(c12381_ctx* ctx, size_t n, const uint8_t* pts96, uint8_t* out, int out_fmt);
 /* The boundary function sum_of_products(point1&, int, point1*, const big*) with the reference's value for EVERY input
  * (src/miracl_core_interface.cpp:134-137 -> ECP_muln ecp_BLS12381.cpp:1112-1148, a plain Pippenger): the sum of the true multiples
  * [k_i mod r]P_i.  For points of G1 this equals c12381_g1_msm, which is the fast path; off the subgroup the two differ because the

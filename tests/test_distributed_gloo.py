@@ -37,7 +37,13 @@ def _worker(rank, world, port, pts, sc, expect, q):
         tp = torch.frombuffer(bytearray(shard_bytes(pts, 96, rank, world)), dtype=torch.uint8)
         ts = torch.frombuffer(bytearray(shard_bytes(sc, 32, rank, world)), dtype=torch.uint8)
         res_t = msm_sharded_tensors(local_t, tp, ts, 49).numpy().tobytes()
-        q.put((rank, res == expect and res_t == expect))
+        # with an injected combine (on the GPU box c12381_g1_sum_dev; here the oracle's unit-scalar product plays the sum)
+        one = (1).to_bytes(32, "big")
+        res_c = msm_sharded(lambda p, s, fmt: orc.g1_msm(p, s, fmt, 1), shard_bytes(pts, 96, rank, world), shard_bytes(sc, 32, rank, world), 49,
+                            combine=lambda p, fmt: orc.g1_msm(p, one * (len(p) // 96), fmt, 1))
+        res_ct = msm_sharded_tensors(local_t, tp, ts, 49, combine_t=lambda p, fmt: local_t(
+            p, torch.frombuffer(bytearray(one * (p.numel() // 96)), dtype=torch.uint8), fmt)).numpy().tobytes()
+        q.put((rank, res == expect and res_t == expect and res_c == expect and res_ct == expect))
     finally:
         dist.destroy_process_group()
 

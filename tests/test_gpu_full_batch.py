@@ -71,6 +71,15 @@ def test_every_lane_of_2_16_pairings_vs_oracle(ctx, orc):
     # is covered at small sizes; here the second launch only has to reproduce the first bit for bit (same queue, new schedule)
     gt2 = np.frombuffer(ctx.pair(P, Q), dtype=np.uint8).reshape(n, 576)
     assert (gt2 == gt).all()
+    # the split forms at the same size (miller3_queue_kernel / fexp3_queue_kernel: quarter-loop and exponentiation-step tasks from the
+    # work queue): every Miller value is the reference's field element (pair_ate), every final exponentiation of it the pairing above
+    mil = ctx.miller(P, Q)
+    expm = np.frombuffer(orc.miller_t(P, Q, THREADS), dtype=np.uint8).reshape(n, 576)
+    badm = np.nonzero((np.frombuffer(mil, dtype=np.uint8).reshape(n, 576) != expm).any(axis=1))[0]
+    assert len(badm) == 0, _describe(badm, 21)
+    fx = np.frombuffer(ctx.fexp(mil), dtype=np.uint8).reshape(n, 576)
+    badf = np.nonzero((fx != gt).any(axis=1))[0]
+    assert len(badf) == 0, _describe(badf, 21)
 
 
 def test_every_lane_of_2_20_g1_multiplications_vs_oracle(ctx, orc):

@@ -279,3 +279,25 @@ def test_g2_product(ctx, oracle_port):
     assert ctx.g2_msm(Q, K, 192) == acc
     assert ctx.g2_msm(b"", None, 97) == bytes(97)
     assert ctx.g2_msm(Q[:192], K[:32], 192) == T[:192]
+
+
+def test_g1_sum_of_points(ctx, oracle_port):
+    """c12381_g1_sum: the plain sum of affine points (a chain of add(point1&, point1&); the combine step of a sharded product) against
+    the oracle's product with unit scalars — ragged sizes around the reduction levels, infinity terms, P + (-P), the empty sum, and a
+    point that is not on the curve (left out, reported)."""
+    from crypto12381_amd.capi import C12381Error, E_POINT
+    g = golden("g1")
+    gen = bytes.fromhex(g["generator"])
+    m = 4200
+    P = ctx.g1_mul(gen * m, scalars(1301, m), 96)
+    one = (1).to_bytes(32, "big")
+    for n in (1, 2, 3, 8, 63, 64, 65, 4095, 4096, 4097, m):
+        assert ctx.g1_sum(P[:96 * n], 96) == oracle_port.g1_msm(P[:96 * n], one * n, 96, 8), n
+    assert ctx.g1_sum(b"", 96) == bytes(96) and ctx.g1_sum(b"", 49) == bytes(49)
+    neg = oracle_port.g1_mul(P[:96], (R - 1).to_bytes(32, "big"), 96)
+    assert ctx.g1_sum(P[:96] + neg, 96) == bytes(96)                                    # P + (-P)
+    assert ctx.g1_sum(P[:96] + bytes(96) + P[96:192] + bytes(96), 49) == oracle_port.g1_msm(P[:192], one * 2, 49)
+    bad = bytearray(P[:96 * 5]); bad[96 * 2 + 95] ^= 1
+    with pytest.raises(C12381Error) as e:
+        ctx.g1_sum(bytes(bad), 96)
+    assert e.value.code == E_POINT
