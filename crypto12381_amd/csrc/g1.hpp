@@ -189,7 +189,7 @@ C12381_HD void soa_load_g1(g1p& p, const int32_t* base, size_t stride, size_t id
 // eleven 16-byte accesses).  A lane's whole table is one contiguous 2816-byte record, so a gather of one
 // entry touches 176 consecutive bytes of HBM instead of 42 scattered dwords (the limb-major layout of the
 // first version moved ~16x the algorithmic bytes: profiles/r01_pmc_summary_before_table_fix.txt).
-// Per scalar multiplication: 1 + 125 doublings and 14 + 52 additions (4-bit windows: 1 + 128 and 6 + 66).
+// Per scalar multiplication: 8 + 125 doublings and 7 + 52 additions (4-bit windows: 4 + 128 and 3 + 66).
 #ifndef C12381_G1_WIN
 #define C12381_G1_WIN 5                                 // 4 or 5; A/B on MI355X: 5 is 3.5 % faster
 #endif
@@ -252,8 +252,8 @@ C12381_HD void glv_bias(uint32_t (&kb)[5], const uint32_t (&k)[4]) {
         kb[4] = (uint32_t)c + B[4];
     }
 }
-// acc += sign(d) * T[|d|]  (d == 0 adds the point at infinity: same instruction stream)
-C12381_HD void g1_add_digit(g1p& acc, const int32_t* lane_tab, int d, bool endo) {
+// q = sign(d) * T[|d|], or its image under the endomorphism; d == 0 gives the point at infinity (same instruction stream)
+C12381_HD void g1_digit_point(g1p& r, const int32_t* lane_tab, int d, bool endo) {
     const int mag = d < 0 ? -d : d;
     const int idx = mag == 0 ? 1 : mag;
     g1p q;
@@ -265,13 +265,13 @@ C12381_HD void g1_add_digit(g1p& acc, const int32_t* lane_tab, int d, bool endo)
     const bool isz = mag == 0;
     fp_select(q.x, isz, zero, q.x); fp_select(q.y, isz, one, q.y); fp_select(q.z, isz, zero, q.z);
     C12381_BOUNDS(q.x.lb = q.y.lb = q.z.lb = 268435456.0 + 8.0;)
-    if (endo) {                                     // compile-time constant at both call sites
-        g1p e;
-        g1_endo_x2(e, q);
-        g1_add(acc, e);
-    } else {
-        g1_add(acc, q);
-    }
+    if (endo) g1_endo_x2(r, q); else r = q;          // compile-time constant at every call site
+}
+// acc += sign(d) * T[|d|]
+C12381_HD void g1_add_digit(g1p& acc, const int32_t* lane_tab, int d, bool endo) {
+    g1p e;
+    g1_digit_point(e, lane_tab, d, endo);
+    g1_add(acc, e);
 }
 
 // p <- [|x|]p, plain double-and-add over the 64-bit curve parameter (weight 6)
@@ -349,22 +349,35 @@ C12381_HD void g1_scalar_mul(g1p& acc, const fp& px, const fp& py, bool p_is_inf
         tab_store_g1(lane_tab + G1_ENT_DWORDS, n);              // T[2]
         t = n;
     }
+    // even multiples by doubling the entry half as large (8 products + 7 reductions against 12 + 9 for an addition; the entry comes
+    // back from the lane's own record), odd ones by adding P to the previous entry: 8 doublings + 7 additions for 16 entries
 #pragma unroll 1
     for (int j = 3; j <= G1_TAB; ++j) {
-        g1_add(t, base);
+        if ((j & 1) == 0) {                                     // wave-uniform
+            tab_load_g1(t, lane_tab + (j / 2 - 1) * G1_ENT_DWORDS);
+            g1_dbl(t);
+        } else {
+            g1_add(t, base);
+        }
         g1p n;
         g1_norm1(n, t);
         tab_store_g1(lane_tab + (j - 1) * G1_ENT_DWORDS, n);
         t = n;
     }
 
-    g1_set_inf(acc);
+    // the top window starts the accumulator with its first digit's entry (an addition to the point at infinity would compute the same
+    // point): 51 + 7 additions in all
+    g1_digit_point(acc, lane_tab, glv_digit(kb0, G1_WINDOWS - 1), false);
+    {
+        g1p n;
+        g1_norm1(n, acc);
+        acc = n;
+    }
+    g1_add_digit(acc, lane_tab, glv_digit(kb1, G1_WINDOWS - 1), true);
 #pragma unroll 1
-    for (int w = G1_WINDOWS - 1; w >= 0; --w) {
-        if (w != G1_WINDOWS - 1) {                                              // wave-uniform
-            g1_dbl(acc); g1_dbl(acc); g1_dbl(acc); g1_dbl(acc);
-            if (G1_WIN == 5) g1_dbl(acc);
-        }
+    for (int w = G1_WINDOWS - 2; w >= 0; --w) {
+        g1_dbl(acc); g1_dbl(acc); g1_dbl(acc); g1_dbl(acc);
+        if (G1_WIN == 5) g1_dbl(acc);
         g1_add_digit(acc, lane_tab, glv_digit(kb0, w), false);
         g1_add_digit(acc, lane_tab, glv_digit(kb1, w), true);
     }

@@ -226,18 +226,24 @@ C12381_HD void gs_bias(uint32_t (&ub)[3], const uint32_t (&u)[2]) {
     uint64_t c = (uint64_t)u[0] + b0; ub[0] = (uint32_t)c; c >>= 32;
     c += (uint64_t)u[1] + b1; ub[1] = (uint32_t)c; ub[2] = (uint32_t)(c >> 32) + (G2_WIN == 4 ? 0u : gs_bias_word5(2));
 }
-// acc += (-1)^I sign(d) psi^I(T[|d|])
+// e = (-1)^I sign(d) psi^I(T[|d|]); d == 0 gives the point at infinity
 template <int I, class F>
-C12381_HD void g2_add_digit(g2pt<F>& acc, const int32_t* lane_tab, int d) {
-    constexpr bool INL = g2_inline_loop<F>::value;
+C12381_HD void g2_digit_point(g2pt<F>& e, const int32_t* lane_tab, int d) {
     const int mag = d < 0 ? -d : d;
     const int idx = mag == 0 ? 1 : mag;
-    g2pt<F> q, e, inf;
+    g2pt<F> q, inf;
     tab_load_g2(q, lane_tab + (idx - 1) * g2_ent_dwords(q));
     g2_psi_signed<I>(e, q, (d < 0) != ((I & 1) != 0));
     g2_set_inf(inf);
     const bool isz = mag == 0;
     fp2_select(e.x, isz, inf.x, e.x); fp2_select(e.y, isz, inf.y, e.y); fp2_select(e.z, isz, inf.z, e.z);
+}
+// acc += (-1)^I sign(d) psi^I(T[|d|])
+template <int I, class F>
+C12381_HD void g2_add_digit(g2pt<F>& acc, const int32_t* lane_tab, int d) {
+    constexpr bool INL = g2_inline_loop<F>::value;
+    g2pt<F> e;
+    g2_digit_point<I>(e, lane_tab, d);
     if (INL) g2_add_core(acc, e); else g2_add(acc, e);
 }
 
@@ -291,7 +297,7 @@ template <class F> C12381_HDN void g2_gs_zero_digit_terms(g2pt<F>& acc, const g2
 // PAIR_G2mul pair_BLS12381.cpp:927-983: R = u0 Q - u1 psi(Q) + u2 psi^2(Q) - u3 psi^3(Q) for the base-|x| digits of
 // k mod r — exactly what the reference evaluates (ECP2_mul4 after gs() and the sign minimisation), on ANY point of
 // the twist; for Q in G2 it equals [k]Q.  Signed 5-bit windows: 60 doublings + 52 additions on one 16-entry table of multiples of Q
-// (1 doubling + 14 additions to build; 4-bit windows: 64 + 68 on 8 entries, 1 + 6).
+// (8 doublings + 7 additions to build; 4-bit windows: 64 + 68 on 8 entries, 4 + 3).
 // in_g2: the caller asserts Q lies in G2 (C12381_F_IN_SUBGROUP) — the [r]psi^i(Q) terms are then the point at infinity and
 // their evaluation (a membership test of 64 doublings per affected lane) is skipped.
 template <class F> C12381_HDN void g2_scalar_mul(g2pt<F>& acc, const F& qx, const F& qy, bool q_is_inf, const uint32_t (&kin)[8], int32_t* lane_tab, bool in_g2 = false) {
@@ -318,9 +324,15 @@ template <class F> C12381_HDN void g2_scalar_mul(g2pt<F>& acc, const F& qx, cons
         tab_store_g2(lane_tab + g2_ent_dwords(n), n);
         t = n;
     }
+    // even multiples by doubling the entry half as large, odd ones by adding Q to the previous entry (as g1_scalar_mul)
 #pragma unroll 1
     for (int j = 3; j <= G2_TAB; ++j) {
-        g2_add(t, base);
+        if ((j & 1) == 0) {                                     // wave-uniform
+            tab_load_g2(t, lane_tab + (j / 2 - 1) * g2_ent_dwords(t));
+            g2_dbl(t);
+        } else {
+            g2_add(t, base);
+        }
         g2pt<F> n;
         g2_norm1(n, t);
         tab_store_g2(lane_tab + (j - 1) * g2_ent_dwords(n), n);
@@ -338,8 +350,10 @@ template <class F> C12381_HDN void g2_scalar_mul(g2pt<F>& acc, const F& qx, cons
 #pragma unroll 1
                 for (int i = 0; i < G2_WIN; ++i) { F a, b, c; g2_dbl_core(run, a, b, c); }
             } else g2_dbl_n(run, G2_WIN);
+            g2_add_digit<0>(run, lane_tab, gs_digit(ub[0], w));
+        } else {
+            g2_digit_point<0>(run, lane_tab, gs_digit(ub[0], w));       // the top window starts the accumulator: infinity + entry = entry
         }
-        g2_add_digit<0>(run, lane_tab, gs_digit(ub[0], w));
         g2_add_digit<1>(run, lane_tab, gs_digit(ub[1], w));
         g2_add_digit<2>(run, lane_tab, gs_digit(ub[2], w));
         g2_add_digit<3>(run, lane_tab, gs_digit(ub[3], w));
