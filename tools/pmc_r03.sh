@@ -44,7 +44,7 @@ for name, v in res.items():
         d["wait_any_frac"] = d.get("SQ_WAIT_ANY", 0) / d["SQ_WAVE_CYCLES"]
     summ[name] = d
 json.dump(summ, open("%s/summary.json" % out, "w"), indent=1)
-for name in ("g1_mul_kernel", "g2_mul2_kernel", "pair3_queue_kernel", "miller3_kernel", "gt3_op_kernel", "msm_bucket_kernel", "pair3_prod_fixed_queue_kernel"):
+for name in ("g1_mul_kernel", "g2_mul2_kernel", "pair3_queue_kernel", "miller3_queue_kernel", "fexp3_queue_kernel", "msm_bucket_kernel", "pair3_prod_fixed_queue_kernel"):
     if name in summ:
         d = summ[name]
         print("%-32s %8.3f ms  clock %.3f GHz  HBM-side %.3f GB  VALU %.4g  wait %.3f" % (

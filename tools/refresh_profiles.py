@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Copy the outputs of tools/final_pass.sh (gpurun_out/final/) into profiles/ under the round's names and refresh
-profiles/traffic.json from the counter passes.  usage: python3 tools/refresh_profiles.py [round-prefix, default r02]"""
+profiles/traffic.json from the counter passes.  usage: python3 tools/refresh_profiles.py [round-prefix, default r03]"""
 import csv
 import json
 import os
@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(ROOT)
-R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 F = "gpurun_out/final"
 
 
@@ -32,23 +32,31 @@ with open("profiles/%s_kernel_stats_bench.csv" % R, "w") as f:
     for r in rows:
         f.write("%s,%s,%s,%s,%s,%s\n" % (short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"]))
 for src, dst in (("bench_under_rocprof.json", "bench_under_rocprof.json"), ("bench.json", "bench_final.json"), ("pmc/summary.json", "pmc_summary.json"),
-                 ("soak.log", "soak.log"), ("pytest_gpu.log", "pytest_gpu_final.log"), ("bench_2rank_gloo.json", "bench_2rank_gloo.json")):
+                 ("soak.log", "soak.log"), ("pytest_gpu.log", "pytest_gpu_final.log"), ("bench_2rank_gloo.json", "bench_2rank_gloo.json"),
+                 ("clock_probe.txt", "clock_probe.txt"), ("pmc.txt", "pmc_passes.txt")):
     if os.path.exists(F + "/" + src):
         shutil.copy(F + "/" + src, "profiles/%s_%s" % (R, dst))
 s = json.load(open(F + "/pmc/summary.json"))
 t = json.load(open("profiles/traffic.json"))
-g, p = s["g1_mul_kernel"], s["pair3_queue_kernel"]
+g = s["g1_mul_kernel"]
 t["FETCH_SIZE_KB"], t["WRITE_SIZE_KB"] = g["FETCH_SIZE"], g["WRITE_SIZE"]
 t["g1_mul_kernel_hbm_bytes_per_launch"] = g["FETCH_SIZE"] * 2048 + g["WRITE_SIZE"] * 1024
-t["pair_kernel"]["FETCH_SIZE_KB"], t["pair_kernel"]["WRITE_SIZE_KB"] = p["FETCH_SIZE"], p["WRITE_SIZE"]
-t["pair_kernel"]["hbm_bytes_per_launch"] = p["FETCH_SIZE"] * 2048 + p["WRITE_SIZE"] * 1024
+for key, kern in (("pair_kernel", "pair3_queue_kernel"), ("pair3_prod_fixed_queue_kernel", "pair3_prod_fixed_queue_kernel"),
+                  ("msm_bucket_kernel", "msm_bucket_kernel"), ("g2_mul2_kernel", "g2_mul2_kernel")):
+    if kern in s and "FETCH_SIZE" in s[kern]:
+        t[key]["FETCH_SIZE_KB"], t[key]["WRITE_SIZE_KB"] = s[kern]["FETCH_SIZE"], s[kern]["WRITE_SIZE"]
+        t[key]["hbm_bytes_per_launch"] = s[kern]["FETCH_SIZE"] * 2048 + s[kern]["WRITE_SIZE"] * 1024
 json.dump(t, open("profiles/traffic.json", "w"), indent=1)
-print("g1 %.2f GB  pairing %.2f GB per launch" % (t["g1_mul_kernel_hbm_bytes_per_launch"] / 1e9, t["pair_kernel"]["hbm_bytes_per_launch"] / 1e9))
-print("pairing: SQ_WAIT_ANY/SQ_WAVE_CYCLES %.3f  SQ_INSTS_VALU/SQ_WAVE_CYCLES %.3f  VALU %.3e" % (p["SQ_WAIT_ANY"] / p["SQ_WAVE_CYCLES"], p["SQ_INSTS_VALU"] / p["SQ_WAVE_CYCLES"], p["SQ_INSTS_VALU"]))
-print("g1: VALU per launch %.3e" % g["SQ_INSTS_VALU"])
-for r in rows[:6]:
+for k in ("g1_mul_kernel", "g2_mul2_kernel", "pair3_queue_kernel", "pair3_prod_fixed_queue_kernel", "msm_bucket_kernel", "miller3_queue_kernel", "fexp3_queue_kernel"):
+    if k in s:
+        v = s[k]
+        print("%-32s HBM-side %.2f GB  VALU %.3e  wait %.3f" % (k, v.get("hbm_bytes_per_launch", 0) / 1e9, v.get("SQ_INSTS_VALU", 0), v.get("wait_any_frac", 0)))
+for r in rows[:8]:
     print("%-50s %5s calls  avg %.3f ms" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e6))
 d = json.load(open(F + "/bench.json"))
-print("bench: g1 %.3e /s %.2f ms (frac %.3f) | pairing %.3e /s %.2f ms (frac %.3f) | msm %.2f ms | bbs %.2f ms" % (
-    d["value"], d["ms_per_step"], d["valu_roofline"]["frac"], d["pairing"]["value"], d["pairing"]["ms_per_step"], d["pairing"]["valu_roofline"]["frac"],
-    d["msm"]["ms_per_step"], d["bbs_plus"]["ms_per_step"]))
+print("bench: g1 %.3e /s %.2f ms (frac %.3f / %.3f) | pairing %.3e /s %.2f ms (%.3f / %.3f)" % (
+    d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["frac_vs_round2_peak"], d["pairing"]["value"], d["pairing"]["ms_per_step"],
+    d["pairing"]["roofline"]["frac"], d["pairing"]["roofline"]["frac_vs_round2_peak"]))
+for k in ("g2_mul", "miller", "fexp", "msm", "bbs_plus"):
+    print("   %-9s %.3e /s  %.2f ms  frac %.3f / %.3f  kernel %.2f ms" % (k, d[k]["value"], d[k]["ms_per_step"], d[k]["roofline"]["frac"], d[k]["roofline"]["frac_vs_round2_peak"],
+                                                                          d[k]["roofline"]["avg_launch_ms"]))

@@ -37,6 +37,14 @@ for n in (43009, 50000, 65536, 65541, 100003, 131072, 262144):
         assert c.sync() == 0
         assert torch.equal(out, ref) and torch.equal(ok0, ok1), (n, it)
         launches += 2
+    # the split forms through the same queue (miller3_queue_kernel / fexp3_queue_kernel): fexp(miller(P, Q)) == pair(P, Q), repeatedly
+    mil = torch.empty(576 * n, dtype=torch.uint8, device=dev)
+    for it in range(4):
+        c.miller_dev(n, dp.data_ptr(), dq.data_ptr(), mil.data_ptr())
+        c.gt_op_dev("fexp", n, mil.data_ptr(), None, out.data_ptr())
+        assert c.sync() == 0
+        assert torch.equal(out, ref), ("split", n, it)
+        launches += 2
     # first row against the small plain-kernel launch
     small = torch.empty(576 * 21, dtype=torch.uint8, device=dev)
     c.pair_dev(21, dp.data_ptr(), dq.data_ptr(), small.data_ptr()); c.sync()
