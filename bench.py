@@ -450,6 +450,12 @@ def main():
                 traffic = tj["g1_mul_kernel_hbm_bytes_per_launch"] * units_per_launch / tj["units_per_launch"]
                 if pair is not None:
                     pair_traffic = tj["pair_kernel"]["hbm_bytes_per_launch"] * pair["npair"] / tj["pair_kernel"]["units_per_launch"]
+                if split is not None and "g2_mul2_kernel" in tj:
+                    g2_traffic = tj["g2_mul2_kernel"]["hbm_bytes_per_launch"]          # per launch of 2^17 points
+                if msm is not None and "msm_bucket_kernel" in tj:
+                    msm_traffic = tj["msm_bucket_kernel"]["hbm_bytes_per_launch"] * msm["n"] / tj["msm_bucket_kernel"]["units_per_launch"]
+                if bbs is not None and "pair3_prod_fixed_queue_kernel" in tj:
+                    bbs_traffic = tj["pair3_prod_fixed_queue_kernel"]["hbm_bytes_per_launch"] * bbs["n"] / tj["pair3_prod_fixed_queue_kernel"]["units_per_launch"]
             except Exception:
                 traffic = pair_traffic = msm_traffic = bbs_traffic = g2_traffic = None
 
