@@ -73,14 +73,21 @@ BYTES_PAIRING = 864              # 96 + 192 in, 576 out
 BYTES_MSM_TERM = 128             # 96 + 32
 BYTES_BBS_VERIFY = 96 + 32 + 32 + 32 + 1
 HBM_PEAK_GBS = 8000.0
-# Measured multiply-add issue rates, profiles/r03_valu_rates.txt (csrc/microbench/valu_rates.hip, 16-ms runs, in-kernel clock recorded):
-#   v_mad_i64_i32 — the instruction every limb product compiles to — with 8 wavefronts per SIMD: 3.30e13 lane-ops/s at 2.32 GHz;
-#   with 2 wavefronts per SIMD — the occupancy of every 256-register kernel here — 2.84e13 at 2.40 GHz: a wavefront issues a 64-bit
-#   multiply-add every ~11 cycles, so two of them cannot saturate the pipe (dependent and independent chains alike).
-# Rounds 1-2 used 3.10e13 (v_mad_u64_u32 with vcc carry-out, a 1-ms run); `frac` below is against the higher, sustained figure.
-VALU_PEAK_MAC32 = 3.30e13
-VALU_PEAK_MAC32_2WAVES = 2.84e13
+# The multiply-add rate, measured inside the kernel (csrc/microbench/issue_mix.hip, profiles/r03_issue_mix.txt: shader cycles per wavefront
+# from s_memtime, 128 instructions per loop iteration): a SIMD issues one v_mad_i64_i32 — the instruction every limb product compiles
+# to — per 4.125 cycles, at ONE wavefront per SIMD (4.25) as well as at two (the occupancy of every 256-register kernel here):
+# 62.06 lanes per clock and CU of the documented 64.  `peak` prices that issue rate at the 2.4 GHz maximum clock: 3.81e13 MAC32/s.
+# Earlier figures, kept for comparison only: rounds 1-2 used 3.10e13 (v_mad_u64_u32, a 1-ms run timed with events); the first half of
+# round 3 3.30e13 (csrc/microbench/valu_rates.hip, 16 multiply-adds per loop iteration timed with events: the loop's own scalar
+# instructions and the uneven arrival of the workgroups are in that number — profiles/r03_valu_rates.txt).
+VALU_PEAK_MAC32 = 256 * 4 * (64 / 4.125) * 2.4e9
 VALU_PEAK_MAC32_R02 = 3.10e13
+# What bounds these kernels is the ISSUE of vector instructions, whatever they are (profiles/r03_issue_mix.txt): a SIMD takes its next
+# vector instruction from its OLDEST wavefront every 4.06 cycles — multiply-add, mask, shift, select alike — and a second wavefront
+# only fills the stalls of the first (mixed streams of two wavefronts take exactly the sum of their single-wavefront times).
+# roofline.issue = VALU instructions per launch (SQ_INSTS_VALU, profiles/issue.json) x 4.06 cycles / 1024 SIMDs / the clock the chip
+# holds inside that kernel (tools/clock_probe.py), against the measured launch time.
+VALU_ISSUE_CYCLES = 4.06
 # documented ceiling: a wave64 64-bit multiply-add occupies its SIMD for 4 cycles = 16 lanes per clock and SIMD,
 # 256 CUs x 4 SIMDs, 2.4 GHz maximum clock (MI355X_MICROARCH.md)
 VALU_PEAK_THEORETICAL_MAC32 = 256 * 4 * 16 * 2.4e9
@@ -459,6 +466,12 @@ def main():
             except Exception:
                 traffic = pair_traffic = msm_traffic = bbs_traffic = g2_traffic = None
 
+        issue_json = {}
+        try:
+            issue_json = json.load(open(os.path.join(ROOT, "profiles", "issue.json")))
+        except Exception:
+            issue_json = {}
+
         def hbm(bytes_per_unit, units, secs, kernel, tr=None, **more):
             a = bytes_per_unit * units / secs / 1e9
             d = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": tr, "kernel": kernel,
@@ -470,12 +483,20 @@ def main():
             """the binding roofline: algorithmic multiply-adds per launch / average launch time against the measured multiply-add rate"""
             a = mac_per_unit * units / secs
             d = {"bound": "int-valu", "achieved": a / 1e9, "peak": VALU_PEAK_MAC32 / 1e9, "peak_theoretical": VALU_PEAK_THEORETICAL_MAC32 / 1e9,
-                 "peak_at_2_waves_per_simd": VALU_PEAK_MAC32_2WAVES / 1e9, "unit": "GMAC32/s", "frac": a / VALU_PEAK_MAC32,
-                 "frac_of_theoretical": a / VALU_PEAK_THEORETICAL_MAC32, "frac_of_2_wave_peak": a / VALU_PEAK_MAC32_2WAVES,
+                 "unit": "GMAC32/s", "frac": a / VALU_PEAK_MAC32, "frac_of_theoretical": a / VALU_PEAK_THEORETICAL_MAC32,
                  "frac_vs_round2_peak": a / VALU_PEAK_MAC32_R02, "traffic": tr,
                  "algorithmic_mac32_per_unit": mac_per_unit, "avg_launch_ms": secs * 1e3}
             if kernel:
                 d["kernel"] = kernel
+                ik = issue_json.get("kernels", {}).get(kernel.split(" ")[-1])          # "... dominant kernel <name>" for the BBS+ pipeline
+                if ik:
+                    insts = ik["valu_insts_per_launch"] * units / ik["units_per_launch"]
+                    bound_s = insts * VALU_ISSUE_CYCLES / 1024 / (ik["clock_GHz"] * 1e9)
+                    d["issue"] = {"valu_insts_per_launch": insts, "cycles_per_inst": VALU_ISSUE_CYCLES, "clock_GHz": ik["clock_GHz"],
+                                  "bound_ms": bound_s * 1e3, "frac_of_issue_bound": bound_s / secs,
+                                  "multiply_add_share_of_insts": mac_per_unit * units / 64 / insts,
+                                  "note": "issue-bound: one vector instruction per 4.06 cycles and SIMD whatever it is (profiles/r03_issue_mix.txt); "
+                                          "insts and clock from profiles/issue.json (counter pass, clock probe), not from this run"}
             d.update(more)
             return d
         result = {

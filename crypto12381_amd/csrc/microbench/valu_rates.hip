@@ -7,6 +7,9 @@
 //          S  = 12 x 32-bit saturated limbs (R = 2^384)
 //          U  = 14 x 29-bit unsaturated limbs (R = 2^406), one 64-bit column accumulator
 //
+// NOTE (round 3): part 1 times 16 instructions per loop iteration with events.  The loop's own scalar instructions and the uneven
+// arrival of the workgroups are inside those rates; issue_mix.hip counts cycles inside the kernel with 128 instructions per
+// iteration and is what bench.py's peak comes from.  This file stays for the relative rates of the instruction kinds.
 // Build:  hipcc -O3 --offload-arch=gfx950 valu_rates.hip -o valu_rates
 // Run:    ./valu_rates [out.txt]       (prints one line per measurement)
 #include <hip/hip_runtime.h>

@@ -47,6 +47,25 @@ for key, kern in (("pair_kernel", "pair3_queue_kernel"), ("pair3_prod_fixed_queu
         t[key]["FETCH_SIZE_KB"], t[key]["WRITE_SIZE_KB"] = s[kern]["FETCH_SIZE"], s[kern]["WRITE_SIZE"]
         t[key]["hbm_bytes_per_launch"] = s[kern]["FETCH_SIZE"] * 2048 + s[kern]["WRITE_SIZE"] * 1024
 json.dump(t, open("profiles/traffic.json", "w"), indent=1)
+# profiles/issue.json: what bench.py's `roofline.issue` object is computed from — VALU instructions per launch (SQ_INSTS_VALU pass) and the
+# clock the chip holds inside each kernel (tools/clock_probe.py); the cycles per instruction come from csrc/microbench/issue_mix.hip
+clk = {}
+for line in open("profiles/%s_clock_probe.txt" % R):
+    m = re.match(r"(\w+) .*median ([\d.]+) GHz", line)
+    if m:
+        clk[m.group(1)] = float(m.group(2))
+issue = {"source": "SQ_INSTS_VALU: rocprofv3 --pmc pass of tools/pmc_r03.sh (profiles/%s_pmc_summary.json); clock_GHz: median of tools/clock_probe.py "
+                   "(profiles/%s_clock_probe.txt; the BBS+ kernel takes the pairing kernel's); cycles_per_valu_inst: csrc/microbench/issue_mix.hip, "
+                   "profiles/r03_issue_mix.txt — a SIMD issues one vector instruction per 4.06 cycles from its OLDEST wavefront whatever the "
+                   "instruction is; a second wavefront only fills the older one's stalls" % (R, R),
+         "cycles_per_valu_inst": 4.06, "simds": 1024, "kernels": {}}
+for kern, units, ck in (("g1_mul_kernel", 131072, "g1_mul"), ("g2_mul2_kernel", 131072, "g2_mul"), ("pair3_queue_kernel", 65536, "pairing"),
+                        ("miller3_queue_kernel", 65536, "miller"), ("fexp3_queue_kernel", 65536, "fexp"), ("msm_bucket_kernel", 4194304, "msm"),
+                        ("pair3_prod_fixed_queue_kernel", 262144, "pairing")):
+    if kern in s and "SQ_INSTS_VALU" in s[kern] and ck in clk:
+        issue["kernels"][kern] = {"units_per_launch": units, "valu_insts_per_launch": s[kern]["SQ_INSTS_VALU"], "clock_GHz": clk[ck],
+                                  "wait_any_frac": s[kern].get("wait_any_frac")}
+json.dump(issue, open("profiles/issue.json", "w"), indent=1)
 for k in ("g1_mul_kernel", "g2_mul2_kernel", "pair3_queue_kernel", "pair3_prod_fixed_queue_kernel", "msm_bucket_kernel", "miller3_queue_kernel", "fexp3_queue_kernel"):
     if k in s:
         v = s[k]
