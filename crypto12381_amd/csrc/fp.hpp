@@ -47,8 +47,13 @@ namespace c12381 { __device__ __forceinline__ int32_t limb_opaque(int32_t v) { a
 // of the previous column afterwards (one v_lshl_add_u64 per column, ~1 instruction per 15 multiply-adds), and it splits the signed limb
 // products and the non-negative m * p products into two chains.  -DC12381_ACC_FENCE=1 puts an empty asm on the accumulator after every
 // multiply-add, which forces ONE linear chain per column sequence: the adds disappear (g1_mul_kernel: -20 % non-multiply instructions,
-// no spill), but a dependent v_mad_i64_i32 needs a wait state and the compiler pays it with an s_nop per ~2 multiply-adds — measured:
-// G1 -1 %, G2 +5 %, MSM +2 %, pairing kernel 18.1 -> 24.4 ms.  The compiler's two-chain form stays.
+// no spill), but the hazard recognizer puts one wait state (s_nop 0, a full 4-cycle issue slot) between a vector instruction and an inline
+// asm that reads its result — the empty asm could hold a v_readlane — wherever the scheduler left the two adjacent: 345 s_nop for 208
+// adds saved in the bucket kernel.  Measured: G1 -1 %, G2 +5 %, MSM +2 %, pairing kernel 18.1 -> 24.4 ms (the linear chains also make
+// the max-ilp scheduler interleave five reductions: spills).  A second use of every partial sum (__builtin_assume) instead of the asm
+// keeps the carry first but splits the m * p terms off into a chain of their own: two adds per column instead of one, and 3 x the
+// compile time.  A hand-written multiplier in one asm statement is out of reach in HIP C++: 42 register operands against the limit of
+// 30, and a 16-dword tuple operand cannot be indexed inside the asm string.  The compiler's two-chain form stays.
 #ifndef C12381_ACC_FENCE
 #define C12381_ACC_FENCE 0
 #endif
