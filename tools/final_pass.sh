@@ -13,6 +13,8 @@ bash tools/pmc_r03.sh gpurun_out/final/pmc > gpurun_out/final/pmc.txt 2>&1; tail
 bash tools/bench_2rank_gloo.sh > gpurun_out/final/bench_2rank_gloo.json 2> gpurun_out/final/bench_2rank_gloo.err; echo "2rank rc=$?"
 timeout -k 10 200 python tools/clock_probe.py 2>&1 | grep -v amdgpu.ids > gpurun_out/final/clock_probe.txt; echo "clock rc=$?"
 timeout -k 10 400 python3 tools/soak.py > gpurun_out/final/soak.log 2>&1; echo "soak rc=$?"; tail -2 gpurun_out/final/soak.log
+# fresh random inputs, every lane against the compiled reference (CPU-bound: ~70 s per iteration); the long form is run on its own
+timeout -k 10 400 python3 tools/parity_soak.py --minutes 2.5 > gpurun_out/final/parity_soak_short.log 2>&1; echo "parity soak rc=$?"; tail -1 gpurun_out/final/parity_soak_short.log
 python - <<'PY'
 import json
 d=json.load(open("gpurun_out/final/bench.json"))
