@@ -458,7 +458,7 @@ def main():
                 if pair is not None:
                     pair_traffic = tj["pair_kernel"]["hbm_bytes_per_launch"] * pair["npair"] / tj["pair_kernel"]["units_per_launch"]
                 if split is not None and "g2_mul2_kernel" in tj:
-                    g2_traffic = tj["g2_mul2_kernel"]["hbm_bytes_per_launch"]          # per launch of 2^17 points
+                    g2_traffic = tj["g2_mul2_kernel"]["hbm_bytes_per_launch"] / tj["g2_mul2_kernel"]["units_per_launch"]     # per point; scaled per launch below
                 if msm is not None and "msm_bucket_kernel" in tj:
                     msm_traffic = tj["msm_bucket_kernel"]["hbm_bytes_per_launch"] * msm["n"] / tj["msm_bucket_kernel"]["units_per_launch"]
                 if bbs is not None and "pair3_prod_fixed_queue_kernel" in tj:
@@ -592,7 +592,8 @@ def main():
                 launches_per_step = kprof[1] / max(st, 1)
                 d = {"metric": metric, "value": world * units * st / el, "unit": unit, "steps": st, "ms_per_step": el / st * 1e3,
                      "config": {"workload": workload}, "parity": parity,
-                     "roofline": valu(mac, units / max(launches_per_step, 1), k_s, kernel, tr, launches_per_step=launches_per_step),
+                     "roofline": valu(mac, units / max(launches_per_step, 1), k_s, kernel, tr, launches_per_step=launches_per_step,
+                                      units_per_launch=units / max(launches_per_step, 1)),
                      "hbm_roofline": hbm(nbytes, units / max(launches_per_step, 1), k_s, kernel, tr)}
                 if do_cpu:
                     d["cpu_baseline"] = {"value": ns / cpu_s, "unit": unit, "cores": cores, "kind": kind, "sample": "first %d lanes of the same batch, %d threads" % (ns, cores)}
@@ -600,7 +601,8 @@ def main():
             result["g2_mul"] = leg("G2 scalar-muls/s per MI355X (batch 2^%d per GPU), bit-exact vs CPU" % args.log2_g2, "scalar-muls/s", ng2, split["g2_el"],
                                    split["g2k"], MAC32_G2_MUL, BYTES_G2_MUL, "g2_mul2_kernel",
                                    "PAIR_G2mul: 2^%d random (point, scalar) pairs, 192-B affine in / out, 32-B scalars (edge scalars in lanes 0..4)" % args.log2_g2,
-                                   {"checked_lanes": ns, "of": ng2, "oracle": kind, "bit_exact": True}, g2_s, g2_traffic)
+                                   {"checked_lanes": ns, "of": ng2, "oracle": kind, "bit_exact": True}, g2_s,
+                                   None if g2_traffic is None else g2_traffic * ng2 / max(split["g2k"][1] / max(st, 1), 1))
             result["miller"] = leg("Miller loops/s per MI355X (batch 2^%d per GPU), the reference's field element" % args.log2_pairings, "Miller loops/s", npair,
                                    split["mil_el"], split["milk"], MAC32_MILLER, 96 + 192 + 576, "miller3_queue_kernel" if (npair + 20) // 21 > 2048 else "miller3_kernel",
                                    "PAIR_ate: the 2^%d (P_i, Q_i) of the pairing leg -> 576-B Miller value each" % args.log2_pairings,

@@ -31,11 +31,23 @@ inline const char* tuning_env(const char* name) { return std::getenv(name); }
 #else
 inline const char* tuning_env(const char*) { return nullptr; }
 #endif
-// elements per scalar-mul launch: G1 = the lanes resident at the kernel's occupancy (256 CUs x 4 SIMDs x 64 lanes x waves per SIMD),
-// one machine-filling round per launch; G2 (two lanes per point) = two rounds.  Table slabs: 2816 B per lane (G1 352 MiB, G2 704 MiB at 2 waves)
+// elements per scalar-mul launch, in machine rounds (one round = the lanes resident at the kernel's occupancy: 256 CUs x 4 SIMDs x
+// 64 lanes x waves per SIMD).  EIGHT rounds per launch, not one: a SIMD serves its oldest wavefront first and the younger one only
+// fills its stalls (csrc/microbench/issue_mix.hip), so in a launch of exactly the resident size the older workgroup of each CU runs at
+// full speed, leaves, and the younger one then runs ALONE with every wait for its table records exposed (SQ_WAIT_ANY 12 % per
+// wavefront: + 6 % on the launch).  With more rounds per launch the dispatcher puts a new workgroup beside the one that is left, and only
+// the last round runs alone: G1 26.8 -> 25.8-26.1 ms per 2^20, G2 8.04 -> 7.66 ms per 2^17 (profiles/r03_ab_chunk_rounds.txt).
+// Table slabs: 2816 B per lane — 2.95 GB for a full G1 launch of 2^20 points, 2.95 GB for a full G2 launch of 2^19 (two lanes per point);
+// smaller batches allocate for their own size.
 int g_queue_groups_host = 0;                    // experiments builds: C12381_QUEUE_GROUPS (the device copy is set alongside, k_pair3.hip)
-constexpr size_t G1_CHUNK = (size_t)65536 * C12381_G1_OCC;
-constexpr size_t G2_CHUNK = (size_t)65536 * C12381_G2H_OCC;
+#ifndef C12381_G1_CHUNK_ROUNDS
+#define C12381_G1_CHUNK_ROUNDS 8
+#endif
+#ifndef C12381_G2_CHUNK_ROUNDS
+#define C12381_G2_CHUNK_ROUNDS 8
+#endif
+constexpr size_t G1_CHUNK = (size_t)65536 * C12381_G1_OCC * C12381_G1_CHUNK_ROUNDS;
+constexpr size_t G2_CHUNK = (size_t)32768 * C12381_G2H_OCC * C12381_G2_CHUNK_ROUNDS;
 constexpr int FLAG_WORDS = 4;                    // device status words (read_flag)
 // terms per bucket-method pass (2 * n * windows sort items < 2^31); C12381_MSM_MAX_TERMS lowers it so that tests reach
 // the multi-part path with small inputs

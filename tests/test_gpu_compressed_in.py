@@ -99,8 +99,8 @@ def test_compressed_inputs_vs_reference(oracle_ref):
 
 
 def test_compressed_inputs_device_pointers_full_chunks(oracle_ref):
-    """_dev forms on a batch that spans several scalar-multiplication launches (2^17 + 77 G1 elements) and the bucket MSM at 2^14
-    compressed terms, sampled against the reference"""
+    """_dev forms on a batch that spans two scalar-multiplication launches (2^20 + 77 G1 elements: a launch takes 2^20) and the
+    bucket MSM at 2^14 compressed terms, sampled against the reference"""
     import torch
     from crypto12381_amd import Context
     from crypto12381_amd.capi import F_COMPRESSED_IN
@@ -109,7 +109,7 @@ def test_compressed_inputs_device_pointers_full_chunks(oracle_ref):
     g1 = oracle_ref.g1_generator()
     m = 1 << 10
     base = ctx.g1_mul(g1 * m, scalars(1211, m), 49)
-    n = (1 << 17) + 77
+    n = (1 << 20) + 77
     c1 = (base * (n // m + 1))[:49 * n]
     sc = scalars(1212, 512, 1 << 256) * (n // 512 + 1)
     sc = sc[:32 * n]
@@ -120,7 +120,7 @@ def test_compressed_inputs_device_pointers_full_chunks(oracle_ref):
     ctx.g1_mul_flags_dev(n, dc.data_ptr(), ds.data_ptr(), out.data_ptr(), 96, F_COMPRESSED_IN)
     assert ctx.sync() == 0
     got = out.cpu().numpy().tobytes()
-    idx = [0, 1, 2, 511, 512, 1023, 1024, (1 << 17) - 1, 1 << 17, n - 1]
+    idx = [0, 1, 2, 511, 512, 1023, 1024, (1 << 17) - 1, 1 << 17, (1 << 20) - 1, 1 << 20, (1 << 20) + 1, n - 1]
     pts96 = oracle_ref.g1_decompress(b"".join(c1[49 * i:49 * i + 49] for i in idx))[0]
     assert b"".join(got[96 * i:96 * i + 96] for i in idx) == oracle_ref.g1_mul(pts96, b"".join(sc[32 * i:32 * i + 32] for i in idx), 96, 4)
     nm = 1 << 14
@@ -129,4 +129,30 @@ def test_compressed_inputs_device_pointers_full_chunks(oracle_ref):
     assert ctx.sync() == 0
     d96 = ctx.g1_decompress(c1[:49 * nm])[0]
     assert o1.cpu().numpy().tobytes() == ctx.g1_msm(d96, sc[:32 * nm], 96)
+    ctx.close()
+
+
+def test_g2_batch_spanning_two_launches(oracle_ref):
+    """2^19 + 33 G2 multiplications through the _dev entry (a launch takes 2^19 points): lanes either side of the launch boundary and
+    at both ends against the reference"""
+    import torch
+    from crypto12381_amd import Context
+    ctx = Context(0)
+    dev = torch.device("cuda", 0)
+    g2 = oracle_ref.g2_generator()
+    m = 1 << 10
+    base = ctx.g2_mul(g2 * m, scalars(1311, m), 192)
+    n = (1 << 19) + 33
+    pts = (base * (n // m + 1))[:192 * n]
+    sc = (scalars(1312, 512, 1 << 256) * (n // 512 + 1))[:32 * n]
+    dp, ds = torch.frombuffer(bytearray(pts), dtype=torch.uint8).to(dev), torch.frombuffer(bytearray(sc), dtype=torch.uint8).to(dev)
+    out = torch.empty(192 * n, dtype=torch.uint8, device=dev)
+    s = torch.cuda.Stream(device=dev)
+    ctx.set_stream(s.cuda_stream)
+    ctx.g2_mul_dev(n, dp.data_ptr(), ds.data_ptr(), out.data_ptr(), 192)
+    assert ctx.sync() == 0
+    got = out.cpu().numpy().tobytes()
+    idx = [0, 1, 63, 64, (1 << 17) - 1, 1 << 17, (1 << 19) - 2, (1 << 19) - 1, 1 << 19, (1 << 19) + 1, n - 2, n - 1]
+    want = oracle_ref.g2_mul(b"".join(pts[192 * i:192 * i + 192] for i in idx), b"".join(sc[32 * i:32 * i + 32] for i in idx), 192, 4)
+    assert b"".join(got[192 * i:192 * i + 192] for i in idx) == want
     ctx.close()
