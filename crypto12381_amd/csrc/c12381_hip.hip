@@ -123,7 +123,7 @@ struct timed {
 // scalar multiplication of n elements into the projective SoA workspace (stride = padded n)
 // (results land at proj[proj_off + i]; pt_stride 96 = per-lane points, 0 = one broadcast point)
 // in_g1: the caller asserts every point lies in G1 (C12381_F_IN_SUBGROUP): the [r]phi(P) terms of scalars below x^2 are then
-// the point at infinity and the fix-up pass — a membership test as long as a scalar multiplication per such lane — is not launched
+// the point at infinity and the kernel skips them — a membership test as long as a scalar multiplication per such lane
 int g1_mul_to_proj(c12381_ctx* c, size_t n, const uint8_t* d_pts, const uint8_t* d_sc, size_t stride, size_t pt_stride = 96,
                    size_t proj_off = 0, const int32_t* skip_if = nullptr, bool in_g1 = false) {
     const size_t chunk = n < G1_CHUNK ? round_up(n, 64) : G1_CHUNK;
@@ -132,30 +132,13 @@ int g1_mul_to_proj(c12381_ctx* c, size_t n, const uint8_t* d_pts, const uint8_t*
     if ((rc = ensure(c, c12381_ctx::WS_PROJ, (size_t)3 * NL * stride * 4))) return rc;
     for (size_t off = 0; off < n; off += chunk) {
         const size_t m = n - off < chunk ? n - off : chunk;
-        {
-            timed tm(c, 0);
-            hipLaunchKernelGGL(g1_mul_kernel, dim3(grid_for(m)), dim3(BLOCK), 0, c->stream, m, d_pts + pt_stride * off, pt_stride, d_sc + 32 * off,
-                               (int32_t*)c->ws[c12381_ctx::WS_TAB], (int32_t*)c->ws[c12381_ctx::WS_PROJ], stride, proj_off + off, c->d_flag, skip_if);
-            HIPCK(c, hipGetLastError());
-        }
-        // the reference's small-scalar term (g1.hpp) for this chunk: empty unless some k mod r < x^2, and then a few lanes
-        // at single-wavefront latency (~1 ms) — on the side stream, so it overlaps the next chunk
-        if (in_g1) continue;
-        const size_t ci = off / chunk;
-        while (c->ev_chunk.size() <= ci) {
-            hipEvent_t e;
-            HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            c->ev_chunk.push_back(e);
-        }
-        HIPCK(c, hipEventRecord(c->ev_chunk[ci], c->stream));
-        HIPCK(c, hipStreamWaitEvent(c->side, c->ev_chunk[ci], 0));
-        hipLaunchKernelGGL(g1_small_scalar_kernel, dim3(grid_for(m)), dim3(BLOCK), 0, c->side, m, d_pts + pt_stride * off, pt_stride, d_sc + 32 * off,
-                           (int32_t*)c->ws[c12381_ctx::WS_PROJ], stride, proj_off + off, skip_if);
+        timed tm(c, 0);
+        // small_term: the reference's [r]phi(P) for scalars below x^2, inside the kernel (k_g1.hip); in_g1 callers have none to add
+        hipLaunchKernelGGL(g1_mul_kernel, dim3(grid_for(m)), dim3(BLOCK), 0, c->stream, m, d_pts + pt_stride * off, pt_stride, d_sc + 32 * off,
+                           (int32_t*)c->ws[c12381_ctx::WS_TAB], (int32_t*)c->ws[c12381_ctx::WS_PROJ], stride, proj_off + off, c->d_flag, skip_if,
+                           in_g1 ? 0 : 1);
         HIPCK(c, hipGetLastError());
     }
-    if (in_g1) return 0;
-    HIPCK(c, hipEventRecord(c->ev_side, c->side));
-    HIPCK(c, hipStreamWaitEvent(c->stream, c->ev_side, 0));
     return 0;
 }
 int g1_finish(c12381_ctx* c, size_t n, const int32_t* proj, size_t stride, uint8_t* d_out, int fmt) {

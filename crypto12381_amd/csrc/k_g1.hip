@@ -54,7 +54,8 @@ __global__ void __launch_bounds__(BLOCK, 2) fp_mulchain_kernel(size_t n, int ite
 // proj layout: coordinate-major, limb-major SoA: proj[(c*NL + limb) * stride + element]
 // pt_stride = 96 for per-lane points, 0 to broadcast one point to every lane (fixed-base columns of BBS+)
 __global__ void __launch_bounds__(BLOCK, C12381_G1_OCC) g1_mul_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab,
-                                                       int32_t* proj, size_t proj_stride, size_t proj_off, int* bad_flag, const int32_t* skip_if) {
+                                                       int32_t* proj, size_t proj_stride, size_t proj_off, int* bad_flag, const int32_t* skip_if,
+                                                       int small_term) {
     if (skip_if && skip_if[HDR_VALID] != 0) return;          // this column is served by a valid fixed-base table (k_fixed.hip)
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -66,34 +67,22 @@ __global__ void __launch_bounds__(BLOCK, C12381_G1_OCC) g1_mul_kernel(size_t n, 
     scalar_from_raw32(k, raw);
     g1p acc;
     g1_scalar_mul(acc, px, py, inf || !ok, k, tab + i * (size_t)G1_TAB_DWORDS);
+    // the reference's [r]phi(P) term of scalars below x^2 (g1.hpp): no lane of a batch of random scalars, and then one that keeps its
+    // wavefront for the length of a second scalar multiplication.  In a launch of several machine rounds that wavefront's workgroup
+    // simply leaves later while others take the free slots; a separate fix-up launch behind the kernel (rounds 1-3) costs its full
+    // single-wavefront latency, 1.3 ms, whenever one lane of 2^20 owes the term.
+    if (small_term && ok && !inf && scalar_below_x2(k)) {
+        g1p base, nn;
+        base.x = px; base.y = py; fp_one(base.z);
+        g1_norm1(nn, acc);
+        g1_glv_small_scalar_term(nn, base);
+        acc = nn;
+    }
     if (!ok) {
         *bad_flag = 1;
         // poison: Z = 0, X = 1 marks "invalid" for the finish kernel
         fp_one(acc.x); fp_zero(acc.y); fp_zero(acc.z);
     }
-    g1p o;
-    g1_norm1(o, acc);
-    soa_store_g1(proj, proj_stride, proj_off + i, o);
-}
-
-// Fix-up pass after g1_mul_kernel: lanes whose scalar is below x^2 add the reference's [r]phi(P) term (g1.hpp).  Every
-// other lane — with random scalars: all of them — leaves after reading its scalar.
-__global__ void __launch_bounds__(BLOCK, 2) g1_small_scalar_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars,
-                                                                int32_t* proj, size_t proj_stride, size_t proj_off, const int32_t* skip_if) {
-    if (skip_if && skip_if[HDR_VALID] != 0) return;
-    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    uint32_t raw[8], k[8];
-    load_raw32(raw, scalars + 32 * i);
-    scalar_from_raw32(k, raw);
-    if (!scalar_below_x2(k)) return;
-    g1p base, acc;
-    bool inf, ok;
-    g1_parse_any(base.x, base.y, inf, ok, pts, pt_stride, i);
-    if (inf || !ok) return;
-    fp_one(base.z);
-    soa_load_g1(acc, proj, proj_stride, proj_off + i);
-    g1_glv_small_scalar_term(acc, base);
     g1p o;
     g1_norm1(o, acc);
     soa_store_g1(proj, proj_stride, proj_off + i, o);

@@ -40,8 +40,7 @@ constexpr int GATE_OTHER = 49;                   // (gate + GATE_OTHER)[HDR_VALI
 #endif
 __global__ void __launch_bounds__(BLOCK, 2) fp_op_kernel(int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out);
 __global__ void __launch_bounds__(BLOCK, 2) fp_mulchain_kernel(size_t n, int iters, const uint8_t* a, const uint8_t* b, uint8_t* out);
-__global__ void __launch_bounds__(BLOCK, C12381_G1_OCC) g1_mul_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab, int32_t* proj, size_t proj_stride, size_t proj_off, int* bad_flag, const int32_t* skip_if);
-__global__ void __launch_bounds__(BLOCK, 2) g1_small_scalar_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* proj, size_t proj_stride, size_t proj_off, const int32_t* skip_if);
+__global__ void __launch_bounds__(BLOCK, C12381_G1_OCC) g1_mul_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab, int32_t* proj, size_t proj_stride, size_t proj_off, int* bad_flag, const int32_t* skip_if, int small_term);
 __global__ void __launch_bounds__(BLOCK, 2) g1_rsub_kernel(size_t n, int32_t* acc, size_t acc_stride, const int32_t* other, size_t other_stride, size_t other_off, const int32_t* run_if);
 __global__ void __launch_bounds__(BLOCK, 2) g1_add_kernel(size_t n, const uint8_t* a, const uint8_t* b, int32_t* proj, size_t proj_stride, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) g1_finish_kernel(size_t n, const int32_t* proj, size_t stride, int32_t* pref, uint8_t* out, int fmt, size_t T);
