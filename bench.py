@@ -493,10 +493,12 @@ def main():
                     insts = ik["valu_insts_per_launch"] * units / ik["units_per_launch"]
                     bound_s = insts * VALU_ISSUE_CYCLES / 1024 / (ik["clock_GHz"] * 1e9)
                     d["issue"] = {"valu_insts_per_launch": insts, "cycles_per_inst": VALU_ISSUE_CYCLES, "clock_GHz": ik["clock_GHz"],
-                                  "bound_ms": bound_s * 1e3, "frac_of_issue_bound": bound_s / secs,
+                                  "issue_time_ms": bound_s * 1e3, "issue_time_over_launch_time": bound_s / secs,
                                   "multiply_add_share_of_insts": mac_per_unit * units / 64 / insts,
-                                  "note": "issue-bound: one vector instruction per 4.06 cycles and SIMD whatever it is (profiles/r03_issue_mix.txt); "
-                                          "insts and clock from profiles/issue.json (counter pass, clock probe), not from this run"}
+                                  "note": "issue time = the launch's vector instructions x 4.06 cycles / 1024 SIMDs / clock: one vector instruction per 4.06 "
+                                          "cycles and SIMD whatever it is (profiles/r03_issue_mix.txt).  insts and clock come from profiles/issue.json "
+                                          "(counter pass and clock probe of the same build), not from this run; the probe's median clock is good to "
+                                          "about +-3 %, so a ratio of 1.0 +- 0.03 reads 'at the issue rate'"}
             d.update(more)
             return d
         result = {
