@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Fixed workload for the round-3 rocprofv3 passes: ONE launch sequence of every dominant kernel at its BASELINE size through the
-device-pointer entry points — G1 2^18 (two g1_mul_kernel launches), G2 2^17 (one g2_mul2_kernel launch), 2^16 pairings
+device-pointer entry points — G1 2^18 (one g1_mul_kernel launch of two machine rounds), G2 2^17 (one g2_mul2_kernel launch), 2^16 pairings
 (pair3_queue_kernel), Miller loops and final exponentiations alone, MSM 2^22 (msm_bucket_kernel), 2^18 BBS+ verifications
 (pair3_prod_fixed_queue_kernel).  Usage: python3 tools/prof_driver3.py [all|g1|g2|pair|msm|bbs]"""
 import os

@@ -41,6 +41,7 @@ t = json.load(open("profiles/traffic.json"))
 g = s["g1_mul_kernel"]
 t["FETCH_SIZE_KB"], t["WRITE_SIZE_KB"] = g["FETCH_SIZE"], g["WRITE_SIZE"]
 t["g1_mul_kernel_hbm_bytes_per_launch"] = g["FETCH_SIZE"] * 2048 + g["WRITE_SIZE"] * 1024
+t["units_per_launch"] = 262144          # tools/prof_driver3.py: 2^18 G1 elements, ONE launch since launches span eight rounds
 for key, kern in (("pair_kernel", "pair3_queue_kernel"), ("pair3_prod_fixed_queue_kernel", "pair3_prod_fixed_queue_kernel"),
                   ("msm_bucket_kernel", "msm_bucket_kernel"), ("g2_mul2_kernel", "g2_mul2_kernel")):
     if kern in s and "FETCH_SIZE" in s[kern]:
@@ -59,7 +60,7 @@ issue = {"source": "SQ_INSTS_VALU: rocprofv3 --pmc pass of tools/pmc_r03.sh (pro
                    "profiles/r03_issue_mix.txt — a SIMD issues one vector instruction per 4.06 cycles from its OLDEST wavefront whatever the "
                    "instruction is; a second wavefront only fills the older one's stalls" % (R, R),
          "cycles_per_valu_inst": 4.06, "simds": 1024, "kernels": {}}
-for kern, units, ck in (("g1_mul_kernel", 131072, "g1_mul"), ("g2_mul2_kernel", 131072, "g2_mul"), ("pair3_queue_kernel", 65536, "pairing"),
+for kern, units, ck in (("g1_mul_kernel", 262144, "g1_mul"), ("g2_mul2_kernel", 131072, "g2_mul"), ("pair3_queue_kernel", 65536, "pairing"),
                         ("miller3_queue_kernel", 65536, "miller"), ("fexp3_queue_kernel", 65536, "fexp"), ("msm_bucket_kernel", 4194304, "msm"),
                         ("pair3_prod_fixed_queue_kernel", 262144, "pairing")):
     if kern in s and "SQ_INSTS_VALU" in s[kern] and ck in clk:
