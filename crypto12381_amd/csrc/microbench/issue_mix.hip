@@ -19,7 +19,8 @@
 //         (vector instructions of both wavefronts) x 4.06 cycles + the stalls both wavefronts have at the same time;
 //   - ds_bpermute_b32 costs the issuing wavefront 24 cycles each (48 with two wavefronts per SIMD doing it), multiply-adds issued
 //     behind it are hidden in that time;
-//   - a run of VOP2 v_cndmask_b32 reading vcc is slow on its own (19-32 cycles each), not next to other instructions.
+//   - VOP2 v_cndmask_b32 reading vcc: 16 in a row issue at 4 cycles each, every further one of the same run at 20-40 cycles (32 in a row:
+//     768 cycles instead of 196); the VOP3 form with an SGPR-pair condition stays at 4.
 //
 // Build:  hipcc -O3 --offload-arch=gfx950 issue_mix.hip -o issue_mix      Run:  ./issue_mix [out.txt]
 #include <hip/hip_runtime.h>
@@ -107,6 +108,11 @@ __global__ void __launch_bounds__(256) mix_kernel(uint32_t* out, uint32_t seed, 
         else if constexpr (KIND == 26) asm volatile(X8(M8 M8 T8 T8) OPERANDS);
         else if constexpr (KIND == 27) asm volatile(X8(P8 P8 "s_waitcnt lgkmcnt(0)\n\t") OPERANDS);   // 16 ds_bpermute + one wait
         else if constexpr (KIND == 28) asm volatile(X8(M8 M8 P8 P8 "s_waitcnt lgkmcnt(0)\n\t") OPERANDS);
+        else if constexpr (KIND == 30) asm volatile(X8(M8 M8 S8 S8 S8 S8) OPERANDS);                     // 16 mads, then a run of 32 vcc selects
+        else if constexpr (KIND == 31) asm volatile(X8(M8 M8 S8 S8 S8 S8 S8 S8 S8 S8) OPERANDS);         // ... of 64
+        else if constexpr (KIND == 32) asm volatile(X8(M8 M8 S8 S8 S8 S8 S8 S8 S8 S8 S8 S8 S8 S8 S8 S8 S8 S8) OPERANDS);   // ... of 128
+        else if constexpr (KIND == 33) asm volatile(X8(M8 M8 T8 T8 T8 T8 T8 T8 T8 T8) OPERANDS);         // 16 mads, then 64 SGPR-pair selects
+        else if constexpr (KIND == 34) asm volatile(X8(M8 M8 "v_cmp_gt_u32 vcc, %16, %17\n\t" S8 S8 S8 S8 S8 S8 S8 S8) OPERANDS);   // vcc written by a compare in front of the run, as compiled code does
         else if constexpr (KIND == 29) asm volatile(X8(P8 P8 M8 M8 "s_waitcnt lgkmcnt(0)\n\t") OPERANDS);   // the permutes issued first, the wait after the mads
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), w1 = __builtin_amdgcn_s_memrealtime();
@@ -170,7 +176,7 @@ int run(const char* name, int mads, int others, int waves_per_simd, FILE* fo) {
 
 int main(int argc, char** argv) {
     FILE* fo = argc > 1 ? fopen(argv[1], "w") : nullptr;
-    for (int w : {2, 1, 4, 8}) {
+    for (int w : {2, 1}) {
         if (run<0>("16 mad", 16, 0, w, fo)) return 1;
         if (run<22>("16 x (mad, s_nop)", 16, 0, w, fo)) return 1;
         if (run<1>("16 add", 0, 16, w, fo)) return 1;
@@ -201,6 +207,11 @@ int main(int argc, char** argv) {
         if (run<27>("16 ds_bpermute + wait", 0, 16, w, fo)) return 1;
         if (run<28>("16 mad, 16 ds_bpermute, wait", 16, 16, w, fo)) return 1;
         if (run<29>("16 ds_bpermute, 16 mad, wait", 16, 16, w, fo)) return 1;
+        if (run<30>("16 mad then 32 cndmask vcc", 16, 32, w, fo)) return 1;
+        if (run<31>("16 mad then 64 cndmask vcc", 16, 64, w, fo)) return 1;
+        if (run<32>("16 mad then 128 cndmask vcc", 16, 128, w, fo)) return 1;
+        if (run<33>("16 mad then 64 cndmask SGPR pair", 16, 64, w, fo)) return 1;
+        if (run<34>("16 mad, v_cmp, 64 cndmask vcc", 16, 65, w, fo)) return 1;
     }
     if (fo) fclose(fo);
     return 0;
