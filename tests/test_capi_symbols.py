@@ -33,3 +33,24 @@ def test_create_fails_loudly_without_gpu():
     except C12381Error:
         return
     raise AssertionError("Context() succeeded without a GPU")
+
+
+def test_profile_metadata_the_bench_line_reads():
+    """profiles/traffic.json and profiles/issue.json carry, for every dominant kernel the bench line names, what bench.py computes its
+    `traffic` and `roofline.issue` fields from (counter passes of tools/pmc_r03.sh, clock probe) — and bench.py names no kernel they lack."""
+    import json
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    i = json.load(open(os.path.join(ROOT, "profiles", "issue.json")))
+    assert t["units_per_launch"] > 0 and t["g1_mul_kernel_hbm_bytes_per_launch"] > 0
+    for key in ("pair_kernel", "pair3_prod_fixed_queue_kernel", "msm_bucket_kernel", "g2_mul2_kernel"):
+        assert t[key]["hbm_bytes_per_launch"] > 0 and t[key]["units_per_launch"] > 0, key
+    assert abs(i["cycles_per_valu_inst"] - 4.06) < 0.2 and i["simds"] == 1024
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for kern in ("g1_mul_kernel", "g2_mul2_kernel", "pair3_queue_kernel", "miller3_queue_kernel", "fexp3_queue_kernel", "msm_bucket_kernel",
+                 "pair3_prod_fixed_queue_kernel"):
+        k = i["kernels"][kern]
+        assert k["valu_insts_per_launch"] > 1e8 and 1.5 < k["clock_GHz"] < 2.6 and k["units_per_launch"] > 0, kern
+        assert kern in src, kern
+        # the issue time of the counter pass's launch is a plausible kernel time (0.5 ms .. 100 ms)
+        ms = k["valu_insts_per_launch"] * i["cycles_per_valu_inst"] / i["simds"] / (k["clock_GHz"] * 1e9) * 1e3
+        assert 0.5 < ms < 100, (kern, ms)
