@@ -8,12 +8,19 @@ kernel + inversion/encode kernel) over one batch whose inputs are already reside
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line.  Besides the headline it carries one object per remaining BASELINE config, each with its
+Started plainly with --gpus N > 1 (no WORLD_SIZE in the environment) the script becomes the launcher: before anything touches the
+GPU it starts N ranks of itself under torch.distributed.run on 127.0.0.1, relays their output and exits with their status.  Under a
+launcher WORLD_SIZE must equal --gpus, otherwise the run stops (a silent 1-GPU run of an "N-GPU" command is the failure to avoid).
+
+Rank 0 prints ONE JSON line, kept short enough for a log tail (floats rounded to 6 significant digits, explanations once under
+`notes`, the pairing leg — the second half of BASELINE's metric — LAST).  Besides the headline it carries one object per remaining BASELINE config, each with its
 own timing, parity against the CPU oracle, `roofline` / `hbm_roofline` and (N = 1) `cpu_baseline`:
     pairing   configs[2]  2^16 ate pairings (the WHOLE batch is compared with the oracle at N = 1)
     g2_mul / miller / fexp   the G2 scalar multiplication, the Miller loop and the final exponentiation alone
     msm       configs[3]  one product of 2^22 terms
-    bbs_plus  configs[4]  2^18 BBS+ verifications (real signatures, a known set of corrupted lanes)
+    bbs_plus  configs[4]  2^18 BBS+ verifications (real signatures, a known set of corrupted lanes), decoded inputs
+    bbs_plus_wire          the same 2^18 verifications END TO END from the serialized forms the reference's verify() parses
+                           (145-B signatures, raw messages, 195 + 49 nh + 97 B of public material; bbs+.cpp:57-73)
 and `cpu_baselines` for G2 multiplication, Miller loop and final exponentiation alone.
 With --gpus N every rank runs the weak-scaled legs on its own shard (independent units, no data-path collective) and
 two STRONG-scaled legs exercise what BASELINE describes for configs 4 and 5:
@@ -26,13 +33,19 @@ with `peak_theoretical` = 256 CUs x 4 SIMDs x 16 lanes/clock x 2.4 GHz beside it
 FETCH_SIZE / WRITE_SIZE counter passes (profiles/traffic.json).  `hbm_roofline` is the HBM view of the same kernel (algorithmic
 bytes / kernel time against 8 TB/s): evidence that the path is not memory bound.  Legs `g2_mul`, `miller`, `fexp` time the three
 remaining hot-path functions (PAIR_G2mul, PAIR_ate, PAIR_fexp) alone, each against the compiled reference on a sample.
-Only the parity / cpu_baseline legs touch oracle/ (the compiled reference when oracle/_ref is present, else our C port).
+`roofline.issue` prices the kernel's vector-instruction count (SQ_INSTS_VALU pass, profiles/issue.json — a property of the build) at
+the clock the chip holds inside that kernel IN THIS RUN (one-lane probe beside the kernel, lib/libc12381_probe.so).
+Only the parity / cpu_baseline legs touch oracle/: the compiled reference when oracle/_ref is present (`parity.pinned` true), else
+our C port — then every parity object says `"oracle": "port", "pinned": false`; nothing substitutes silently.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -72,6 +85,12 @@ BYTES_G1_MUL = 224               # 96 in + 32 scalar + 96 out
 BYTES_PAIRING = 864              # 96 + 192 in, 576 out
 BYTES_MSM_TERM = 128             # 96 + 32
 BYTES_BBS_VERIFY = 96 + 32 + 32 + 32 + 1
+# wire form: + the decode of A per signature (ECP_fromOctet: 502 products + 505 reductions); the public material is
+# decoded once per batch.  Bytes: 145-B signature + 12-B message in, 1 B out.
+MAC32_G1_DECODE = 502 * 144 + 505 * 156
+MAC32_BBS_WIRE_PIPELINE = MAC32_BBS_PIPELINE + MAC32_G1_DECODE
+BBS_MSG_LEN = 12
+BYTES_BBS_WIRE = 145 + BBS_MSG_LEN + 1
 HBM_PEAK_GBS = 8000.0
 # The multiply-add rate, measured inside the kernel (csrc/microbench/issue_mix.hip, profiles/r03_issue_mix.txt: shader cycles per wavefront
 # from s_memtime, 128 instructions per loop iteration): a SIMD issues one v_mad_i64_i32 — the instruction every limb product compiles
@@ -124,6 +143,71 @@ def sum_of_products_mod_r(a: np.ndarray, b: np.ndarray) -> int:
     return tot % R_ORDER
 
 
+def compact(o):
+    """floats to 6 significant digits, recursively (the line has to fit a log tail)"""
+    if isinstance(o, float):
+        return float("%.6g" % o)
+    if isinstance(o, dict):
+        return {k: compact(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [compact(v) for v in o]
+    return o
+
+
+def launch_ranks(ngpus: int) -> int:
+    """`python bench.py --gpus N` started plainly: run N ranks of this script (one per GPU) under torch.distributed.run and relay
+    their output.  Called before anything in this process has touched the GPU; the children are fresh processes."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without a launcher: starting %d ranks: %s" % (ngpus, ngpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.run(cmd).returncode
+
+
+class ClockProbe:
+    """the clock the chip holds while fn() runs back to back: lib/libc12381_probe.so samples (s_memtime, s_memrealtime) from one lane on
+    a stream of its own (csrc/microbench/clock_probe.hip); median over the second half of the run"""
+
+    def __init__(self, dev_index, dev):
+        path = os.path.join(ROOT, "crypto12381_amd", "lib", "libc12381_probe.so")
+        self.lib = ctypes.CDLL(path) if os.path.exists(path) else None
+        self.dev_index, self.dev = dev_index, dev
+        self.nsamp, self.gap = 2500, 30                       # ~100 us per sample: 0.25 s
+        if self.lib is not None:
+            self.lib.c12381_probe_start.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+            self.buf = torch.zeros(2 * self.nsamp, dtype=torch.int64, device=dev)
+
+    def during(self, fn, sync):
+        if self.lib is None:
+            return None
+        self.buf.zero_()
+        torch.cuda.synchronize(self.dev)
+        t0 = time.perf_counter()
+        if self.lib.c12381_probe_start(self.dev_index, ctypes.c_void_p(self.buf.data_ptr()), self.nsamp, self.gap) != 0:
+            return None
+        reps = 0
+        while time.perf_counter() - t0 < 0.25:
+            fn()
+            reps += 1
+            if reps % 4 == 0:
+                sync()
+        sync()
+        el = time.perf_counter() - t0
+        torch.cuda.synchronize(self.dev)
+        h = self.buf.cpu().numpy().reshape(self.nsamp, 2)
+        h = h[h[:, 1] != 0]
+        if len(h) < 16:
+            return None
+        span = h[:, 1] - h[0, 1]                              # 100 MHz ticks since the probe started
+        inrun = h[(span > 0.4 * el * 1e8) & (span < 0.95 * el * 1e8)]
+        if len(inrun) < 8:
+            return None
+        ghz = np.diff(inrun[:, 0]) / np.maximum(np.diff(inrun[:, 1]), 1) * 0.1
+        return float(np.median(ghz))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,20 +226,37 @@ def main():
     ap.add_argument("--all-configs", action="store_true", help="also time the SURVEY 8(f) extras (hash-to-G1, fixed base, Zp inversion, aggregate BBS+)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sampled-parity", action="store_true", help="compare 64 pairing lanes instead of the whole batch (quick A/B runs)")
+    ap.add_argument("--no-clock-probe", action="store_true", help="skip the in-run clock probe (roofline.issue then has no clock)")
+    ap.add_argument("--lib", default=None, help="another build of the same C ABI (A/B runs, tools/build_variant.sh); default: the product library")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            # nothing in this process has touched the GPU yet (importing torch does not): become the launcher of N fresh ranks
+            sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): refusing to report a %d-GPU run as %d GPUs"
+                         % (args.gpus, world, world, args.gpus))
+    # RCCL ("nccl") over xGMI on the GPU node; C12381_BENCH_BACKEND=gloo lets the N>1 path be rehearsed on one GPU
+    backend = os.environ.get("C12381_BENCH_BACKEND", "nccl")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     ndev = torch.cuda.device_count()
+    if world > ndev and backend == "nccl":
+        raise SystemExit("bench.py: %d ranks but %d visible GPU(s): one rank per GPU (C12381_BENCH_BACKEND=gloo rehearses N ranks on fewer GPUs)"
+                         % (world, ndev))
+    if args.lib:
+        from crypto12381_amd import capi
+        capi.use_library(args.lib)
     dev_index = local_rank % max(ndev, 1)          # one rank per GPU on the 8-GPU node; wraps only in single-GPU rehearsals
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    # RCCL ("nccl") over xGMI on the GPU node; C12381_BENCH_BACKEND=gloo lets the N>1 path be rehearsed on one GPU
-    backend = os.environ.get("C12381_BENCH_BACKEND", "nccl")
     comm_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         import torch.distributed as dist_mod
@@ -192,6 +293,13 @@ def main():
             el = float(t.item())
         return el
 
+    probe = None if args.no_clock_probe else ClockProbe(dev_index, dev)
+    clocks = {}                                       # kernel name -> GHz held inside it in THIS run (rank 0 reports them)
+
+    def probe_clock(name, fn):
+        if probe is not None and rank == 0:
+            clocks[name] = probe.during(fn, ctx.sync)
+
     n = 1 << args.log2_batch
     # ---- synthetic inputs, resident in HBM before the timed region
     base_sc_h = make_scalars(1000 + rank, n)
@@ -224,6 +332,7 @@ def main():
     ctx.profile(False)
     if ctx.sync() != 0:
         raise SystemExit("bench: invalid input point reported by the kernels")
+    probe_clock("g1_mul_kernel", g1_step)
 
     # ================================================================== configs[2]: pairings
     pair = None
@@ -244,6 +353,7 @@ def main():
         pel = timed(lambda: ctx.pair_dev(npair, p1.data_ptr(), q2.data_ptr(), gt.data_ptr()), max(1, args.steps), 0)
         pk_ms, pk_launches = ctx.profile_read(3)
         ctx.profile(False)
+        probe_clock("pair", lambda: ctx.pair_dev(npair, p1.data_ptr(), q2.data_ptr(), gt.data_ptr()))
         pair = {"npair": npair, "steps": max(1, args.steps), "elapsed": pel, "kernel_ms": pk_ms, "launches": pk_launches,
                 "p1": p1, "q2": q2, "gt": gt}
 
@@ -274,6 +384,9 @@ def main():
         ctx.profile(False)
         if ctx.sync() != 0:
             raise SystemExit("bench: invalid input reported by the split kernels")
+        probe_clock("g2_mul2_kernel", lambda: ctx.g2_mul_dev(ng2, g2_in.data_ptr(), g2_sc.data_ptr(), g2_out.data_ptr(), 192))
+        probe_clock("miller", lambda: ctx.miller_dev(npair, pair["p1"].data_ptr(), pair["q2"].data_ptr(), mil.data_ptr()))
+        probe_clock("fexp", lambda: ctx.gt_op_dev("fexp", npair, mil.data_ptr(), None, fex.data_ptr()))
         split = {"ng2": ng2, "steps": ssteps, "g2_el": g2_el, "mil_el": mil_el, "fex_el": fex_el, "g2k": (g2k_ms, g2k_launches),
                  "milk": (milk_ms, milk_launches), "fexk": (fexk_ms, fexk_launches), "g2_in": g2_in, "g2_sc_h": g2_sc_h, "g2_out": g2_out,
                  "mil": mil, "fex": fex}
@@ -294,6 +407,7 @@ def main():
         mel = timed(lambda: ctx.g1_msm_dev(nm, mp_.data_ptr(), ms_.data_ptr(), mo_.data_ptr(), 96), msteps, 0)
         bk_ms, bk_launches = ctx.profile_read(5)
         ctx.profile(False)
+        probe_clock("msm_bucket_kernel", lambda: ctx.g1_msm_dev(nm, mp_.data_ptr(), ms_.data_ptr(), mo_.data_ptr(), 96))
         msm = {"n": nm, "steps": msteps, "elapsed": mel, "bucket_ms": bk_ms, "bucket_launches": bk_launches, "out": mo_.cpu().numpy().tobytes(),
                "reps": reps, "scalars": ms_h}
         if world > 1:
@@ -359,13 +473,22 @@ def main():
         gamma = reduced_scalars(5102, 1).tobytes()
         w = ctx.g2_mul_fixed(g2p, gamma, 192)
         # strong leg: the job's 2^18 signatures are the same on every rank (seeds without the rank); the weak leg of rank r uses its own
+        def encode_msgs(raw):
+            """encode_to<Zp> (zp_number.hpp:1011-1037) of one unit: 0x01 || message || zero padding as a 32-byte big-endian scalar"""
+            mm = np.zeros((raw.shape[0], 32), dtype=np.uint8)
+            mm[:, 0] = 1
+            mm[:, 1:1 + raw.shape[1]] = raw
+            return mm
+
         def make_sigs(seed, count):
-            xs, rs, mm = reduced_scalars(seed, count), reduced_scalars(seed + 1, count), reduced_scalars(seed + 2, count)
-            A = np.frombuffer(ctx.bbs_plus_sign(pub_g1, pub_h0, pub_h, gamma, xs.tobytes(), rs.tobytes(), mm.tobytes()), dtype=np.uint8).reshape(count, 96).copy()
+            xs, rs = reduced_scalars(seed, count), reduced_scalars(seed + 1, count)
+            raw = np.random.Generator(np.random.PCG64(seed + 2)).integers(0, 256, size=(count, BBS_MSG_LEN), dtype=np.uint8)   # raw messages
+            A = np.frombuffer(ctx.bbs_plus_sign(pub_g1, pub_h0, pub_h, gamma, xs.tobytes(), rs.tobytes(), encode_msgs(raw).tobytes()),
+                              dtype=np.uint8).reshape(count, 96).copy()
             badl = np.arange(7, count, 1009)
-            mm[badl, 31] ^= 1                                          # corrupted message block: exactly these lanes must fail
-            return A, xs, rs, mm, badl
-        A_h, xs_h, rs_h, mm_h, bad_lanes = make_sigs(5200 + 10 * rank, nb)
+            raw[badl, BBS_MSG_LEN - 1] ^= 1                            # corrupted message: exactly these lanes must fail
+            return A, xs, rs, encode_msgs(raw), badl, raw
+        A_h, xs_h, rs_h, mm_h, bad_lanes, raw_h = make_sigs(5200 + 10 * rank, nb)
         dA, dx, dr, dm = (torch.from_numpy(a).to(dev) for a in (A_h, xs_h, rs_h, mm_h))
         dpub = [dev_bytes(b, dev) for b in (pub_g1, g2p, pub_h0, pub_h, w)]
         okb = torch.empty(nb, dtype=torch.uint8, device=dev)
@@ -385,10 +508,39 @@ def main():
         exp_ok = np.ones(nb, dtype=np.uint8); exp_ok[bad_lanes] = 0
         if not (ok_h == exp_ok).all():
             raise SystemExit("bench: BBS+ verdicts differ from the construction (valid signatures / corrupted lanes) — number withheld")
+        probe_clock("pair3_prod_fixed_queue_kernel", bbs_step)
         bbs = {"n": nb, "steps": bsteps, "elapsed": bel, "pair_ms": bpk_ms, "pair_launches": bpk_launches, "A": A_h, "x": xs_h, "r": rs_h, "m": mm_h, "ok": ok_h,
                "pub": (pub_g1, g2p, pub_h0, pub_h, w)}
+        # ---- the same verifications end to end from the wire formats verify() parses (bbs+.cpp:57-73): pp.g1_g2_h0 (49 + 97 + 49 B),
+        # pp.h (49 B each), pk (97 B), signatures A || x || r as 49 + 48 + 48 B, raw messages.  Serialized on the device, untimed.
+        one32 = torch.zeros(nb, 32, dtype=torch.uint8, device=dev); one32[:, 31] = 1
+        A49 = torch.empty(nb * 49, dtype=torch.uint8, device=dev)
+        ctx.g1_mul_flags_dev(nb, dA.data_ptr(), one32.data_ptr(), A49.data_ptr(), 49, 1)           # 1 x A in the compressed form (C12381_F_IN_SUBGROUP)
+        sig = torch.zeros(nb, 145, dtype=torch.uint8, device=dev)
+        ctx.sync()
+        sig[:, 0:49] = A49.view(nb, 49); sig[:, 65:97] = dx.view(nb, 32); sig[:, 113:145] = dr.view(nb, 32)
+        one1 = (1).to_bytes(32, "big")
+        pp195 = ctx.g1_mul(pub_g1, one1, 49) + ctx.g2_mul(g2p, one1, 97) + ctx.g1_mul(pub_h0, one1, 49)
+        h49, pk97 = ctx.g1_mul(pub_h, one1, 49), ctx.g2_mul(w, one1, 97)
+        dwire = [dev_bytes(b, dev) for b in (pp195, h49, pk97)]
+        draw = torch.from_numpy(raw_h).to(dev)
+        okw = torch.empty(nb, dtype=torch.uint8, device=dev)
+        del one32, A49
+
+        def wire_step():
+            ctx.bbs_plus_verify_wire_dev(nb, 1, BBS_MSG_LEN, dwire[0].data_ptr(), dwire[1].data_ptr(), dwire[2].data_ptr(), sig.data_ptr(), draw.data_ptr(),
+                                         okw.data_ptr())
+        wire_step()
+        torch.cuda.synchronize(dev)
+        wel = timed(wire_step, bsteps, 0)
+        ctx.sync()
+        okw_h = okw.cpu().numpy()
+        if not (okw_h == exp_ok).all():
+            raise SystemExit("bench: wire-format BBS+ verdicts differ from the construction (valid signatures / corrupted lanes) — number withheld")
+        bbs["wire"] = {"elapsed": wel, "pp": pp195, "h49": h49, "pk": pk97, "sig": sig.cpu().numpy(), "raw": raw_h, "ok": okw_h}
+        del sig, draw, okw
         if world > 1:
-            gA, gx, gr, gm, gbad = make_sigs(5200, nb) if rank != 0 else (A_h, xs_h, rs_h, mm_h, bad_lanes)
+            gA, gx, gr, gm, gbad = make_sigs(5200, nb)[:5] if rank != 0 else (A_h, xs_h, rs_h, mm_h, bad_lanes)
             lo, hi = shard_bounds(nb, rank, world)
             sA, sx, sr, sm = (torch.from_numpy(np.ascontiguousarray(a[lo:hi])).to(dev) for a in (gA, gx, gr, gm))
             sok = torch.empty(max(hi - lo, 1), dtype=torch.uint8, device=dev)
@@ -430,8 +582,12 @@ def main():
 
     # ================================================================== parity and CPU baselines (outside every timed region)
     from oracle.bindings import Oracle, have_reference
+    # the compiled reference when it travelled with the snapshot (oracle/_ref), else the C port — said on every parity object, never silent
     kind = "reference" if have_reference() else "port"
+    pinned = kind == "reference"
     orc = Oracle(kind)
+    if rank == 0 and not pinned:
+        print("bench.py: oracle/_ref/libc12381_ref.so is absent: parity is checked against the C port (parity.pinned = false)", file=sys.stderr, flush=True)
     cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)   # the GPU box gives one GPU a 16-CPU share
     do_cpu = world == 1 and not args.no_cpu_baseline
     pts_h = pts.cpu().numpy().reshape(n, 96)
@@ -442,6 +598,11 @@ def main():
     if exp != out_h[idx].tobytes():
         raise SystemExit("bench: GPU results differ from the CPU oracle — number withheld")
     g1_checked = len(idx)
+
+    def par(**kw):
+        d = {"oracle": kind, "pinned": pinned, "bit_exact": True}
+        d.update(kw)
+        return d
 
     result = None
     if rank == 0:
@@ -472,33 +633,25 @@ def main():
         except Exception:
             issue_json = {}
 
-        def hbm(bytes_per_unit, units, secs, kernel, tr=None, **more):
-            a = bytes_per_unit * units / secs / 1e9
-            d = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": tr, "kernel": kernel,
-                 "avg_launch_ms": secs * 1e3}
-            d.update(more)
-            return d
-
-        def valu(mac_per_unit, units, secs, kernel=None, tr=None, **more):
-            """the binding roofline: algorithmic multiply-adds per launch / average launch time against the measured multiply-add rate"""
+        def valu(mac_per_unit, units, secs, kernel, tr=None, nbytes=None, clock_key=None, head=False, **more):
+            """the binding roofline: algorithmic multiply-adds per launch / average launch time against the measured multiply-add rate;
+            `hbm` beside it = algorithmic bytes / the same time against 8 TB/s (evidence that the path is not memory bound)"""
             a = mac_per_unit * units / secs
-            d = {"bound": "int-valu", "achieved": a / 1e9, "peak": VALU_PEAK_MAC32 / 1e9, "peak_theoretical": VALU_PEAK_THEORETICAL_MAC32 / 1e9,
-                 "unit": "GMAC32/s", "frac": a / VALU_PEAK_MAC32, "frac_of_theoretical": a / VALU_PEAK_THEORETICAL_MAC32,
-                 "frac_vs_round2_peak": a / VALU_PEAK_MAC32_R02, "traffic": tr,
-                 "algorithmic_mac32_per_unit": mac_per_unit, "avg_launch_ms": secs * 1e3}
-            if kernel:
-                d["kernel"] = kernel
-                ik = issue_json.get("kernels", {}).get(kernel.split(" ")[-1])          # "... dominant kernel <name>" for the BBS+ pipeline
-                if ik:
-                    insts = ik["valu_insts_per_launch"] * units / ik["units_per_launch"]
-                    bound_s = insts * VALU_ISSUE_CYCLES / 1024 / (ik["clock_GHz"] * 1e9)
-                    d["issue"] = {"valu_insts_per_launch": insts, "cycles_per_inst": VALU_ISSUE_CYCLES, "clock_GHz": ik["clock_GHz"],
-                                  "issue_time_ms": bound_s * 1e3, "issue_time_over_launch_time": bound_s / secs,
-                                  "multiply_add_share_of_insts": mac_per_unit * units / 64 / insts,
-                                  "note": "issue time = the launch's vector instructions x 4.06 cycles / 1024 SIMDs / clock: one vector instruction per 4.06 "
-                                          "cycles and SIMD whatever it is (profiles/r03_issue_mix.txt).  insts and clock come from profiles/issue.json "
-                                          "(counter pass and clock probe of the same build), not from this run; the probe's median clock is good to "
-                                          "about +-3 %, so a ratio of 1.0 +- 0.03 reads 'at the issue rate'"}
+            # the legs' objects leave out what the headline's states once: bound int-valu, peak, unit GMAC32/s
+            d = {"bound": "int-valu", "kernel": kernel, "achieved": a / 1e9, "peak": VALU_PEAK_MAC32 / 1e9, "unit": "GMAC32/s"} if head else {"kernel": kernel, "achieved": a / 1e9}
+            d.update({"frac": a / VALU_PEAK_MAC32, "traffic": tr, "avg_launch_ms": secs * 1e3, "mac32_per_unit": mac_per_unit})
+            if nbytes is not None:
+                g = nbytes * units / secs / 1e9
+                d["hbm_GBs"] = g                                   # algorithmic bytes / the same time; HBM peak 8000 GB/s
+            ik = issue_json.get("kernels", {}).get(kernel)
+            clk = clocks.get(clock_key or kernel)
+            if ik and clk:
+                insts = ik["valu_insts_per_launch"] * units / ik["units_per_launch"]
+                bound_s = insts * VALU_ISSUE_CYCLES / 1024 / (clk * 1e9)
+                d["issue"] = {"valu_insts": insts, "clock_GHz_in_run": clk, "issue_ms": bound_s * 1e3, "issue_over_launch": bound_s / secs,
+                              "mad_share": mac_per_unit * units / 64 / insts}
+            elif ik:
+                d["issue"] = {"valu_insts": ik["valu_insts_per_launch"] * units / ik["units_per_launch"], "clock_GHz_in_run": None}
             d.update(more)
             return d
         result = {
@@ -506,12 +659,11 @@ def main():
             "value": value, "unit": "scalar-muls/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "rccl_ranks": (dist.get_world_size() if dist else 1),
             "vs_baseline": None, "dtype": "int64 accumulate over 14x28-bit signed limbs", "data": "synthetic",
-            "config": {"workload": "configs[1]: batch of 2^%d random G1 scalar-muls (96-B affine in, 32-B scalar, 96-B affine out) per GPU"
-                                   % args.log2_batch, "batch_per_gpu": n, "parallelism": "independent shards x%d" % world},
-            "roofline": valu(MAC32_G1_MUL, units_per_launch, avg_launch_s, "g1_mul_kernel", traffic, launches=int(mul_launches),
-                             units_per_launch=units_per_launch, finish_kernel_ms_per_step=fin_ms / max(args.steps, 1)),
-            "hbm_roofline": hbm(BYTES_G1_MUL, units_per_launch, avg_launch_s, "g1_mul_kernel", traffic,
-                                note="not the binding bound: the path is integer-VALU bound (roofline)"),
+            "config": {"workload": "configs[1]: 2^%d random G1 scalar-muls (96-B affine in, 32-B scalar, 96-B affine out) per GPU" % args.log2_batch,
+                       "batch_per_gpu": n, "parallelism": "independent shards x%d" % world},
+            "roofline": valu(MAC32_G1_MUL, units_per_launch, avg_launch_s, "g1_mul_kernel", traffic, BYTES_G1_MUL, head=True, launches=int(mul_launches),
+                             units_per_launch=units_per_launch, finish_kernel_ms_per_step=fin_ms / max(args.steps, 1),
+                             peak_theoretical=VALU_PEAK_THEORETICAL_MAC32 / 1e9),
         }
         if do_cpu:
             sample = min(n, 1 << 16)
@@ -526,11 +678,52 @@ def main():
                 raise SystemExit("bench: CPU baseline output differs from the GPU output")
             g1_checked = sample + len(idx)
             result["cpu_baseline"] = {"value": sample / cpu_s, "unit": "scalar-muls/s", "cores": cores, "kind": kind,
-                                      "sample": "first %d lanes of the same batch, %d threads; full compare with GPU output bit-exact" % (sample, cores),
+                                      "sample": "first %d lanes; every lane equal to the GPU output" % sample,
                                       "single_thread_value": 2048 / cpu1_s}
-        result["parity"] = {"checked_lanes": g1_checked, "oracle": kind, "bit_exact": True}
+        result["parity"] = par(checked_lanes=g1_checked)
 
-        # ---------------------------------------------------------------- pairing
+        def cpu_b(v, unit, sample):
+            return {"value": v, "cores": cores, "kind": kind, "sample": sample}      # unit = the leg's unit
+
+        # ---------------------------------------------------------------- MSM
+        if msm is not None:
+            nm = msm["n"]
+            # full-size parity: every P_i = G^{s_i}, so the product is G^(sum s_i k_i) — one oracle multiplication
+            s_full = np.tile(base_sc_h, (msm["reps"], 1))[:nm]
+            # lanes 0..4 of base_sc are edge values (0, 1, r-1, r, 2^256-1): the exponent sum works mod r for all of them
+            e = sum_of_products_mod_r(s_full, msm["scalars"])
+            if orc.g1_mul(G1_GEN, e.to_bytes(32, "big"), 96, 1) != msm["out"]:
+                raise SystemExit("bench: MSM result differs from G^(sum s_i k_i) (CPU oracle) — number withheld")
+            per = msm["elapsed"] / msm["steps"]
+            bk_s = msm["bucket_ms"] / max(msm["bucket_launches"], 1) * 1e-3
+            result["msm"] = {
+                "metric": "G1 multi-scalar product terms/s (one product of 2^%d terms per GPU)" % args.log2_msm,
+                "value": world * nm / per, "unit": "terms/s", "steps": msm["steps"], "ms_per_step": per * 1e3,
+                "workload": "configs[3]",
+                "parity": par(check="result == G^(sum s_i k_i) over ALL terms"),
+                # dominant kernel alone, then the whole product (sorts, preparation, reductions included) against the same peak
+                "roofline": valu(MAC32_MSM_TERM, nm, bk_s, "msm_bucket_kernel", msm_traffic, BYTES_MSM_TERM),
+                "roofline_whole_step": {"frac": MAC32_MSM_TERM * nm / per / VALU_PEAK_MAC32, "achieved": MAC32_MSM_TERM * nm / per / 1e9},
+            }
+            if do_cpu:
+                sm = 1 << 14
+                t7 = time.perf_counter()
+                cpu_m = orc.g1_msm(pts_h[:sm].tobytes(), msm["scalars"][:sm].tobytes(), 96, cores)
+                cm_s = time.perf_counter() - t7
+                if cpu_m != ctx.g1_msm(pts_h[:sm].tobytes(), msm["scalars"][:sm].tobytes(), 96):
+                    raise SystemExit("bench: CPU MSM baseline differs from the GPU product of the same sample")
+                result["msm"]["cpu_baseline"] = cpu_b(sm / cm_s, "terms/s", "first 2^14 terms as the reference evaluates the product; equals the GPU's")
+            if "sharded" in msm:
+                sh = msm["sharded"]
+                if not sh["same_on_every_rank"] or sh["equals_single_gpu"] is False:
+                    raise SystemExit("bench: sharded MSM results disagree (ranks or single-GPU value) — number withheld")
+                result["msm_sharded"] = {"metric": "G1 multi-scalar product terms/s, ONE product of 2^%d terms over %d GPUs" % (args.log2_msm, world),
+                                         "value": nm * sh["steps"] / sh["elapsed"], "unit": "terms/s", "scaling": "strong", "steps": sh["steps"],
+                                         "ms_per_step": sh["elapsed"] / sh["steps"] * 1e3, "rccl_ranks": sh["rccl_ranks"], "backend": sh["backend"],
+                                         "exchange": "all_gather of 96 B per rank + local sum",
+                                         "same_on_every_rank": True, "equals_single_gpu": sh["equals_single_gpu"]}
+
+        # ---------------------------------------------------------------- pairing parity first (the split legs compare with its output)
         if pair is not None:
             npair = pair["npair"]
             p1_h = pair["p1"].cpu().numpy().reshape(npair, 96)
@@ -554,21 +747,6 @@ def main():
                 if cpu_gt != gt_h[pidx].tobytes():
                     raise SystemExit("bench: GPU pairing results differ from the CPU oracle — number withheld")
                 checked, ps = len(pidx), len(pidx)
-            avg_s = pair["kernel_ms"] / max(pair["launches"], 1) * 1e-3
-            kname = "pair3_queue_kernel" if (npair + 20) // 21 > 2048 else "pair3_kernel"
-            result["pairing"] = {
-                "metric": "ate pairings/s per MI355X (batch 2^%d per GPU), bit-exact vs CPU" % args.log2_pairings,
-                "value": world * npair * pair["steps"] / pair["elapsed"], "unit": "pairings/s", "steps": pair["steps"],
-                "ms_per_step": pair["elapsed"] / pair["steps"] * 1e3,
-                "config": {"workload": "configs[2]: 2^%d pairings e(P_i, Q_i) -> 576-B GT each, per GPU" % args.log2_pairings},
-                "parity": {"checked_lanes": checked, "of": npair, "oracle": kind, "bit_exact": True},
-                "roofline": valu(MAC32_PAIRING, npair, avg_s, kname, pair_traffic),
-                "hbm_roofline": hbm(BYTES_PAIRING, npair, avg_s, kname, pair_traffic),
-            }
-            if do_cpu:
-                result["pairing"]["cpu_baseline"] = {"value": ps / cpu_ps, "unit": "pairings/s", "cores": cores, "kind": kind,
-                                                     "sample": ("the whole batch of %d pairings, %d threads; every lane bit-exact vs GPU" % (ps, cores)) if full
-                                                     else "%d sampled lanes" % ps}
 
         # ---------------------------------------------------------------- G2 multiplication, Miller loop, final exponentiation alone
         if split is not None:
@@ -588,93 +766,54 @@ def main():
                 raise SystemExit("bench: GPU Miller values differ from the CPU oracle — number withheld")
             if f_cpu != fex_h[:ns].tobytes() or not (fex_h == gt_h).all():
                 raise SystemExit("bench: GPU final exponentiations differ from the CPU oracle / the pairing outputs — number withheld")
+            queued = (npair + 20) // 21 > 2048
 
-            def leg(metric, unit, units, el, kprof, mac, nbytes, kernel, workload, parity, cpu_s, tr=None):
+            def leg(metric, unit, units, el, kprof, mac, nbytes, kernel, workload, parity, cpu_s, tr=None, clock_key=None):
                 k_s = kprof[0] / max(kprof[1], 1) * 1e-3
-                launches_per_step = kprof[1] / max(st, 1)
+                lps = max(kprof[1] / max(st, 1), 1)
                 d = {"metric": metric, "value": world * units * st / el, "unit": unit, "steps": st, "ms_per_step": el / st * 1e3,
-                     "config": {"workload": workload}, "parity": parity,
-                     "roofline": valu(mac, units / max(launches_per_step, 1), k_s, kernel, tr, launches_per_step=launches_per_step,
-                                      units_per_launch=units / max(launches_per_step, 1)),
-                     "hbm_roofline": hbm(nbytes, units / max(launches_per_step, 1), k_s, kernel, tr)}
+                     "workload": workload, "parity": parity,
+                     "roofline": valu(mac, units / lps, k_s, kernel, tr, nbytes, clock_key, units_per_launch=units / lps)}
                 if do_cpu:
-                    d["cpu_baseline"] = {"value": ns / cpu_s, "unit": unit, "cores": cores, "kind": kind, "sample": "first %d lanes of the same batch, %d threads" % (ns, cores)}
+                    d["cpu_baseline"] = cpu_b(ns / cpu_s, unit, "first %d lanes of the same batch" % ns)
                 return d
             result["g2_mul"] = leg("G2 scalar-muls/s per MI355X (batch 2^%d per GPU), bit-exact vs CPU" % args.log2_g2, "scalar-muls/s", ng2, split["g2_el"],
                                    split["g2k"], MAC32_G2_MUL, BYTES_G2_MUL, "g2_mul2_kernel",
-                                   "PAIR_G2mul: 2^%d random (point, scalar) pairs, 192-B affine in / out, 32-B scalars (edge scalars in lanes 0..4)" % args.log2_g2,
-                                   {"checked_lanes": ns, "of": ng2, "oracle": kind, "bit_exact": True}, g2_s,
+                                   "PAIR_G2mul, 192-B affine in/out, edge scalars in lanes 0..4",
+                                   par(checked_lanes=ns, of=ng2), g2_s,
                                    None if g2_traffic is None else g2_traffic * ng2 / max(split["g2k"][1] / max(st, 1), 1))
             result["miller"] = leg("Miller loops/s per MI355X (batch 2^%d per GPU), the reference's field element" % args.log2_pairings, "Miller loops/s", npair,
-                                   split["mil_el"], split["milk"], MAC32_MILLER, 96 + 192 + 576, "miller3_queue_kernel" if (npair + 20) // 21 > 2048 else "miller3_kernel",
-                                   "PAIR_ate: the 2^%d (P_i, Q_i) of the pairing leg -> 576-B Miller value each" % args.log2_pairings,
-                                   {"checked_lanes": ns, "of": npair, "oracle": kind, "bit_exact": True}, mil_s)
+                                   split["mil_el"], split["milk"], MAC32_MILLER, 96 + 192 + 576, "miller3_queue_kernel" if queued else "miller3_kernel",
+                                   "PAIR_ate on the pairing leg's inputs", par(checked_lanes=ns, of=npair), mil_s, None, "miller")
             result["fexp"] = leg("final exponentiations/s per MI355X (batch 2^%d per GPU)" % args.log2_pairings, "final exponentiations/s", npair,
-                                 split["fex_el"], split["fexk"], MAC32_FEXP, 2 * 576, "fexp3_queue_kernel" if (npair + 20) // 21 > 2048 else "gt3_op_kernel",
-                                 "PAIR_fexp: the 2^%d Miller values above -> canonical GT" % args.log2_pairings,
-                                 {"checked_lanes": npair, "of": npair, "oracle": "%s on %d lanes + every lane equal to the pairing leg's output" % (kind, ns), "bit_exact": True}, fx_s)
+                                 split["fex_el"], split["fexk"], MAC32_FEXP, 2 * 576, "fexp3_queue_kernel" if queued else "gt3_op_kernel",
+                                 "PAIR_fexp on those Miller values",
+                                 par(checked_lanes=ns, of=npair, check="+ every lane equals the pairing leg's output"), fx_s, None, "fexp")
 
-
-        # ---------------------------------------------------------------- MSM
-        if msm is not None:
-            nm = msm["n"]
-            # full-size parity: every P_i = G^{s_i}, so the product is G^(sum s_i k_i) — one oracle multiplication
-            s_full = np.tile(base_sc_h, (msm["reps"], 1))[:nm]
-            # lanes 0..4 of base_sc are edge values (0, 1, r-1, r, 2^256-1): the exponent sum works mod r for all of them
-            e = sum_of_products_mod_r(s_full, msm["scalars"])
-            if orc.g1_mul(G1_GEN, e.to_bytes(32, "big"), 96, 1) != msm["out"]:
-                raise SystemExit("bench: MSM result differs from G^(sum s_i k_i) (CPU oracle) — number withheld")
-            per = msm["elapsed"] / msm["steps"]
-            bk_s = msm["bucket_ms"] / max(msm["bucket_launches"], 1) * 1e-3
-            result["msm"] = {
-                "metric": "G1 multi-scalar product terms/s (one product of 2^%d terms per GPU)" % args.log2_msm,
-                "value": world * nm / per, "unit": "terms/s", "steps": msm["steps"], "ms_per_step": per * 1e3,
-                "config": {"workload": "configs[3]: Π g_i^{x_i}, n = 2^%d (96-B affine points, 32-B scalars -> one 96-B point), per GPU" % args.log2_msm},
-                "parity": {"check": "result == G^(sum s_i k_i mod r) by one oracle multiplication over ALL 2^%d terms" % args.log2_msm, "oracle": kind, "bit_exact": True},
-                # dominant kernel alone, then the whole product (sorts, preparation, reductions included) against the same peak
-                "roofline": valu(MAC32_MSM_TERM, nm, bk_s, "msm_bucket_kernel", msm_traffic,
-                                 note="actual count of the bucket method as built: 16 mixed additions (11 products + 8 reductions) per term"),
-                "roofline_whole_step": valu(MAC32_MSM_TERM, nm, per, "c12381_g1_msm_dev: prep + sorts + buckets + reductions + Horner + affine"),
-                "hbm_roofline": hbm(BYTES_MSM_TERM, nm, bk_s, "msm_bucket_kernel", msm_traffic),
-            }
-            if do_cpu:
-                sm = 1 << 14
-                t7 = time.perf_counter()
-                cpu_m = orc.g1_msm(pts_h[:sm].tobytes(), msm["scalars"][:sm].tobytes(), 96, cores)
-                cm_s = time.perf_counter() - t7
-                if cpu_m != ctx.g1_msm(pts_h[:sm].tobytes(), msm["scalars"][:sm].tobytes(), 96):
-                    raise SystemExit("bench: CPU MSM baseline differs from the GPU product of the same sample")
-                result["msm"]["cpu_baseline"] = {"value": sm / cm_s, "unit": "terms/s", "cores": cores, "kind": kind,
-                                                 "sample": "first 2^14 terms as the reference evaluates Π (n scalar multiplications + additions, g1_point.hpp:371-404), "
-                                                           "%d threads; equals the GPU product of the same terms" % cores}
-            if "sharded" in msm:
-                sh = msm["sharded"]
-                if not sh["same_on_every_rank"] or sh["equals_single_gpu"] is False:
-                    raise SystemExit("bench: sharded MSM results disagree (ranks or single-GPU value) — number withheld")
-                result["msm_sharded"] = {"metric": "G1 multi-scalar product terms/s, ONE product of 2^%d terms over %d GPUs" % (args.log2_msm, world),
-                                         "value": nm * sh["steps"] / sh["elapsed"], "unit": "terms/s", "scaling": "strong", "steps": sh["steps"],
-                                         "ms_per_step": sh["elapsed"] / sh["steps"] * 1e3, "rccl_ranks": sh["rccl_ranks"], "backend": sh["backend"],
-                                         "exchange": "all_gather of 96 B per rank (device tensors) + local sum of the %d partial points on every rank (c12381_g1_sum_dev)" % world,
-                                         "same_on_every_rank": True, "equals_single_gpu": sh["equals_single_gpu"]}
-
-        # ---------------------------------------------------------------- BBS+
+        # ---------------------------------------------------------------- BBS+ (decoded inputs, then the wire formats end to end)
         if bbs is not None:
             nb = bbs["n"]
             per = bbs["elapsed"] / bbs["steps"]
             result["bbs_plus"] = {
-                "metric": "BBS+ signature verifications/s (2^%d per GPU, 1 message block)" % args.log2_bbs,
+                "metric": "BBS+ signature verifications/s (2^%d per GPU, 1 message block), decoded inputs" % args.log2_bbs,
                 "value": world * nb / per, "unit": "verifications/s", "steps": bbs["steps"], "ms_per_step": per * 1e3,
-                "config": {"workload": "configs[4]: 2^%d verifications e(A, w g2^x) == e(g1 h0^r h1^m, g2), real signatures, every 1009th message corrupted" % args.log2_bbs},
-                "parity": {"check": "all %d verdicts equal the construction (valid / corrupted lanes)" % nb, "bit_exact": True},
-                # the pipeline's OWN operation sequence (x A generic, r h0 and m h1 from tables, two-table product of pairings, one final
-                # exponentiation: tools/count_ops.py -> profiles/r03_op_counts.json) over the wall time of the whole pipeline
-                "roofline": valu(MAC32_BBS_PIPELINE, nb, per, "whole pipeline (c12381_bbs_plus_verify_batch_dev); dominant kernel pair3_prod_fixed_queue_kernel",
-                                 bbs_traffic, pair_kernel_avg_ms=bbs["pair_ms"] / max(bbs["pair_launches"], 1)),
-                "hbm_roofline": hbm(BYTES_BBS_VERIFY, nb, per, "whole pipeline", bbs_traffic),
-                "reference_sequence_equivalent": {"mac32_per_unit": MAC32_BBS_VERIFY, "gmac32_per_s": MAC32_BBS_VERIFY * nb / per / 1e9,
-                                                  "note": "NOT a utilisation figure: the reference's operation sequence (bbs+.cpp:57-73: generic G2 mul, two generic "
-                                                          "G1 muls, two Miller loops with running G2 points, one final exponentiation) per verification over this "
-                                                          "pipeline's wall time"},
+                "workload": "configs[4]: real signatures, every 1009th message corrupted",
+                "parity": {"check": "all verdicts equal the construction", "bit_exact": True},
+                # the pipeline's OWN operation sequence (tools/count_ops.py -> profiles/r03_op_counts.json) over the wall time of the whole pipeline
+                "roofline": valu(MAC32_BBS_PIPELINE, nb, per, "pair3_prod_fixed_queue_kernel", bbs_traffic, BYTES_BBS_VERIFY,
+                                 pair_kernel_avg_ms=bbs["pair_ms"] / max(bbs["pair_launches"], 1), time_base="whole pipeline"),
+                "reference_sequence_gmac32_per_s": MAC32_BBS_VERIFY * nb / per / 1e9,
+            }
+            wr = bbs["wire"]
+            wper = wr["elapsed"] / bbs["steps"]
+            result["bbs_plus_wire"] = {
+                "metric": "BBS+ verifications/s END TO END from wire formats (2^%d per GPU: 145-B signatures, %d-B raw messages)" % (args.log2_bbs, BBS_MSG_LEN),
+                "value": world * nb / wper, "unit": "verifications/s", "steps": bbs["steps"], "ms_per_step": wper * 1e3,
+                "workload": "configs[4] through verify()'s own input forms (bbs+.cpp:57-73: parse<G1,Zp,Zp>, parse<G1,G2,G1>, parse<G2>, encode_to<Zp>)",
+                "parity": {"check": "all verdicts equal the construction", "bit_exact": True},
+                "roofline": {"kernel": "whole pipeline", "achieved": MAC32_BBS_WIRE_PIPELINE * nb / wper / 1e9,
+                             "frac": MAC32_BBS_WIRE_PIPELINE * nb / wper / VALU_PEAK_MAC32, "traffic": None,
+                             "mac32_per_unit": MAC32_BBS_WIRE_PIPELINE, "hbm_GBs": BYTES_BBS_WIRE * nb / wper / 1e9},
             }
             if do_cpu:
                 sb = 1 << 11
@@ -686,11 +825,15 @@ def main():
                 cb_s = time.perf_counter() - t8
                 if cpu_ok != bbs["ok"][sl].tobytes():
                     raise SystemExit("bench: CPU BBS+ verdicts differ from the GPU verdicts")
-                result["bbs_plus"]["parity"]["oracle_lanes"] = int(len(sl))
-                result["bbs_plus"]["parity"]["oracle"] = kind
-                result["bbs_plus"]["cpu_baseline"] = {"value": len(sl) / cb_s, "unit": "verifications/s", "cores": cores, "kind": kind,
-                                                      "sample": "%d signatures (incl. corrupted lanes) through the reference's op sequence bbs+.cpp:57-73, %d threads; "
-                                                                "verdicts equal the GPU's" % (len(sl), cores)}
+                result["bbs_plus"]["parity"].update(par(oracle_lanes=int(len(sl))))
+                result["bbs_plus"]["cpu_baseline"] = cpu_b(len(sl) / cb_s, "verifications/s", "%d signatures incl. corrupted ones, bbs+.cpp:57-73 on decoded inputs; verdicts equal the GPU's" % len(sl))
+                t9 = time.perf_counter()
+                cpu_okw = orc.bbs_plus_verify_wire(wr["pp"], wr["h49"], wr["pk"], wr["sig"][sl].tobytes(), wr["raw"][sl].tobytes(), BBS_MSG_LEN, cores)
+                cw_s = time.perf_counter() - t9
+                if cpu_okw != wr["ok"][sl].tobytes():
+                    raise SystemExit("bench: CPU wire-format BBS+ verdicts differ from the GPU verdicts")
+                result["bbs_plus_wire"]["parity"].update(par(oracle_lanes=int(len(sl))))
+                result["bbs_plus_wire"]["cpu_baseline"] = cpu_b(len(sl) / cw_s, "verifications/s", "the same %d signatures from the same bytes (from_bytes + encode + op sequence); verdicts equal the GPU's" % len(sl))
             if "sharded" in bbs:
                 sh = bbs["sharded"]
                 if sh["accepted"] != sh["expected_accepted"]:
@@ -698,10 +841,36 @@ def main():
                 result["bbs_plus_sharded"] = {"metric": "BBS+ verifications/s, 2^%d signatures split over %d GPUs" % (args.log2_bbs, world),
                                               "value": nb * sh["steps"] / sh["elapsed"], "unit": "verifications/s", "scaling": "strong", "steps": sh["steps"],
                                               "ms_per_step": sh["elapsed"] / sh["steps"] * 1e3, "accepted": sh["accepted"],
-                                              "exchange": "none on the data path (independent units)"}
+                                              "exchange": "none"}
         if extras:
             result["extra_configs"] = extras
-        print(json.dumps(result), flush=True)
+        result["notes"] = {
+            "roofline": "int-valu binds: algorithmic 32x32 multiply-adds (SURVEY 8(d)) / avg launch time (HIP events on the library's stream) vs the "
+                        "v_mad_i64_i32 issue rate measured in-kernel (62.06 lanes/clk/CU x 256 CUs x 2.4 GHz; theoretical 64); hbm_GBs = algorithmic "
+                        "bytes / same time (peak 8000); traffic = FETCH_SIZE x2 + WRITE_SIZE passes (profiles/traffic.json)",
+            "issue": "issue_ms = VALU instructions per launch (SQ_INSTS_VALU pass of this build, profiles/issue.json) x 4.06 cycles / 1024 SIMDs / "
+                     "the clock held inside the kernel in THIS run (one-lane probe, median)",
+            "bbs_plus": "MAC32 = the pipeline's own op sequence (wire leg: + decode of A); reference_sequence_gmac32_per_s prices the reference's "
+                        "sequence over this wall time, not a utilisation",
+            "cpu_baseline": "%s, %d host threads of this box, same inputs" % ("oracle/_ref = the reference's sources compiled here" if pinned else "C port (oracle/_ref absent)", cores),
+        }
+        # the pairing leg goes LAST: the second half of BASELINE's metric survives any truncation of the line's head
+        if pair is not None:
+            avg_s = pair["kernel_ms"] / max(pair["launches"], 1) * 1e-3
+            kname = "pair3_queue_kernel" if (npair + 20) // 21 > 2048 else "pair3_kernel"
+            result["pairing"] = {
+                "metric": "ate pairings/s per MI355X (batch 2^%d per GPU), bit-exact vs CPU" % args.log2_pairings,
+                "value": world * npair * pair["steps"] / pair["elapsed"], "unit": "pairings/s", "steps": pair["steps"],
+                "ms_per_step": pair["elapsed"] / pair["steps"] * 1e3,
+                "workload": "configs[2]: 2^%d pairings e(P_i, Q_i) -> 576-B GT each, per GPU" % args.log2_pairings,
+                "parity": par(checked_lanes=checked, of=npair),
+                "roofline": valu(MAC32_PAIRING, npair, avg_s, kname, pair_traffic, BYTES_PAIRING, "pair", head=True),
+            }
+            if do_cpu:
+                result["pairing"]["cpu_baseline"] = cpu_b(ps / cpu_ps, "pairings/s", ("the whole batch of %d pairings; every lane bit-exact vs GPU" % ps) if full
+                                                          else "%d sampled lanes" % ps)
+        line = json.dumps(compact(result), separators=(",", ":"))
+        print(line, flush=True)
     if dist:
         dist.barrier()
     ctx.close()

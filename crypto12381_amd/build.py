@@ -1,6 +1,7 @@
 """Build the HIP shared libraries in-tree for gfx950.
 
     crypto12381_amd/lib/libc12381_hip.so       the product: one code path, reads no environment variable
+    crypto12381_amd/lib/libc12381_probe.so     bench-only clock probe (csrc/microbench/clock_probe.hip), loaded by bench.py alone
     crypto12381_amd/lib/libc12381_hip_exp.so   the same sources with -DC12381_EXPERIMENTS: tuning / diagnostic switches (C12381_*
                                                environment variables) and the superseded one-lane pairing kernels, for tools/, A/B
                                                runs and tests/test_gpu_variants.py (selected with C12381_LIB in the Python binding)
@@ -22,6 +23,9 @@ UNITS = ["c12381_hip.hip", "k_g1.hip", "k_g2gt.hip", "k_g2h.hip", "k_pair3.hip",
 EXP_UNITS = ["c12381_hip.hip", "k_g2gt.hip"]                # the units that test C12381_EXPERIMENTS
 LIB = os.path.join(HERE, "lib", "libc12381_hip.so")
 LIB_EXP = os.path.join(HERE, "lib", "libc12381_hip_exp.so")
+# bench-only: the one-lane clock probe bench.py runs beside each dominant kernel (csrc/microbench/clock_probe.hip); not linked into the product
+LIB_PROBE = os.path.join(HERE, "lib", "libc12381_probe.so")
+PROBE_SRC = os.path.join(CSRC, "microbench", "clock_probe.hip")
 OBJ = os.path.join(HERE, "lib", "obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-optimize-sibling-calls: LLVM drops the "callee saves nothing" treatment of an internal function as soon as one
@@ -109,11 +113,11 @@ def _jobs():
 def needs_build() -> bool:
     if _hipcc_version() is None:
         # no compiler here: prebuilt libraries are taken as they are (they were stamped where they were built); missing ones are an error
-        if os.path.exists(LIB) and os.path.exists(LIB_EXP):
+        if os.path.exists(LIB) and os.path.exists(LIB_EXP) and os.path.exists(LIB_PROBE):
             return False
         raise RuntimeError("crypto12381_amd.build: %s not found and no prebuilt %s — build the library where hipcc is available" % (HIPCC, LIB))
     srcs = _headers() + [os.path.join(CSRC, u) for u in UNITS]
-    return (_stale(LIB, srcs) or _stale(LIB_EXP, srcs)
+    return (_stale(LIB, srcs) or _stale(LIB_EXP, srcs) or _stale(LIB_PROBE, [PROBE_SRC])
             or not all(_stamp_ok(u, e) and os.path.exists(os.path.join(OBJ, _obj_name(u, e) + ".o")) for u, e in _jobs()))
 
 
@@ -148,6 +152,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
         for lib, exp in ((LIB, False), (LIB_EXP, True)):
             link = [objs[(u, exp and u in EXP_UNITS)] for u in UNITS]
             cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *link]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+        if force or _stale(LIB_PROBE, [PROBE_SRC]):
+            cmd = [HIPCC, "-O2", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PROBE, PROBE_SRC]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)

@@ -9,7 +9,10 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("C12381_LIB") or os.path.join(_HERE, "lib", "libc12381_hip.so")   # C12381_LIB: A/B builds of the same ABI
+LIB_PATH = os.path.join(_HERE, "lib", "libc12381_hip.so")
+# The binding reads NO environment variable.  Tools, A/B runs and the variant tests that need another build of the same ABI (the
+# experiments library, tools/build_variant.sh outputs) say so explicitly with use_library(path) before the first Context — see
+# tools/libsel.py, which is where their C12381_LIB convention lives now.
 
 E_ARG, E_HIP, E_POINT, E_NOMEM, E_INTERNAL = -1, -2, -3, -4, -5
 F_IN_SUBGROUP = 1
@@ -24,17 +27,26 @@ class C12381Error(RuntimeError):
 
 
 _lib = None
+_lib_path = LIB_PATH
+
+
+def use_library(path: str) -> None:
+    """Select another build of the same C ABI (experiments / A-B library) for this process; must precede the first load."""
+    global _lib_path
+    if _lib is not None and os.path.abspath(path) != os.path.abspath(_lib_path):
+        raise RuntimeError("use_library(%s): %s is already loaded in this process" % (path, _lib_path))
+    _lib_path = path
 
 
 def load_library() -> ctypes.CDLL:
     """Load libc12381_hip.so (built by crypto12381_amd.build / __graft_entry__.build)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        if not os.path.exists(_lib_path):
             raise FileNotFoundError(
-                f"{LIB_PATH} not found: the HIP extension is not built (run `python -m crypto12381_amd.build`). "
+                f"{_lib_path} not found: the HIP extension is not built (run `python -m crypto12381_amd.build`). "
                 "There is no CPU fallback.")
-        lib = ctypes.CDLL(LIB_PATH)
+        lib = ctypes.CDLL(_lib_path)
         vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
         lib.c12381_create.argtypes = [ci, ctypes.POINTER(vp)]
         lib.c12381_destroy.argtypes = [vp]

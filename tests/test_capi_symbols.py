@@ -54,3 +54,19 @@ def test_profile_metadata_the_bench_line_reads():
         # the issue time of the counter pass's launch is a plausible kernel time (0.5 ms .. 100 ms)
         ms = k["valu_insts_per_launch"] * i["cycles_per_valu_inst"] / i["simds"] / (k["clock_GHz"] * 1e9) * 1e3
         assert 0.5 < ms < 100, (kern, ms)
+
+
+def test_bench_gpus_flag_without_a_gpu():
+    """No compute here (there is no GPU): `bench.py --gpus 2` started plainly must turn into the launcher of two ranks — each of which then
+    stops for want of a HIP device — and under a launcher whose world size contradicts --gpus it must refuse before doing anything."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert "starting 2 ranks" in r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and r.stderr.count("needs a HIP device") >= 2, r.stderr[-2000:]
+    env.update({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "refusing" in r.stderr + r.stdout

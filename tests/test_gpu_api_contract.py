@@ -183,6 +183,7 @@ def test_two_host_threads_two_contexts():
 POISON_CODE = r"""
 import ctypes, sys
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+import tools.libsel  # C12381_LIB -> capi.use_library
 from util import cat, golden
 from crypto12381_amd import Context
 from crypto12381_amd.capi import _p, E_INTERNAL

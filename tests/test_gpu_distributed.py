@@ -91,6 +91,7 @@ def test_msm_in_parts(oracle_port):
     import sys
     code = (
         "import sys; sys.path.insert(0, 'tests'); sys.path.insert(0, '.')\n"
+        "import tools.libsel\n"
         "from util import golden, scalars\n"
         "from crypto12381_amd import Context\n"
         "g1 = bytes.fromhex(golden('g1')['generator']); n = 11000\n"
@@ -115,6 +116,7 @@ def test_msm_in_parts(oracle_port):
 RCCL_CODE = r"""
 import os, sys
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+import tools.libsel  # C12381_LIB -> capi.use_library
 import torch
 import torch.distributed as dist
 from util import golden, scalars
@@ -185,3 +187,33 @@ def test_bench_two_ranks_on_one_gpu_dry_run():
     for leg in ("pairing", "g2_mul", "miller", "fexp", "msm", "bbs_plus"):
         assert leg in d and d[leg]["value"] > 0, leg
     assert wall < 600, "the two-rank dry run took %.0f s" % wall
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """Exactly `python3 bench.py --gpus 2 ...` — no torchrun wrapper, the shape of the driver's N = 1 command: the script must become the
+    launcher of two ranks (gloo on the ONE test GPU), not run one rank and print n_gpus 1 (missing 1); with a launcher whose
+    world size contradicts --gpus it must stop instead of reporting the wrong GPU count."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env["C12381_BENCH_BACKEND"] = "gloo"
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    small = ["--steps", "1", "--warmup", "1", "--log2-batch", "14", "--log2-pairings", "10", "--log2-g2", "12", "--log2-msm", "14", "--log2-bbs", "12",
+             "--no-cpu-baseline", "--sampled-parity", "--no-clock-probe"]
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + small, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints ONE JSON line, got %d" % len(lines)
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2
+    assert d["msm_sharded"]["equals_single_gpu"] is True and d["msm_sharded"]["rccl_ranks"] == 2
+    assert d["bbs_plus_sharded"]["accepted"] > 0
+    assert list(d)[-1] == "pairing" and d["pairing"]["value"] > 0          # the second half of BASELINE's metric closes the line
+    assert d["bbs_plus_wire"]["value"] > 0
+    assert len(lines[0]) < 8000, "the JSON line outgrew the driver's log tail: %d characters" % len(lines[0])
+    # a launcher that started ONE rank for --gpus 2: refuse
+    env1 = dict(env); env1.update({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + small, cwd=ROOT, env=env1, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing" in (r.stdout + r.stderr)

@@ -29,6 +29,7 @@ def exp_env(extra):
 CODE = r"""
 import sys
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+import tools.libsel  # C12381_LIB -> capi.use_library
 from util import cat, golden
 from crypto12381_amd import Context
 c = Context(0)
@@ -73,6 +74,7 @@ def test_environment_selected_paths(env):
 DIGEST_CODE = r"""
 import hashlib, sys
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+import tools.libsel  # C12381_LIB -> capi.use_library
 from util import golden, scalars
 from crypto12381_amd import Context
 c = Context(0)

@@ -9,6 +9,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import tools.libsel  # noqa: E402,F401  (C12381_LIB -> capi.use_library)
 from crypto12381_amd import Context  # noqa: E402
 from bench import G1_GEN, G2_GEN, make_scalars  # noqa: E402
 

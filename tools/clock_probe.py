@@ -16,6 +16,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("C12381_LIB", os.path.join(ROOT, "crypto12381_amd", "lib", "libc12381_hip_exp.so"))
+import tools.libsel  # noqa: E402,F401  (C12381_LIB -> capi.use_library)
 from crypto12381_amd import Context  # noqa: E402
 from crypto12381_amd.capi import _p  # noqa: E402
 from tools.prof_driver import G1, G2, sc  # noqa: E402

@@ -1,5 +1,6 @@
 import sys, time, torch
 sys.path.insert(0, '.')
+import tools.libsel  # noqa: E402,F401  (C12381_LIB -> capi.use_library)
 from crypto12381_amd import Context
 from tools.prof_driver import G1, sc
 c = Context(0); dev = torch.device('cuda', 0)

@@ -1,6 +1,7 @@
 import sys, os, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
+import tools.libsel  # noqa: E402,F401  (C12381_LIB -> capi.use_library)
 from crypto12381_amd import Context
 from tools.prof_driver import G1, G2, sc
 c = Context(0)

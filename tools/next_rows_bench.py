@@ -20,6 +20,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import tools.libsel  # noqa: E402,F401  (C12381_LIB -> capi.use_library)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from crypto12381_amd import Context  # noqa: E402
 from oracle.bindings import Oracle, build, have_reference  # noqa: E402

@@ -13,6 +13,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tools.libsel  # noqa: E402,F401  (C12381_LIB -> capi.use_library)
 from crypto12381_amd import Context  # noqa: E402
 from oracle.bindings import Oracle  # noqa: E402  (the checker; tools/ and tests/ only)
 from tools.prof_driver import G1, G2  # noqa: E402

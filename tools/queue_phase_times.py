@@ -8,6 +8,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 path = os.environ.setdefault("C12381_PAIR_STAMPS", "/tmp/c12381_stamps.bin")
+import tools.libsel  # noqa: E402,F401  (C12381_LIB -> capi.use_library)
 from crypto12381_amd import Context  # noqa: E402
 from tools.prof_driver import G1, G2, sc  # noqa: E402
 

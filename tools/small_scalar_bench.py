@@ -10,6 +10,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tools.libsel  # noqa: E402,F401  (C12381_LIB -> capi.use_library)
 from crypto12381_amd import Context  # noqa: E402
 from tools.prof_driver import G1, G2, sc  # noqa: E402
 
