@@ -36,8 +36,15 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # tools/ab_all.sh: pairing kernel 22.8 -> 22.1 ms).  NOT combined with -amdgpu-use-amdgpu-trackers=1: that (experimental)
 # option gained another 1 %, but together with max-ilp an experimental variant of the pairing routines (Fp4 squarings as
 # calls) returned wrong values for a few lanes of a full-size batch while passing every small test — not worth the risk.
+# -opt-disable=reassociate (round 4): LLVM's Reassociate pass orders the operands of every column sum by rank and therefore adds the
+# carry of the previous column LAST — each column of a Montgomery product is summed from zero and joined to the carry by one
+# v_lshl_add_u64 (26-30 per reduction, 3.4-5 % of every kernel's vector instructions), and the m * p terms become a chain of their
+# own.  With the pass off the source order survives: ONE linear v_mad_i64_i32 chain per column sequence through one accumulator pair —
+# fp_mul 488 -> 463 vector instructions (the hand count is 460) and 84 -> 44 registers.  A/B in one session, every output digest equal
+# (profiles/r04_ab_noreassoc.txt): G1 -3.0 %, G2 -4.3 %, pairing -2.2 %, MSM -2.2 %, BBS+ -2.5 %.  (Inline-asm multiply-adds, the other
+# way to pin the chain, cost one s_nop per instruction: the hazard recognizer pads every asm -> dependent-instruction edge.)
 CFLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-fno-optimize-sibling-calls",
-          "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+          "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-opt-disable=reassociate"]
 # Round 2 reproduced the wrong-values event with a rebuilt variant: whole wavefront groups wrong, plain grid as
 # well as queue, only with -amdgpu-use-amdgpu-trackers=1; the same source without it is exact on every lane.  The option is
 # refused outright — in CFLAGS and in every environment variable through which hipcc / clang accept extra flags — and the

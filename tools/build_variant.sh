@@ -1,13 +1,14 @@
 #!/bin/bash
 # Build an alternative libc12381_hip.so with extra compile flags into crypto12381_amd/lib/exp/lib<name>.so (A/B runs: C12381_LIB).
 # usage: bash tools/build_variant.sh <name> <extra flags...>      e.g.  bash tools/build_variant.sh occ3 -DC12381_G1_OCC=3
-# (add -DC12381_EXPERIMENTS for a variant that also reads the C12381_* tuning variables)
+# (add -DC12381_EXPERIMENTS for a variant that also reads the C12381_* tuning variables; BASEFLAGS="..." in the environment replaces the
+# product's base flags, e.g. to drop the max-ilp scheduling strategy)
 set -e
 NAME=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/crypto12381_amd/lib/exp; OBJ=$OUT/obj_$NAME
 mkdir -p $OBJ
-FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -fno-optimize-sibling-calls -mllvm -amdgpu-sched-strategy=max-ilp"
+FLAGS=${BASEFLAGS:-"-O3 --offload-arch=gfx950 -fPIC -std=c++17 -fno-optimize-sibling-calls -mllvm -amdgpu-sched-strategy=max-ilp -mllvm -opt-disable=reassociate"}
 for f in "$@"; do case "$f" in *amdgpu-use-amdgpu-trackers*) echo "refused: $f (DESIGN.md 5b)"; exit 2;; esac; done
 pids=""
 for u in c12381_hip k_g1 k_g2gt k_g2h k_pair3 k_hash_zp k_fixed; do
