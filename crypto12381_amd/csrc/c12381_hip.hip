@@ -7,6 +7,8 @@
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 #include <new>
 #include <thread>
 #include <vector>
@@ -190,6 +192,8 @@ static int msm_c(size_t n) {
     static const int forced = [] { const char* e = tuning_env("C12381_MSM_C"); const int v = e ? std::atoi(e) : 0; return v >= 4 && v <= 16 ? v : 0; }();
     return forced ? forced : msm_window_bits(n);
 }
+// the unsorted value of entry x of a window segment, as the sort's input iterator reads it (msm_entry_value)
+struct msm_value_fn { uint32_t n; __host__ __device__ uint32_t operator()(uint32_t x) const { return msm_entry_value(x, n); } };
 // Bucket-method MSM (msm.hpp): prep -> radix sort -> bucket sums -> window reduction -> Horner -> affine.
 int g1_msm_pippenger(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t* sc, uint8_t* out, int fmt, int in_fmt = 96) {
     const int cb = msm_c(n), W = msm_windows(cb);
@@ -209,42 +213,48 @@ int g1_msm_pippenger(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t*
     uint32_t* lo = (uint32_t*)c->ws[c12381_ctx::WS_MSM_RNG];
     uint32_t* hi = lo + nbx + 1;
     int32_t* bk = (int32_t*)c->ws[c12381_ctx::WS_MSM_BK];
-    hipLaunchKernelGGL(msm_prep_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, pts, in_fmt, sc, cb, W, pts2, k0, v0, c->d_flag);
-    HIPCK(c, hipGetLastError());
     // Sort by digit inside every window segment (msm_prep_one lays the entries out window by window): bits [0, cb) only — two
-    // 8-bit passes for cb = 16.  rocPRIM's radix sort is called directly; from 2^15 terms on once per segment, below that one
-    // call over all entries with the window bits included (a handful of launches instead of 3 per segment).
-    {
+    // 8-bit passes for cb = 16.  rocPRIM's radix sort is called directly.  From 2^15 terms on: once per segment, on 16-BIT keys (the digit
+    // alone: the window is the position) and with the unsorted values supplied by an iterator (msm_entry_value: they are positional too) —
+    // round 4: 6 instead of 8 bytes read and written per entry and pass, no value array written by the preparation.  Below that: one
+    // call over all entries with the window bits in 32-bit keys (a handful of launches instead of 3 per segment).
+    const bool per_window = n >= ((size_t)1 << 15) && cb <= 16;
+    if (per_window) {
+        uint16_t *q0 = (uint16_t*)k0, *q1 = (uint16_t*)k1;
+        hipLaunchKernelGGL(msm_prep16_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, pts, in_fmt, sc, cb, W, pts2, q0, c->d_flag);
+        HIPCK(c, hipGetLastError());
+        auto vin = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), msm_value_fn{(uint32_t)n});
         size_t tmp_bytes = 0, tb = 0;
-        const bool per_window = n >= ((size_t)1 << 15);
-        int end_bit = cb;
-        while ((1 << (end_bit - cb)) <= W) ++end_bit;              // keys < (W + 1) << cb
-        if (per_window) {
-            HIPCK(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, k0, k1, v0, v1, 2 * n, 0, cb, c->stream));
-            HIPCK(c, rocprim::radix_sort_pairs(nullptr, tb, k0, k1, v0, v1, n, 0, 1, c->stream));
-            if (tb > tmp_bytes) tmp_bytes = tb;
-        } else {
-            HIPCK(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, k0, k1, v0, v1, E, 0, end_bit, c->stream));
-        }
+        HIPCK(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, q0, q1, vin, v1, 2 * n, 0, cb, c->stream));
+        HIPCK(c, rocprim::radix_sort_pairs(nullptr, tb, q0, q1, vin, v1, n, 0, 1, c->stream));
+        if (tb > tmp_bytes) tmp_bytes = tb;
         if ((rc = ensure(c, c12381_ctx::WS_MSM_TMP, tmp_bytes + 256))) return rc;
         void* tmp = c->ws[c12381_ctx::WS_MSM_TMP];
-        if (per_window) {
-            for (int w = 0; w < W; ++w) {
-                const size_t off = (size_t)2 * w * n;
-                size_t sz = tmp_bytes;
-                HIPCK(c, rocprim::radix_sort_pairs(tmp, sz, k0 + off, k1 + off, v0 + off, v1 + off, 2 * n, 0, cb, c->stream));
-            }
-            const size_t off = (size_t)2 * W * n;
+        for (int w = 0; w < W; ++w) {
+            const size_t off = (size_t)2 * w * n;
             size_t sz = tmp_bytes;
-            HIPCK(c, rocprim::radix_sort_pairs(tmp, sz, k0 + off, k1 + off, v0 + off, v1 + off, n, 0, 1, c->stream));
-        } else {
-            size_t sz = tmp_bytes;
-            HIPCK(c, rocprim::radix_sort_pairs(tmp, sz, k0, k1, v0, v1, E, 0, end_bit, c->stream));
+            HIPCK(c, rocprim::radix_sort_pairs(tmp, sz, q0 + off, q1 + off, vin, v1 + off, 2 * n, 0, cb, c->stream));
         }
+        const size_t off = (size_t)2 * W * n;
+        size_t sz = tmp_bytes;
+        HIPCK(c, rocprim::radix_sort_pairs(tmp, sz, q0 + off, q1 + off, vin, v1 + off, n, 0, 1, c->stream));
+        HIPCK(c, hipMemsetAsync(lo, 0, (nbx + 1) * 8, c->stream));
+        hipLaunchKernelGGL(msm_ranges16_kernel, dim3(grid_for(2 * n), W + 1), dim3(BLOCK), 0, c->stream, n, (const uint16_t*)q1, cb, W, lo, hi);
+        HIPCK(c, hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(msm_prep_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, pts, in_fmt, sc, cb, W, pts2, k0, v0, c->d_flag);
+        HIPCK(c, hipGetLastError());
+        size_t tmp_bytes = 0;
+        int end_bit = cb;
+        while ((1 << (end_bit - cb)) <= W) ++end_bit;              // keys < (W + 1) << cb
+        HIPCK(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, k0, k1, v0, v1, E, 0, end_bit, c->stream));
+        if ((rc = ensure(c, c12381_ctx::WS_MSM_TMP, tmp_bytes + 256))) return rc;
+        size_t sz = tmp_bytes;
+        HIPCK(c, rocprim::radix_sort_pairs(c->ws[c12381_ctx::WS_MSM_TMP], sz, k0, k1, v0, v1, E, 0, end_bit, c->stream));
+        HIPCK(c, hipMemsetAsync(lo, 0, (nbx + 1) * 8, c->stream));
+        hipLaunchKernelGGL(msm_ranges_kernel, dim3(grid_for(E)), dim3(BLOCK), 0, c->stream, E, k1, cb, W, lo, hi);
+        HIPCK(c, hipGetLastError());
     }
-    HIPCK(c, hipMemsetAsync(lo, 0, (nbx + 1) * 8, c->stream));
-    hipLaunchKernelGGL(msm_ranges_kernel, dim3(grid_for(E)), dim3(BLOCK), 0, c->stream, E, k1, cb, W, lo, hi);
-    HIPCK(c, hipGetLastError());
     // buckets in order of decreasing run length (k0 / v0 are free again after the first sort; the sorted size keys go
     // to k1, which the ranges kernel has finished with)
     const size_t key_cap = E > nbx ? E : nbx;

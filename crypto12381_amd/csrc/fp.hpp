@@ -72,6 +72,7 @@ namespace c12381 { __device__ __forceinline__ int32_t limb_opaque(int32_t v) { a
 #include <cmath>
 #include <execinfo.h>
 #define C12381_BOUNDS(...) __VA_ARGS__
+#define C12381_BV(x) (x)                        // a bound expression as a function argument (0 in device builds: fp has no bound fields there)
 // operation counters of the host simulation (tools/count_ops.py): columns of 14 x 14 limb products scanned (27 per product) and
 // Montgomery reductions — the work a device routine does in THIS number format, and, priced at 144 / 156 multiply-adds, the
 // algorithmic MAC32 count of SURVEY.md 8(d) for the operation sequence as built
@@ -79,6 +80,7 @@ namespace c12381 { inline std::atomic<unsigned long long> g_ops_cols{0}, g_ops_r
 #define C12381_COUNT(cols, reds) do { c12381::g_ops_cols.fetch_add((cols), std::memory_order_relaxed); c12381::g_ops_reds.fetch_add((reds), std::memory_order_relaxed); } while (0)
 #else
 #define C12381_BOUNDS(...)
+#define C12381_BV(x) 0.0
 #define C12381_COUNT(cols, reds)
 #endif
 
@@ -105,6 +107,8 @@ inline void check_actual(const fp& a, const char* where) {
     for (int i = 0; i < NL; ++i)
         if (std::fabs((double)a.l[i]) > a.lb) bounds_fail(where, (double)a.l[i], a.lb);
 }
+inline void check_actual_vb(const fp& a, const char* where);
+inline void set_inj_bounds(fp& r, double sum_lblb, double sum_vbvb, double inj_abs, double inj_lb, const char* where);
 inline void set_bounds(fp& r, double lb, double vb, const char* where) {
     r.lb = lb; r.vb = vb;
     if (lb > 2147483648.0) bounds_fail("limb bound exceeds int32", lb, vb);
@@ -387,6 +391,124 @@ C12381_HD void fp_reduce_cols_static(fp& r, ColFn col) {
 #pragma unroll
     for (int i = 0; i < NL; ++i) r.l[i] = out[i];
 }
+// ------------------------------------------------------------------ reductions with linear terms injected (round 4)
+// R = 2^(28 * 14): an addend c enters a Montgomery reduction as c * R, i.e. as c's limb i in column 14 + i —
+//     (T + R * sum_j k_j c_j + m p) / R  =  T / R + sum_j k_j c_j     (mod p, and as integers up to the usual + m p / R < p).
+// One multiply-add per limb and addend (the multiplier k_j is a small constant or a per-lane register: signs and role-dependent choices
+// ride on it), and the sum comes out of the reduction NORMALISED: the lazy additions after a reduction, the carry round they force
+// before the next product and the selects around them disappear.  inj(i, acc) adds the limbs i of the addends (i = 0..13; limb 13 lands
+// on the top limb, behind the last column).  A multiple of p rides along the same way (fp_inj_p): a linear term that passes through
+// unmultiplied — the 2 conj(x) of the cyclotomic squaring — is re-bounded by "- q p" with q = round(term / p) from its top limb, 14
+// multiply-adds instead of a weak reduction (~90 instructions) every other call.
+// Bounds: the addends' limbs are noise against the 2^56-sized products of a column (|k| LB <= 2^32 against a headroom of >= 2^59, asserted
+// by the checker through the callers' declarations); the VALUE bound of the result is declared by the caller (set_inj_bounds).
+C12381_HD void fp_inj(int64_t& acc, const fp& c, int i, int32_t k) { acc += (int64_t)c.l[i] * k; }
+C12381_HD void fp_inj_p(int64_t& acc, int i, int32_t k) { acc += (int64_t)FP_P[i] * k; }
+// round(top / (p / 2^364)) for a value whose lower limbs are normalised: the multiple of p nearest to the value (within 2 p / 106513);
+// the same estimate fp_weak_reduce uses
+C12381_HD int32_t fp_quot_top(int32_t top) { return (int32_t)(((int64_t)top * 40324 + ((int64_t)1 << 31)) >> 32); }
+// a small integer the optimiser cannot see through: multipliers of injected terms must reach instruction selection as REGISTER operands
+// of v_mad_i64_i32 (a literal 2 or -1 is strength-reduced into sign extension + 64-bit shift / add: two or three instructions)
+#if defined(__HIP_DEVICE_COMPILE__)
+C12381_HD int32_t fp_opaque_const(int32_t v) { asm("" : "+s"(v)); return v; }
+#else
+C12381_HD int32_t fp_opaque_const(int32_t v) { return v; }
+#endif
+template <class ColFn, class InjFn>
+C12381_HD void fp_reduce_cols_inj(fp& r, ColFn col, InjFn inj) {
+    C12381_COUNT(0, 1);
+    int32_t m[NL];
+    int32_t out[NL];
+    int64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        col(k, acc);
+#pragma unroll
+        for (int i = 0; i < k; ++i) { acc += (int64_t)m[i] * FP_P[k - i]; C12381_FENCE(acc); }
+        m[k] = (int32_t)(((uint32_t)acc * FP_N0) & LMASK);
+        acc += (int64_t)m[k] * FP_P[0]; C12381_FENCE(acc);
+        acc >>= LB;
+    }
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; ++k) {
+        col(k, acc);
+        inj(k - NL, acc);
+#pragma unroll
+        for (int i = k - NL + 1; i < NL; ++i) { acc += (int64_t)m[i] * FP_P[k - i]; C12381_FENCE(acc); }
+        out[k - NL] = C12381_LIMB((int32_t)((uint32_t)acc & LMASK));
+        acc >>= LB;
+    }
+    inj(NL - 1, acc);
+    out[NL - 1] = (int32_t)acc;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = out[i];
+}
+// r = a * b / R + (injected addends): one product, one reduction, linear terms injected; bounds for the checker: inj_vb = sum |k| VB(c)
+// (or what the caller proves), inj_lb = sum |k| LB(c)
+template <class InjFn>
+C12381_HD void fp_mul_inj(fp& r, const fp& a, const fp& b, InjFn inj, double inj_vb, double inj_lb) {
+    C12381_COUNT(27, 0);
+    fp t;
+    fp_reduce_cols_inj(t, [&](int k, int64_t& acc) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) { const int j = k - i; if (j >= 0 && j < NL) { acc += (int64_t)a.l[i] * b.l[j]; C12381_FENCE(acc); } }
+    }, inj);
+    (void)inj_vb; (void)inj_lb;
+    C12381_BOUNDS({ check_actual(a, "fp_mul_inj"); check_actual(b, "fp_mul_inj"); set_inj_bounds(t, a.lb * b.lb, a.vb * b.vb, inj_vb, inj_lb, "fp_mul_inj"); })
+    r = t;
+}
+// r = a^2 / R + (injected addends): cross terms once against a doubled copy, like fp_sqr
+template <class InjFn>
+C12381_HD void fp_sqr_inj(fp& r, const fp& a, InjFn inj, double inj_vb, double inj_lb) {
+    C12381_COUNT(27, 0);
+    fp t, a2;
+    fp_raw_dbl(a2, a);
+    fp_reduce_cols_inj(t, [&](int k, int64_t& acc) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) { const int j = k - i; if (j > i && j < NL) { acc += (int64_t)a2.l[i] * a.l[j]; C12381_FENCE(acc); } }
+        if ((k & 1) == 0 && k / 2 < NL) { acc += (int64_t)a.l[k / 2] * a.l[k / 2]; C12381_FENCE(acc); }
+    }, inj);
+    (void)inj_vb; (void)inj_lb;
+    C12381_BOUNDS({ check_actual(a, "fp_sqr_inj"); set_inj_bounds(t, a.lb * a.lb, a.vb * a.vb, inj_vb, inj_lb, "fp_sqr_inj"); })
+    r = t;
+}
+// 2 a, normalised: one parallel carry round on the doubled limbs (the doubling rides on the shifts: same count as fp_norm1)
+C12381_HD void fp_norm1_dbl(fp& r, const fp& a) {
+    int32_t c[NL];
+#pragma unroll
+    for (int i = 0; i < NL - 1; ++i) c[i] = a.l[i] >> (LB - 1);
+    const int32_t t13 = 2 * a.l[NL - 1] + c[NL - 2];
+#pragma unroll
+    for (int i = NL - 2; i >= 1; --i) r.l[i] = C12381_LIMB((int32_t)(((uint32_t)a.l[i] << 1) & LMASK)) + c[i - 1];
+    r.l[0] = C12381_LIMB((int32_t)(((uint32_t)a.l[0] << 1) & LMASK));
+    r.l[NL - 1] = t13;
+    C12381_BOUNDS({ double top = 2 * a.vb * TOP_PER_P + 6.0 + std::floor(2 * a.lb / 268435456.0);
+                    double lb = 268435456.0 + std::floor(2 * a.lb / 268435456.0) + 1.0;
+                    set_bounds(r, lb > top ? lb : top, 2 * a.vb, "fp_norm1_dbl"); })
+}
+
+// r = k0 a + k1 b + k2 c + kp p, carried exactly (limbs 0..12 in [0, 2^28), signed top limb): one 64-bit running sum, four multiply-adds,
+// a mask and a shift per limb.  The multipliers are registers (per-lane choices and signs ride on them), so a role-dependent linear
+// combination needs no select and its result no carry round.  Value bound declared by the caller (`vb`: what it can prove, e.g. after
+// a "- q p" term); limbs of the inputs may be lazy.
+C12381_HD void fp_lincomb3p(fp& r, const fp& a, int32_t k0, const fp& b, int32_t k1, const fp& c, int32_t k2, int32_t kp, double vb) {
+    int64_t t = 0;
+    int32_t out[NL];
+#pragma unroll
+    for (int i = 0; i < NL - 1; ++i) {
+        t += (int64_t)a.l[i] * k0; t += (int64_t)b.l[i] * k1; t += (int64_t)c.l[i] * k2; t += (int64_t)FP_P[i] * kp;
+        out[i] = C12381_LIMB((int32_t)((uint32_t)t & LMASK));
+        t >>= LB;
+    }
+    t += (int64_t)a.l[NL - 1] * k0; t += (int64_t)b.l[NL - 1] * k1; t += (int64_t)c.l[NL - 1] * k2; t += (int64_t)FP_P[NL - 1] * kp;
+    out[NL - 1] = (int32_t)t;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = out[i];
+    (void)vb;
+    C12381_BOUNDS({ double top = vb * TOP_PER_P + 2.0;
+                    set_bounds(r, top > 268435456.0 ? top : 268435456.0, vb, "fp_lincomb3p"); check_actual_vb(r, "fp_lincomb3p value"); })
+}
+
 // r = (a*b + c*d) / R  or  (a*b - c*d) / R  with ONE reduction (saves 196 + 14 multiply-adds over two
 // fp_mul).  Needs 14*(LBa*LBb + LBc*LBd) + 14*2^56 + 2^40 < 2^63.
 template <bool SUB>
@@ -402,6 +524,27 @@ inline void set_lazy_bounds(fp& r, double sum_lblb, double sum_vbvb, const char*
     double top = vb * TOP_PER_P + 2.0;
     set_bounds(r, top > 268435456.0 ? top : 268435456.0, vb, where);
 }
+// the same for a reduction with injected addends (fp_reduce_cols_inj): sum_vbvb of the product part, inj_abs = a bound on
+// |sum_j k_j c_j| / p AS THE CALLER PROVES IT (terms that cancel exactly may be left out: the integer identity is exact),
+// inj_lb = sum_j |k_j| LB(c_j) for the column check
+inline void set_inj_bounds(fp& r, double sum_lblb, double sum_vbvb, double inj_abs, double inj_lb, const char* where) {
+    double col = 14.0 * sum_lblb + 14.0 * 72057594037927936.0 + 1099511627776.0 + inj_lb;
+    if (col >= 9223372036854775808.0) bounds_fail(where, sum_lblb, inj_lb);
+    if (sum_vbvb > 1.0e6) bounds_fail("injected form value bound", sum_vbvb, 0);
+    double vb = sum_vbvb * P_OVER_R + 1.0 + inj_abs;
+    double top = vb * TOP_PER_P + 2.0;
+    set_bounds(r, top > 268435456.0 ? top : 268435456.0, vb, where);
+    check_actual_vb(r, where);               // the caller's proof is checked against the data as well
+}
+// |value| / p of an element as it stands (test builds: the declared value bound is checked against the data, too)
+inline double fp_actual_vb(const fp& a) {
+    long double v = 0, w = 1;
+    for (int i = 0; i < NL; ++i) { v += (long double)a.l[i] * w; w *= 268435456.0L; }
+    long double pp = 0; w = 1;
+    for (int i = 0; i < NL; ++i) { pp += (long double)FP_P[i] * w; w *= 268435456.0L; }
+    return (double)fabsl(v / pp);
+}
+inline void check_actual_vb(const fp& a, const char* where) { const double v = fp_actual_vb(a); if (v > a.vb * 1.0000001 + 1e-9) bounds_fail(where, v, a.vb); }
 #endif
 
 template <bool SUB>

@@ -43,6 +43,28 @@ C12381_HD void fp2_mul(fp2& r, const fp2& x, const fp2& y) {
                     set_lazy_bounds(rb, x.a.lb * y.b.lb + x.b.lb * y.a.lb, x.a.vb * y.b.vb + x.b.vb * y.a.vb, "fp2_mul.b"); })
     r.a = ra; r.b = rb;
 }
+// r = x * y + (linear terms injected into the two reductions, fp_reduce_cols_inj): inj_a / inj_b add the addends of the real / imaginary
+// coordinate; ba / bb carry their bounds for the checker builds (sum |k| VB, sum |k| LB).  The result is normalised: what used to be
+// "product, lazy additions, carry round" is one product.
+struct fp_injb { double vb, lb; };
+#ifdef C12381_CHECK_BOUNDS
+#define C12381_INJB(vb_, lb_) c12381::fp_injb{(vb_), (lb_)}
+#else
+#define C12381_INJB(vb_, lb_) c12381::fp_injb{0.0, 0.0}
+#endif
+template <class IA, class IB>
+C12381_HD void fp2_mul_inj(fp2& r, const fp2& x, const fp2& y, IA inj_a, IB inj_b, const fp_injb& ba, const fp_injb& bb) {
+    fp ra, rb, nxb;
+    fp_raw_neg(nxb, x.b);
+    fp_reduce_cols_inj(ra, [&](int k, int64_t& acc) { fp_col_acc(acc, x.a, y.a, k); fp_col_acc(acc, nxb, y.b, k); }, inj_a);
+    fp_reduce_cols_inj(rb, [&](int k, int64_t& acc) { fp_col_acc(acc, x.a, y.b, k); fp_col_acc(acc, x.b, y.a, k); }, inj_b);
+    (void)ba; (void)bb;
+    C12381_BOUNDS({ check_actual(x.a, "fp2_mul_inj"); check_actual(x.b, "fp2_mul_inj"); check_actual(y.a, "fp2_mul_inj"); check_actual(y.b, "fp2_mul_inj");
+                    set_inj_bounds(ra, x.a.lb * y.a.lb + x.b.lb * y.b.lb, x.a.vb * y.a.vb + x.b.vb * y.b.vb, ba.vb, ba.lb, "fp2_mul_inj.a");
+                    set_inj_bounds(rb, x.a.lb * y.b.lb + x.b.lb * y.a.lb, x.a.vb * y.b.vb + x.b.vb * y.a.vb, bb.vb, bb.lb, "fp2_mul_inj.b"); })
+    r.a = ra; r.b = rb;
+}
+C12381_HD void fp2_norm1_dbl(fp2& r, const fp2& x) { fp_norm1_dbl(r.a, x.a); fp_norm1_dbl(r.b, x.b); }
 // r = x^2 = (a^2 - b^2) + 2ab i.  Operand limb bound <= 2^29.
 C12381_HD void fp2_sqr(fp2& r, const fp2& x) {
     fp ra, rb, a2, nb2, nb;

@@ -22,8 +22,24 @@ C12381_HD void g1_norm1(g1p& r, const g1p& p) { fp_norm1(r.x, p.x); fp_norm1(r.y
 
 // P = 2P.  6M + 2S with 7 reductions (Y3 is a lazily reduced sum of two products).
 // Operand limb bound: <= 2^29.
+// Round 4: u = Y^2 - 9b Z^2 leaves the reduction of Y^2 with -3 (3b Z^2) injected (fp_reduce_cols_inj) — normalised, no lazy
+// sum and no carry round; Y^2 itself is u + 3 (3b Z^2), used lazily (-DC12381_INJ_G1=0: the lazy form, A/B).
+#ifndef C12381_INJ_G1
+#define C12381_INJ_G1 1
+#endif
 C12381_HD void g1_dbl(g1p& p) {
     fp t0, t1, t2, z8, u, y3, x3, z3;
+#if C12381_INJ_G1
+    const int32_t cm3 = fp_opaque_const(-3);
+    fp_mul(t1, p.y, p.z);
+    fp_sqr(t2, p.z);
+    fp_mul_small(t2, t2, 12);                            // 3b Z^2
+    fp_sqr_inj(u, p.y, [&](int i, int64_t& acc) { fp_inj(acc, t2, i, cm3); }, C12381_BV(3 * t2.vb), C12381_BV(3 * t2.lb));          // Y^2 - 9b Z^2
+    fp_dbl(t0, t2); fp_add(t0, t0, t2); fp_add(t0, t0, u);                                                    // Y^2 = u + 9b Z^2 (limbs < 2^30)
+    fp_mul_small(z8, t0, 8);                             // 8 Y^2
+    fp_add(y3, t0, t2);
+    fp_mul(z3, t1, z8);
+#else
     fp_sqr(t0, p.y);
     fp_mul(t1, p.y, p.z);
     fp_sqr(t2, p.z);
@@ -34,6 +50,7 @@ C12381_HD void g1_dbl(g1p& p) {
     fp_dbl(u, t2); fp_add(u, u, t2);                     // 9b Z^2
     fp_sub(u, t0, u);
     fp_norm1(u, u);
+#endif
     fp_mul2<false>(y3, u, y3, t2, z8);                   // (Y^2 - 9bZ^2)(Y^2 + 3bZ^2) + 3bZ^2 * 8Y^2
     fp_mul(t1, p.x, p.y);
     fp_mul(x3, u, t1);
@@ -48,10 +65,21 @@ C12381_HD void g1_add(g1p& p, const g1p& q) {
     fp_mul(t0, p.x, q.x);
     fp_mul(t1, p.y, q.y);
     fp_mul(t2, p.z, q.z);
+#if C12381_INJ_G1
+    {   // the Karatsuba corrections -t0 - t1, -t1 - t2 ride in the reductions: t3, t4 normalised without a lazy sum or a carry round
+        const int32_t cm1 = fp_opaque_const(-1);
+        fp sa, sb;
+        fp_add(sa, p.x, p.y); fp_add(sb, q.x, q.y);
+        fp_mul_inj(t3, sa, sb, [&](int i, int64_t& acc) { fp_inj(acc, t0, i, cm1); fp_inj(acc, t1, i, cm1); }, C12381_BV(t0.vb + t1.vb), C12381_BV(t0.lb + t1.lb));
+        fp_add(sa, p.y, p.z); fp_add(sb, q.y, q.z);
+        fp_mul_inj(t4, sa, sb, [&](int i, int64_t& acc) { fp_inj(acc, t1, i, cm1); fp_inj(acc, t2, i, cm1); }, C12381_BV(t1.vb + t2.vb), C12381_BV(t1.lb + t2.lb));
+    }
+#else
     fp_add(t3, p.x, p.y); fp_add(t4, q.x, q.y); fp_mul(t3, t3, t4);
     fp_add(t4, t0, t1); fp_sub(t3, t3, t4); fp_norm1(t3, t3);
     fp_add(t4, p.y, p.z); fp_add(x3, q.y, q.z); fp_mul(t4, t4, x3);
     fp_add(x3, t1, t2); fp_sub(t4, t4, x3);
+#endif
     fp_add(x3, p.x, p.z); fp_add(y3, q.x, q.z); fp_mul(x3, x3, y3);
     fp_add(y3, t0, t2); fp_sub(y3, x3, y3);
     fp_mul_small(t0, t0, 3);

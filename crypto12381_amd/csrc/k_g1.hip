@@ -276,8 +276,9 @@ __global__ void __launch_bounds__(BLOCK, 2) g1_rsub_kernel(size_t n, int32_t* ac
 
 // in_fmt: 96 = affine records, 49 = compressed records (C12381_F_COMPRESSED_IN: decoded here, one square root per term; a rejected
 // encoding becomes the off-curve record (0, 1), which msm_prep_one reports and leaves out of the product like any invalid point)
-__global__ void __launch_bounds__(BLOCK, 2) msm_prep_kernel(size_t n, const uint8_t* pts, int in_fmt, const uint8_t* scalars, int c, int W, int32_t* pts2,
-                                                         uint32_t* keys, uint32_t* vals, int* bad_flag) {
+template <class K>
+static __device__ __forceinline__ void msm_prep_body(size_t n, const uint8_t* pts, int in_fmt, const uint8_t* scalars, int c, int W, int32_t* pts2,
+                                                     K* keys, uint32_t* vals, int* bad_flag) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     uint32_t rp[24], rs[8];
@@ -288,22 +289,30 @@ __global__ void __launch_bounds__(BLOCK, 2) msm_prep_kernel(size_t n, const uint
         else { fp_to_raw48(rp, x); fp_to_raw48(rp + 12, y); }
     } else { load_raw48(rp, pts + 96 * i); load_raw48(rp + 12, pts + 96 * i + 48); }
     load_raw32(rs, scalars + 32 * i);
-    if (!msm_prep_one(i, n, rp, rs, c, W, pts2, keys, vals)) *bad_flag = 1;
+    if (!msm_prep_one<K>(i, n, rp, rs, c, W, pts2, keys, vals)) *bad_flag = 1;
 }
-
+__global__ void __launch_bounds__(BLOCK, 2) msm_prep_kernel(size_t n, const uint8_t* pts, int in_fmt, const uint8_t* scalars, int c, int W, int32_t* pts2,
+                                                         uint32_t* keys, uint32_t* vals, int* bad_flag) {
+    msm_prep_body<uint32_t>(n, pts, in_fmt, scalars, c, W, pts2, keys, vals, bad_flag);
+}
+// large products: 16-bit digit keys, no value array (msm_entry_value)
+__global__ void __launch_bounds__(BLOCK, 2) msm_prep16_kernel(size_t n, const uint8_t* pts, int in_fmt, const uint8_t* scalars, int c, int W, int32_t* pts2,
+                                                           uint16_t* keys, int* bad_flag) {
+    msm_prep_body<uint16_t>(n, pts, in_fmt, scalars, c, W, pts2, keys, nullptr, bad_flag);
+}
 __global__ void __launch_bounds__(BLOCK, 2) msm_ranges_kernel(size_t E, const uint32_t* keys, int c, int W, uint32_t* lo, uint32_t* hi) {
     const size_t j = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (j >= E) return;
     msm_ranges_one(j, E, keys, c, W, lo, hi);
 }
-
-// sort key for "longest run first": buckets are handed to lanes in order of decreasing size, so the 64 lanes of a
-// wavefront sum runs of (almost) the same length instead of waiting for the longest of 64 random ones.
-// A run longer than `cap` (msm_run_cap: uniform scalars stay below it; equal, small or structured scalars give runs of up
-// to 2n, and so does a top window narrower than c bits) is cut: its bucket lane sums the first cap entries, every
-// further seg = cap/2 entries are an OVERFLOW SEGMENT summed by a lane of msm_overflow_kernel, and one wavefront per cut bucket adds the partial sums
-// (msm_overflow_combine_kernel) — so no lane ever walks more than cap entries, whatever the scalars are.
-// cnt[0] = overflow segments, cnt[1] = cut buckets (zeroed by the host before this kernel).
+// digit-only keys: blockIdx.y = the window segment (W = the small-scalar segment of n entries)
+__global__ void __launch_bounds__(BLOCK, 2) msm_ranges16_kernel(size_t n, const uint16_t* keys, int c, int W, uint32_t* lo, uint32_t* hi) {
+    const uint32_t w = blockIdx.y;
+    const uint32_t len = (uint32_t)(w < (uint32_t)W ? 2 * n : n);
+    const uint32_t x = blockIdx.x * BLOCK + threadIdx.x;
+    if (x >= len) return;
+    msm_ranges_seg(x, len, (size_t)2 * w * n, w, keys, c, W, lo, hi);
+}
 __global__ void __launch_bounds__(BLOCK, 2) msm_sizes_kernel(size_t nbk, const uint32_t* lo, const uint32_t* hi, uint32_t* key, uint32_t* ident,
                                                           uint32_t cap, uint32_t* cnt, uint2* seg, uint4* big) {
     const size_t b = (size_t)blockIdx.x * BLOCK + threadIdx.x;

@@ -50,6 +50,8 @@ __global__ void __launch_bounds__(BLOCK, 2) g1_mul_plain_kernel(size_t n, const 
 __global__ void __launch_bounds__(BLOCK, 2) g1_add_const_kernel(size_t n, int32_t* proj, size_t stride, const uint8_t* pt96, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) msm_prep_kernel(size_t n, const uint8_t* pts, int in_fmt, const uint8_t* scalars, int c, int W, int32_t* pts2, uint32_t* keys, uint32_t* vals, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) msm_ranges_kernel(size_t E, const uint32_t* keys, int c, int W, uint32_t* lo, uint32_t* hi);
+__global__ void __launch_bounds__(BLOCK, 2) msm_prep16_kernel(size_t n, const uint8_t* pts, int in_fmt, const uint8_t* scalars, int c, int W, int32_t* pts2, uint16_t* keys, int* bad_flag);
+__global__ void __launch_bounds__(BLOCK, 2) msm_ranges16_kernel(size_t n, const uint16_t* keys, int c, int W, uint32_t* lo, uint32_t* hi);
 __global__ void __launch_bounds__(BLOCK, C12381_MSM_OCC) msm_bucket_kernel(size_t nbk, const uint32_t* lo, const uint32_t* hi, const uint32_t* vals, const int32_t* pts2, int32_t* bk, const uint32_t* order, uint32_t cap);
 __global__ void __launch_bounds__(BLOCK, 2) msm_sizes_kernel(size_t nbk, const uint32_t* lo, const uint32_t* hi, uint32_t* key, uint32_t* ident, uint32_t cap, uint32_t* cnt, uint2* seg, uint4* big);
 __global__ void __launch_bounds__(BLOCK, 2) msm_overflow_kernel(const uint32_t* cnt, const uint2* seg, const uint32_t* lo, const uint32_t* hi, const uint32_t* vals, const int32_t* pts2, int32_t* part, uint32_t cap);

@@ -30,7 +30,10 @@ constexpr int MSM_PT_DWORDS = 2 * NL;          // affine (x, y) in Montgomery fo
 #define C12381_MSM_PT_STRIDE 32
 #endif
 constexpr int MSM_PT_STRIDE = C12381_MSM_PT_STRIDE;
-constexpr int MSM_CHUNK = 16;                  // buckets per lane in the window reduction
+#ifndef C12381_MSM_CHUNK
+#define C12381_MSM_CHUNK 16
+#endif
+constexpr int MSM_CHUNK = C12381_MSM_CHUNK;    // buckets per lane in the window reduction (A/B: -DC12381_MSM_CHUNK=8)
 // entries a bucket lane sums at most: twice the mean run + 32 (uniform scalars: mean + 11 sigma or more, so nothing is
 // cut); the rest of a longer run is cut into overflow segments of half that length, one lane each (k_g1.hip).  A lane
 // with a long run finishes alone at single-wavefront latency (~9 us per addition), hence a cap relative to the mean.
@@ -51,10 +54,21 @@ C12381_HD void g1_add_affine(g1p& p, const fp& qx, const fp& qy) {
     fp t0, t1, t2, t3, t4, y3, z3;
     fp_mul(t0, p.x, qx);
     fp_mul(t1, p.y, qy);
+#if C12381_INJ_G1
+    {   // round 4: the linear terms ride in the reductions (fp_mul_inj): t3, t4 normalised without lazy sums or carry rounds
+        const int32_t c1 = fp_opaque_const(1), cm1 = fp_opaque_const(-1);
+        fp sa, sb;
+        fp_add(sa, qx, qy); fp_add(sb, p.x, p.y);
+        fp_mul_inj(t3, sa, sb, [&](int i, int64_t& acc) { fp_inj(acc, t0, i, cm1); fp_inj(acc, t1, i, cm1); }, C12381_BV(t0.vb + t1.vb), C12381_BV(t0.lb + t1.lb));    // X1 Y2 + X2 Y1
+        fp_mul_inj(t4, qy, p.z, [&](int i, int64_t& acc) { fp_inj(acc, p.y, i, c1); }, C12381_BV(p.y.vb), C12381_BV(p.y.lb));                                         // Y2 Z1 + Y1
+        fp_mul_inj(y3, qx, p.z, [&](int i, int64_t& acc) { fp_inj(acc, p.x, i, c1); }, C12381_BV(p.x.vb), C12381_BV(p.x.lb));                                         // X2 Z1 + X1
+    }
+#else
     fp_add(t3, qx, qy); fp_add(t4, p.x, p.y); fp_mul(t3, t3, t4);
     fp_add(t4, t0, t1); fp_sub(t3, t3, t4); fp_norm1(t3, t3);                 // X1 Y2 + X2 Y1
     fp_mul(t4, qy, p.z); fp_add(t4, t4, p.y); fp_norm1(t4, t4);               // Y2 Z1 + Y1
     fp_mul(y3, qx, p.z); fp_add(y3, y3, p.x);                                 // X2 Z1 + X1
+#endif
     fp_mul_small(t0, t0, 3);
     fp_mul_small(t2, p.z, 12);                                                // b3 Z1
     fp_add(z3, t1, t2); fp_sub(t1, t1, t2);
@@ -92,9 +106,18 @@ C12381_HD uint32_t msm_digit(const uint32_t (&k)[4], int w, int c) {
     if (bit + c > 128) d &= (1u << (128 - bit)) - 1u;
     return d;
 }
+// The value of the entry at position x of a window segment (half 0 of term i at x = i, half 1 at x = n + i): the index of its point record.
+// It depends on the position alone, so the large products never store the unsorted values: the sort reads them from this function
+// through an iterator (c12381_hip.hip) — 68 B of writes per term and as many bytes of the first sorting pass saved.
+C12381_HD uint32_t msm_entry_value(uint32_t x, uint32_t n) { return x < n ? 2u * x : 2u * (x - n) + 1u; }
 // prep: returns false if the point is not on the curve.  pts2 holds P at 2i and P' = (beta x, -y) at 2i+1.
+// K = uint32_t: key = window << c | digit, sorted in one call over all entries (small products);  K = uint16_t: key = the digit alone —
+// the window of an entry is its position, every window segment is sorted on its own and 16-bit keys halve the key traffic of the two
+// radix passes (round 4; c <= 16).  vals may be null (the values are positional: msm_entry_value).
+template <class K>
 C12381_HD bool msm_prep_one(size_t i, size_t n, const uint32_t* raw_pt /*24 words*/, const uint32_t* raw_sc /*8 words*/, int c, int W,
-                            int32_t* pts2, uint32_t* keys, uint32_t* vals) {
+                            int32_t* pts2, K* keys, uint32_t* vals) {
+    constexpr bool WIDE = sizeof(K) == 4;
     fp px, py;
     const bool inf = raw_all_zero(raw_pt, 24);
     fp_from_raw48(px, raw_pt); fp_from_raw48(py, raw_pt + 12);
@@ -125,12 +148,15 @@ C12381_HD bool msm_prep_one(size_t i, size_t n, const uint32_t* raw_pt /*24 word
     // digit, the point at infinity, a point that is not on the curve) sorts to the front of its window and is skipped by
     // msm_ranges.  The last n entries are the small-scalar segment: key = W << c | 1 if the term owes [r]phi(P), else W << c.
     const bool small = (k1[0] | k1[1] | k1[2] | k1[3]) == 0u;             // k mod r < x^2: multiply() owes [r]phi(P)
-    keys[(size_t)(2 * W) * n + i] = ((uint32_t)W << c) | ((usable && small) ? 1u : 0u); vals[(size_t)(2 * W) * n + i] = (uint32_t)(2 * i);
+    keys[(size_t)(2 * W) * n + i] = (K)((WIDE ? ((uint32_t)W << c) : 0u) | ((usable && small) ? 1u : 0u));
+    if (vals) vals[(size_t)(2 * W) * n + i] = (uint32_t)(2 * i);
     for (int w = 0; w < W; ++w) {
         const uint32_t d0 = msm_digit(k0, w, c), d1 = msm_digit(k1, w, c);
         const size_t e0 = ((size_t)(2 * w)) * n + i, e1 = e0 + n;
-        keys[e0] = ((uint32_t)w << c) | (usable ? d0 : 0u); vals[e0] = (uint32_t)(2 * i);
-        keys[e1] = ((uint32_t)w << c) | (usable ? d1 : 0u); vals[e1] = (uint32_t)(2 * i + 1);
+        const uint32_t hi_bits = WIDE ? ((uint32_t)w << c) : 0u;
+        keys[e0] = (K)(hi_bits | (usable ? d0 : 0u));
+        keys[e1] = (K)(hi_bits | (usable ? d1 : 0u));
+        if (vals) { vals[e0] = (uint32_t)(2 * i); vals[e1] = (uint32_t)(2 * i + 1); }
     }
     return ok;
 }
@@ -142,6 +168,14 @@ C12381_HD void msm_ranges_one(size_t j, size_t E, const uint32_t* keys, int c, i
     const uint32_t b = (k >> c) < (uint32_t)W ? k : ((uint32_t)W << c);
     if (j == 0 || keys[j - 1] != k) lo[b] = (uint32_t)j;
     if (j + 1 == E || keys[j + 1] != k) hi[b] = (uint32_t)(j + 1);
+}
+// the same for digit-only keys: entry x of window segment w (w = W: the small-scalar segment); seg = the segment's first entry, len its length
+C12381_HD void msm_ranges_seg(uint32_t x, uint32_t len, size_t seg, uint32_t w, const uint16_t* keys, int c, int W, uint32_t* lo, uint32_t* hi) {
+    const uint32_t d = keys[seg + x];
+    if (d == 0) return;
+    const uint32_t b = w < (uint32_t)W ? ((w << c) | d) : ((uint32_t)W << c);
+    if (x == 0 || keys[seg + x - 1] != d) lo[b] = (uint32_t)(seg + x);
+    if (x + 1 == len || keys[seg + x + 1] != d) hi[b] = (uint32_t)(seg + x + 1);
 }
 // bucket: sum of the points whose (sorted) entries lie in [lo, hi)
 // The gather (index -> 112-byte record somewhere in a table of 2n records) is a two-step dependent load of a few
@@ -179,10 +213,13 @@ C12381_HD void msm_wreduce_one(g1p& out, const int32_t* bk, uint32_t d0, uint32_
         }
     }
     if (d0 < nb) { tab_load_g1(b, bk + (size_t)d0 * G1_ENT_DWORDS); g1_add(run, b); g1p nn; g1_norm1(nn, run); run = nn; }
-    // [d0] S by double-and-add (d0 < 2^16), selects instead of branches
+    // [d0] S by double-and-add (d0 < 2^16), selects instead of branches.  d0 is a multiple of the chunk length: its low bits are
+    // doublings only (round 4: log2(MSM_CHUNK) additions of the point at infinity less)
+    constexpr int LOW = MSM_CHUNK >= 16 ? 4 : (MSM_CHUNK >= 8 ? 3 : (MSM_CHUNK >= 4 ? 2 : (MSM_CHUNK >= 2 ? 1 : 0)));
+    static_assert((1 << LOW) == MSM_CHUNK || MSM_CHUNK > 16, "MSM_CHUNK is a power of two up to 16 (or a larger multiple of 16)");
     g1p t, inf;
     g1_set_inf(t); g1_set_inf(inf);
-    for (int bit = 15; bit >= 0; --bit) {
+    for (int bit = 15; bit >= LOW; --bit) {
         g1_dbl(t);
         g1p s;
         const bool on = (d0 >> bit) & 1u;
@@ -191,6 +228,7 @@ C12381_HD void msm_wreduce_one(g1p& out, const int32_t* bk, uint32_t d0, uint32_
         g1_add(tn, s);
         t = tn;
     }
+    for (int bit = 0; bit < LOW; ++bit) g1_dbl(t);
     g1p tn; g1_norm1(tn, t);
     g1_add(tn, acc);
     g1_norm1(out, tn);

@@ -97,11 +97,28 @@ C12381_HD void slot_load(fp4& r, const fp4& slot) { slot_rd(r, (const c12381_lds
 C12381_HD void slot_store(fp4& slot, const fp4& r) { slot_wr((c12381_lds_v4i*)(&slot), r); }
 C12381_HD void slot_unpark(fp4& r, const fp4& slot) { slot_rd(r, (const volatile c12381_lds_v4i*)(&slot)); }
 C12381_HD void slot_park(fp4& slot, const fp4& r) { slot_wr((volatile c12381_lds_v4i*)(&slot), r); }
+// one Fp2 half of the slot's Fp4 (half 0 = .a: rows 0..6, half 1 = .b: rows 7..13); `half` may differ from lane to lane (an LDS
+// address is per lane anyway): a role-dependent placement of two results costs an address, not 56 selects
+static_assert(sizeof(fp2) == 7 * 16, "an fp2 is 7 rows of 16 bytes");
+C12381_HD void slot_load_half(fp2& r, const fp4& slot, int half) {
+    const c12381_lds_v4i* p = (const c12381_lds_v4i*)(&slot) + 7 * half;
+    int32_t* w = reinterpret_cast<int32_t*>(&r);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { const c12381_v4i v = p[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
+}
+C12381_HD void slot_store_half(fp4& slot, int half, const fp2& r) {
+    c12381_lds_v4i* p = (c12381_lds_v4i*)(&slot) + 7 * half;
+    const int32_t* w = reinterpret_cast<const int32_t*>(&r);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { c12381_v4i v; v.x = w[4 * i]; v.y = w[4 * i + 1]; v.z = w[4 * i + 2]; v.w = w[4 * i + 3]; p[i] = v; }
+}
 #else
 C12381_HD void slot_load(fp4& r, const fp4& slot) { r = slot; }
 C12381_HD void slot_store(fp4& slot, const fp4& r) { slot = r; }
 C12381_HD void slot_unpark(fp4& r, const fp4& slot) { r = slot; }
 C12381_HD void slot_park(fp4& slot, const fp4& r) { slot = r; }
+C12381_HD void slot_load_half(fp2& r, const fp4& slot, int half) { r = half ? slot.b : slot.a; }
+C12381_HD void slot_store_half(fp4& slot, int half, const fp2& r) { (half ? slot.b : slot.a) = r; }
 #endif
 
 // The slot as the kernels allocate it: the Fp4, then one Fp of the same lane — the affine G1 coordinate this lane's role needs
@@ -111,6 +128,19 @@ C12381_HD void slot_park(fp4& slot, const fp4& r) { slot = r; }
 struct alignas(16) pair_slot { fp4 v; fp psel; int32_t pad[6]; };
 #if defined(__HIP_DEVICE_COMPILE__)
 static_assert(sizeof(pair_slot) == 304, "pair_slot stride");
+// The Fp4 in the slot of the lane that holds role `src_role` of this lane's triple, read straight from LDS: the lanes of a triple are
+// adjacent lanes of one wavefront and their slots adjacent records (19 rows of 16 bytes apart), a wavefront's LDS accesses are served in
+// program order, and the value was stored by the same instruction stream earlier — 14 ds_read_b128 where a register shuffle of the
+// same Fp4 is 56 ds_bpermute_b32 (24 issue cycles each, profiles/r03_issue_mix.txt).  The slot must be an element of a pair_slot array
+// indexed by the lane (every kernel's is).
+C12381_HD void slot_load_role(fp4& r, const fp4& slot, int src_role, const tri& t) {
+    slot_rd(r, (const c12381_lds_v4i*)(&slot) + 19 * (src_role - t.role));
+}
+#else
+// host simulation: the three threads of a triple exchange their slot contents through the mailbox
+inline void slot_load_role(fp4& r, const fp4& slot, int src_role, const tri& t) { fp4 tmp; c12381_tri_exchange(&tmp, &slot, sizeof(fp4), src_role, t); r = tmp; }
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
 C12381_HD void slot_psel_store(fp4& slot, const fp& v) {       // 4 rows: 14 dwords + 2 of the pad
     c12381_lds_v4i* p = (c12381_lds_v4i*)(&slot) + 14;
 #pragma unroll
@@ -161,6 +191,42 @@ C12381_HD fp4& m3r_slot(const miller3_regs& r) { return *r.F; }
 #endif
 
 // ------------------------------------------------------------------ inlined Fp4 cores (operands stay in registers)
+// A/B switches of the round-4 injection forms (tools/build_variant.sh -DC12381_INJ_x=0|1).  Defaults by measurement, one session, every
+// digest equal (profiles/r04_ab_injection_switches.txt): the injected forms of the Fp4 product / squaring and of the generic line
+// product issue 1-3 % fewer instructions but 2-4 % MORE multiply-adds, and the Miller loop came out 1.2 % slower with the line form on
+// (8.88 vs 8.99 ms; its fused iteration spilled 130 instead of 91 dwords), the pairing 1.4 % slower with all three on — so they are OFF;
+// the line product against a normalised table entry (f12t_mul_line1_core) loses its weak reduction and is ON (BBS+ -0.7 %), like the
+// cyclotomic squaring (f12t_usqr3_h: fexp -3.7 %, pairing -3.4 %) and the G1 formulas (g1.hpp: G1 -0.6 %, MSM -0.8 %).
+#ifndef C12381_INJ_MUL
+#define C12381_INJ_MUL 0
+#endif
+#ifndef C12381_INJ_LINE
+#define C12381_INJ_LINE 0
+#endif
+#ifndef C12381_INJ_LINE1
+#define C12381_INJ_LINE1 1
+#endif
+#if C12381_INJ_MUL
+// w = x y = (x.a y.a + xi t2) + ((x.a + x.b)(y.a + y.b) - x.a y.a - t2) s,  t2 = x.b y.b  (FP4_mul :274-304).  t2 is reduced first and
+// injected: w.a = x.a y.a + xi t2 directly, and since x.a y.a = w.a - xi t2 the middle term is (x.a + x.b)(y.a + y.b) - w.a + (xi - 1) t2
+// with xi - 1 = i — both coordinates leave their reductions normalised (no lazy sums, no carry round: -168 instructions, +112 of them
+// multiply-adds by +-1).
+C12381_HD void fp4_mul_core(fp4& w, const fp4& x, const fp4& y) {
+    const int32_t c1 = fp_opaque_const(1), cm1 = fp_opaque_const(-1);
+    fp2 t2, sx, sy, wa, wb;
+    fp2_mul(t2, x.b, y.b);
+    fp2_mul_inj(wa, x.a, y.a, [&](int i, int64_t& acc) { fp_inj(acc, t2.a, i, c1); fp_inj(acc, t2.b, i, cm1); },
+                [&](int i, int64_t& acc) { fp_inj(acc, t2.a, i, c1); fp_inj(acc, t2.b, i, c1); },
+                C12381_INJB(t2.a.vb + t2.b.vb, t2.a.lb + t2.b.lb), C12381_INJB(t2.a.vb + t2.b.vb, t2.a.lb + t2.b.lb));
+    fp2_add(sx, x.a, x.b);
+    fp2_add(sy, y.a, y.b);
+    fp2_mul_inj(wb, sx, sy, [&](int i, int64_t& acc) { fp_inj(acc, wa.a, i, cm1); fp_inj(acc, t2.b, i, cm1); },
+                [&](int i, int64_t& acc) { fp_inj(acc, wa.b, i, cm1); fp_inj(acc, t2.a, i, c1); },
+                // value: -w.a + i t2 = -(t1' + xi t2) + i t2 = -t1' - t2 exactly (t1' = the reduced x.a y.a inside w.a): the bound of the old lazy form
+                C12381_INJB(wa.a.vb - t2.b.vb, wa.a.lb + t2.b.lb), C12381_INJB(wa.b.vb - t2.a.vb, wa.b.lb + t2.a.lb));
+    w.a = wa; w.b = wb;
+}
+#else
 C12381_HD void fp4_mul_core(fp4& w, const fp4& x, const fp4& y) {
     fp2 t1, t2, t3, t4;
     fp2_mul(t1, x.a, y.a);
@@ -175,6 +241,7 @@ C12381_HD void fp4_mul_core(fp4& w, const fp4& x, const fp4& y) {
     fp2_norm1(w.b, t4);
     fp2_norm1(w.a, t3);
 }
+#endif
 // the same without the final carry round (limbs up to 3 * 2^28): for a product that only enters a difference which is
 // carried afterwards (the Karatsuba middle term)
 C12381_HD void fp4_mul_core_raw(fp4& w, const fp4& x, const fp4& y) {
@@ -313,6 +380,114 @@ C12381_HDN void f12t_usqr_h(fp4& H, bool reduce, const tri& t) {
     f12t_usqr_tail(r, q, x, reduce, t);
     slot_store(H, r);
 }
+// ------------------------------------------------------------------ the cyclotomic squaring of the exponentiation loops (round 4)
+// Scaled representation: the slot holds y = 3 x.  Granger-Scott's x <- 3 x^2 - 2 conj(x) becomes  y <- y^2 - 2 conj(y)  (an identity of
+// polynomials, so it reproduces FP12_usqr on ANY input, unitary or not — f12t_pow_generic relies on that): no tripling.  The scale
+// survives a product with an unscaled operand (3h * a = 3 (h a)); the exponentiation routines enter with f12t_scale3_h and leave
+// with f12t_unscale3_h.
+// Per lane, with ys the coefficient this lane's OUTPUT needs squared (role a: its own; roles b and c: each other's, read from the
+// partner's slot) and y its own coefficient, u = ys.a, v = ys.b in Fp2, t3 = u v, Q0 = u^2 + xi v^2 = (u + v)(u + xi v) - (1 + xi) t3:
+//   roles a, c:  w.a = Q0 - 2 y.a,       w.b = 2 t3 + 2 y.b
+//   role b:      w.a = xi 2 t3 + 2 y.a,  w.b = Q0 - 2 y.b          (w_b = 3 s c^2 + 2 conj(b): s (Q0 + 2 t3 s) = 2 xi t3 + Q0 s)
+// Both Fp2 values come out of reductions with their linear terms injected (fp_reduce_cols_inj), already normalised:
+//   S = t3 + mu y.b - q p             mu = 1 (roles a, c) | 0 (role b);   2 S is w.b of roles a, c
+//   V = (u + v)(u + xi v) - (1 + xi)(S - mu y.b) + lambda - q' p,   lambda = -2 y.a | -2 y.b:  w.a of roles a, c, w.b of role b
+// (the mu y.b inside S cancels exactly in V: the identity is one of integers), and the remaining value — 2 S, or 2 (xi S + y.a - q'' p) on
+// role b — is one exactly carried linear combination (fp_lincomb3p).  Every "- q p" takes the multiple of p nearest to the linear
+// terms out again, so the value bound of y stays below 5.2 for ever: no weak reduction, no carry round, no select, no register
+// shuffle (the old form: 3 q +- 2 conj(x) assembled from lazy sums behind two carry rounds, a weak reduction every second call, 56
+// ds_bpermute and ~170 selects; 3 906 -> ~3 450 vector instructions per call, 315 calls per pairing).
+C12381_HD void fp4_scale3(fp4& r, const fp4& x) {          // 3 x, weakly reduced: |value| < 1.6 p whatever came in
+    fp4 t;
+    fp4_add(t, x, x); fp4_add(t, t, x);
+    fp4_weak_reduce(r, t);
+}
+C12381_HD void fp4_unscale3(fp4& r, const fp4& y) {        // y / 3
+    fp inv3;
+    fp_set_const(inv3, FP_INV3);
+    fp_mul(r.a.a, y.a.a, inv3); fp_mul(r.a.b, y.a.b, inv3); fp_mul(r.b.a, y.b.a, inv3); fp_mul(r.b.b, y.b.b, inv3);
+}
+C12381_HD void f12t_scale3_h(fp4& H) { fp4 x, y; slot_load(x, H); fp4_scale3(y, x); slot_store(H, y); }
+C12381_HD void f12t_unscale3_h(fp4& H) { fp4 x, y; slot_load(y, H); fp4_unscale3(x, y); slot_store(H, x); }
+#if defined(__HIP_DEVICE_COMPILE__)
+C12381_HD int32_t lane_opaque(int32_t v) { asm("" : "+v"(v)); return v; }     // a per-lane multiplier the optimiser must not fold into selects
+#else
+C12381_HD int32_t lane_opaque(int32_t v) { return v; }
+#endif
+C12381_HDN void f12t_usqr3_h(fp4& H, const tri& t) {
+    const bool r1 = t.role == 1;
+    // multipliers of the injected terms: constants in SGPRs, role-dependent ones in VGPRs (multiply-add operands, not selects)
+    const int32_t c1 = fp_opaque_const(1), cm1 = fp_opaque_const(-1), cm2 = fp_opaque_const(-2);
+    const int32_t mu = lane_opaque(r1 ? 0 : 1);
+    const int32_t a1 = lane_opaque(r1 ? -2 : 2), a2 = lane_opaque(r1 ? 0 : -1), a3 = lane_opaque(r1 ? 0 : -2);
+    const int32_t b1 = lane_opaque(r1 ? 0 : 1), b2 = lane_opaque(r1 ? -2 : 2), b3 = a3;
+    fp2 S, V;
+    fp2 t1, t2;
+    {
+        fp4 ys;
+        slot_load_role(ys, H, t.role == 0 ? 0 : (r1 ? 2 : 1), t);
+        C12381_BOUNDS({ const fp* c4[4] = {&ys.a.a, &ys.a.b, &ys.b.a, &ys.b.b};
+                        for (const fp* c : c4) { if (c->vb > 200.0 || c->lb > 268435456.0 + 64) bounds_fail("f12t_usqr3_h input", c->vb, c->lb); } })
+        {   // S = ys.a * ys.b + mu y.b - q p
+            fp2 yb;
+            slot_load_half(yb, H, 1);
+            fp nab;
+            fp_raw_neg(nab, ys.a.b);
+            const int32_t nq_re = -fp_quot_top(mu * yb.a.l[NL - 1]), nq_im = -fp_quot_top(mu * yb.b.l[NL - 1]);
+            fp_reduce_cols_inj(S.a, [&](int k, int64_t& acc) { fp_col_acc(acc, ys.a.a, ys.b.a, k); fp_col_acc(acc, nab, ys.b.b, k); },
+                               [&](int i, int64_t& acc) { fp_inj(acc, yb.a, i, mu); fp_inj_p(acc, i, nq_re); });
+            fp_reduce_cols_inj(S.b, [&](int k, int64_t& acc) { fp_col_acc(acc, ys.a.a, ys.b.b, k); fp_col_acc(acc, ys.a.b, ys.b.a, k); },
+                               [&](int i, int64_t& acc) { fp_inj(acc, yb.b, i, mu); fp_inj_p(acc, i, nq_im); });
+            // |mu y.b - q p| <= (0.5 + 2 / 106513 + 1e-5 |y.b| / p) p: the nearest multiple of p by the top limb (fp_quot_top)
+            C12381_BOUNDS({ set_inj_bounds(S.a, ys.a.a.lb * ys.b.a.lb + ys.a.b.lb * ys.b.b.lb, ys.a.a.vb * ys.b.a.vb + ys.a.b.vb * ys.b.b.vb, 0.501,
+                                           yb.a.lb + 8.0 * 268435456.0, "usqr3 S.a"); check_actual_vb(S.a, "usqr3 S.a value");
+                            set_inj_bounds(S.b, ys.a.a.lb * ys.b.b.lb + ys.a.b.lb * ys.b.a.lb, ys.a.a.vb * ys.b.b.vb + ys.a.b.vb * ys.b.a.vb, 0.501,
+                                           yb.b.lb + 8.0 * 268435456.0, "usqr3 S.b"); check_actual_vb(S.b, "usqr3 S.b value"); })
+        }
+        fp2 xv;
+        fp2_add(t1, ys.a, ys.b);                               // u + v: limbs < 2^29
+        fp2_mul_ip(xv, ys.b);
+        fp2_add(xv, ys.a, xv);
+        fp2_norm1(t2, xv);                                     // u + xi v, three terms: carried once
+    }
+    {   // V = t1 t2 - (2 + i)(S - mu y.b) + lambda - q p:   (2 + i)(a + b i) = (2a - b) + (a + 2b) i
+        fp2 ya, yb;
+        slot_load_half(ya, H, 0);
+        slot_load_half(yb, H, 1);
+        fp nt1b;
+        fp_raw_neg(nt1b, t1.b);
+        const int32_t top_re = cm2 * S.a.l[NL - 1] + S.b.l[NL - 1] + a1 * yb.a.l[NL - 1] + a2 * yb.b.l[NL - 1] + a3 * ya.a.l[NL - 1];
+        const int32_t top_im = cm1 * S.a.l[NL - 1] + cm2 * S.b.l[NL - 1] + b1 * yb.a.l[NL - 1] + b2 * yb.b.l[NL - 1] + b3 * ya.b.l[NL - 1];
+        const int32_t nq_re = -fp_quot_top(top_re), nq_im = -fp_quot_top(top_im);
+        fp_reduce_cols_inj(V.a, [&](int k, int64_t& acc) { fp_col_acc(acc, t1.a, t2.a, k); fp_col_acc(acc, nt1b, t2.b, k); },
+                           [&](int i, int64_t& acc) { fp_inj(acc, S.a, i, cm2); fp_inj(acc, S.b, i, c1); fp_inj(acc, yb.a, i, a1); fp_inj(acc, yb.b, i, a2);
+                                                      fp_inj(acc, ya.a, i, a3); fp_inj_p(acc, i, nq_re); });
+        fp_reduce_cols_inj(V.b, [&](int k, int64_t& acc) { fp_col_acc(acc, t1.a, t2.b, k); fp_col_acc(acc, t1.b, t2.a, k); },
+                           [&](int i, int64_t& acc) { fp_inj(acc, S.a, i, cm1); fp_inj(acc, S.b, i, cm2); fp_inj(acc, yb.a, i, b1); fp_inj(acc, yb.b, i, b2);
+                                                      fp_inj(acc, ya.b, i, b3); fp_inj_p(acc, i, nq_im); });
+        // the injected sum minus the nearest multiple of p: eight unit multipliers' worth of low-limb error (8 / 106513) + the estimate's 1e-5
+        C12381_BOUNDS({ const double inj_lb = 3.0 * (S.a.lb + S.b.lb) + 3.0 * (yb.a.lb + yb.b.lb) + 2.0 * (ya.a.lb + ya.b.lb) + 64.0 * 268435456.0;
+                        set_inj_bounds(V.a, t1.a.lb * t2.a.lb + t1.b.lb * t2.b.lb, t1.a.vb * t2.a.vb + t1.b.vb * t2.b.vb, 0.502, inj_lb, "usqr3 V.a");
+                        check_actual_vb(V.a, "usqr3 V.a value");
+                        set_inj_bounds(V.b, t1.a.lb * t2.b.lb + t1.b.lb * t2.a.lb, t1.a.vb * t2.b.vb + t1.b.vb * t2.a.vb, 0.502, inj_lb, "usqr3 V.b");
+                        check_actual_vb(V.b, "usqr3 V.b value"); })
+        // the other output: 2 S on roles a, c;  2 (xi S + y.a - q p) on role b, xi S = (S.a - S.b) + (S.a + S.b) i
+        const int32_t k2 = fp_opaque_const(2);
+        const int32_t e_sb = lane_opaque(r1 ? -2 : 0), e_y = lane_opaque(r1 ? 2 : 0), f_sa = lane_opaque(r1 ? 2 : 0);
+        const int32_t kq_re = -e_y * fp_quot_top(ya.a.l[NL - 1]), kq_im = -e_y * fp_quot_top(ya.b.l[NL - 1]);
+        fp2 U;
+        // |2 S| <= 2 VB(S);   role b: 2 (2 VB(S) + 0.501) with VB(S) of the uninjected form (mu = 0: the 0.501 of the declaration is not there)
+        C12381_BOUNDS(const double sv = S.a.vb > S.b.vb ? S.a.vb : S.b.vb; const double vbu = r1 ? 2.0 * (2.0 * (sv - 0.501) + 0.501) : 2.0 * sv;)
+#ifndef C12381_CHECK_BOUNDS
+        const double vbu = 0;
+#endif
+        fp_lincomb3p(U.a, S.a, k2, S.b, e_sb, ya.a, e_y, kq_re, vbu);
+        fp_lincomb3p(U.b, S.b, k2, S.a, f_sa, ya.b, e_y, kq_im, vbu);
+        // placement by address: V is .a on roles a, c and .b on role b
+        slot_store_half(H, r1 ? 1 : 0, V);
+        slot_store_half(H, r1 ? 0 : 1, U);
+    }
+}
 // FP12_conj :117-123
 C12381_HD void f12t_conj(fp4& w, const fp4& x, const tri& t) {
     fp4 c1, c2;
@@ -367,6 +542,45 @@ C12381_HDN void f12t_inv(fp4& w, const fp4& x, const tri& t) {
     fp4_inv(f3i, f3);
     fp4_mul_core(w, f, f3i);
 }
+#if C12381_INJ_LINE
+// f *= line(l0, l1, l2)  (sparse M-type line, see fp12_mul_line).  One dense-by-sparse product per lane:
+//   x <- x (l0 + l1 s) + (q' xi, q'' xi | q'' xi, q') with q0 = x.a l2, q1 = x.b l2 of the NEXT role — roles a, b add ((1+i) qn0, (1+i) qn1),
+//   role c adds ((1+i) qn1, qn0).
+// Everything that is added to the two coordinates of the Fp4 product is INJECTED into their reductions (fp2_mul_inj): the Karatsuba
+// corrections of the product itself (see fp4_mul_core) and the neighbour's terms with their (1 + i) — the result is normalised as it
+// leaves the reductions: no lazy sums, no carry round.  Role-dependent signs / zeros are multiplier registers.
+C12381_HD void f12t_mul_line_core(fp4& x, const fp2& l0, const fp2& l1, const fp2& l2, const tri& t) {
+    const int32_t c1 = fp_opaque_const(1), cm1 = fp_opaque_const(-1);
+    const bool r2 = t.role == 2;
+    fp2 q0, q1, qn0, qn1;
+    fp2_mul(q0, x.a, l2);
+    fp2_mul(q1, x.b, l2);
+    fp2 t2, sx, sy, wa, wb;
+    fp2_mul(t2, x.b, l1);
+    tri_fetch_fp2(qn0, q0, tri_next(t), t);
+    tri_fetch_fp2(qn1, q1, tri_next(t), t);
+    fp2 pick, other;
+    fp2_select(pick, r2, qn1, qn0);                        // enters .a times (1 + i)
+    fp2_select(other, r2, qn0, qn1);                       // enters .b times (1 + i) on roles a, b; as it is on role c
+    const int32_t o_cross = lane_opaque(r2 ? 0 : 1), o_ncross = lane_opaque(r2 ? 0 : -1);
+    // .a = x.a l0 + xi t2 + xi pick:   xi (a + b i) = (a - b) + (a + b) i
+    fp2_mul_inj(wa, x.a, l0, [&](int i, int64_t& acc) { fp_inj(acc, t2.a, i, c1); fp_inj(acc, t2.b, i, cm1); fp_inj(acc, pick.a, i, c1); fp_inj(acc, pick.b, i, cm1); },
+                [&](int i, int64_t& acc) { fp_inj(acc, t2.a, i, c1); fp_inj(acc, t2.b, i, c1); fp_inj(acc, pick.a, i, c1); fp_inj(acc, pick.b, i, c1); },
+                C12381_INJB(t2.a.vb + t2.b.vb + pick.a.vb + pick.b.vb, t2.a.lb + t2.b.lb + pick.a.lb + pick.b.lb),
+                C12381_INJB(t2.a.vb + t2.b.vb + pick.a.vb + pick.b.vb, t2.a.lb + t2.b.lb + pick.a.lb + pick.b.lb));
+    fp2_add(sx, x.a, x.b);
+    fp2_add(sy, l0, l1);
+    // .b = sx sy - x.a l0 - t2 + (other | xi other);   x.a l0 = wa - xi t2 - xi pick  =>  sx sy - wa + i t2 + xi pick + (other | xi other)
+    fp2_mul_inj(wb, sx, sy, [&](int i, int64_t& acc) { fp_inj(acc, wa.a, i, cm1); fp_inj(acc, t2.b, i, cm1); fp_inj(acc, pick.a, i, c1); fp_inj(acc, pick.b, i, cm1);
+                                                       fp_inj(acc, other.a, i, c1); fp_inj(acc, other.b, i, o_ncross); },
+                [&](int i, int64_t& acc) { fp_inj(acc, wa.b, i, cm1); fp_inj(acc, t2.a, i, c1); fp_inj(acc, pick.a, i, c1); fp_inj(acc, pick.b, i, c1);
+                                           fp_inj(acc, other.b, i, c1); fp_inj(acc, other.a, i, o_cross); },
+                // value: -wa + i t2 + xi pick = -(x.a l0 reduced) - t2 exactly; then the neighbour's term
+                C12381_INJB(wa.a.vb - t2.b.vb - pick.a.vb - pick.b.vb + other.a.vb + other.b.vb, wa.a.lb + t2.b.lb + pick.a.lb + pick.b.lb + other.a.lb + other.b.lb),
+                C12381_INJB(wa.b.vb - t2.a.vb - pick.a.vb - pick.b.vb + other.a.vb + other.b.vb, wa.b.lb + t2.a.lb + pick.a.lb + pick.b.lb + other.a.lb + other.b.lb));
+    x.a = wa; x.b = wb;
+}
+#else
 // f *= line(l0, l1, l2)  (sparse M-type line, see fp12_mul_line).  One dense-by-sparse product per lane.
 C12381_HD void f12t_mul_line_core(fp4& x, const fp2& l0, const fp2& l1, const fp2& l2, const tri& t) {
     fp4 la; la.a = l0; la.b = l1;
@@ -387,6 +601,45 @@ C12381_HD void f12t_mul_line_core(fp4& x, const fp2& l0, const fp2& l1, const fp
     fp2_add(p.b, p.b, ib);
     fp4_norm1(x, p);
 }
+#endif
+#if C12381_INJ_LINE1
+// the same for a line whose s-coefficient is 1 (l1 = 1: the lines of a fixed G2 argument are stored divided by it, see
+// miller_lines_precompute): x (l0 + s) = (xa l0 + (1+i) xb) + (xa + xb l0) s — two Fp2 products instead of Karatsuba's three.
+// x passes through UNMULTIPLIED ((1+i) xb in .a, xa in .b): its value bound would double per line, so each reduction also takes the
+// multiple of p nearest to its injected sum out again (fp_inj_p) — that replaces the weak reduction (~360 instructions) this routine
+// used to end in.
+C12381_HD void f12t_mul_line1_core(fp4& x, const fp2& l0, const fp2& l2, const tri& t) {
+    const int32_t c1 = fp_opaque_const(1), cm1 = fp_opaque_const(-1);
+    const bool r2 = t.role == 2;
+    fp2 q0, q1, qn0, qn1;
+    fp2_mul(q0, x.a, l2);
+    fp2_mul(q1, x.b, l2);
+    tri_fetch_fp2(qn0, q0, tri_next(t), t);
+    tri_fetch_fp2(qn1, q1, tri_next(t), t);
+    fp2 pick, other, wa, wb;
+    fp2_select(pick, r2, qn1, qn0);
+    fp2_select(other, r2, qn0, qn1);
+    const int32_t o_cross = lane_opaque(r2 ? 0 : 1), o_ncross = lane_opaque(r2 ? 0 : -1);
+    // .a = x.a l0 + xi x.b + xi pick - q p
+    const int32_t ta_re = x.b.a.l[NL - 1] - x.b.b.l[NL - 1] + pick.a.l[NL - 1] - pick.b.l[NL - 1];
+    const int32_t ta_im = x.b.a.l[NL - 1] + x.b.b.l[NL - 1] + pick.a.l[NL - 1] + pick.b.l[NL - 1];
+    const int32_t nqa_re = -fp_quot_top(ta_re), nqa_im = -fp_quot_top(ta_im);
+    // .b = x.b l0 + x.a + (other | xi other) - q p
+    const int32_t tb_re = x.a.a.l[NL - 1] + other.a.l[NL - 1] + o_ncross * other.b.l[NL - 1];
+    const int32_t tb_im = x.a.b.l[NL - 1] + other.b.l[NL - 1] + o_cross * other.a.l[NL - 1];
+    const int32_t nqb_re = -fp_quot_top(tb_re), nqb_im = -fp_quot_top(tb_im);
+    // the injected sums minus the nearest multiple of p: at most four unit multipliers of low-limb error (4 / 106513) + the estimate's 1e-5 per p
+    fp2_mul_inj(wa, x.a, l0, [&](int i, int64_t& acc) { fp_inj(acc, x.b.a, i, c1); fp_inj(acc, x.b.b, i, cm1); fp_inj(acc, pick.a, i, c1); fp_inj(acc, pick.b, i, cm1);
+                                                        fp_inj_p(acc, i, nqa_re); },
+                [&](int i, int64_t& acc) { fp_inj(acc, x.b.a, i, c1); fp_inj(acc, x.b.b, i, c1); fp_inj(acc, pick.a, i, c1); fp_inj(acc, pick.b, i, c1);
+                                           fp_inj_p(acc, i, nqa_im); },
+                C12381_INJB(0.502, x.b.a.lb + x.b.b.lb + pick.a.lb + pick.b.lb + 64.0 * 268435456.0), C12381_INJB(0.502, x.b.a.lb + x.b.b.lb + pick.a.lb + pick.b.lb + 64.0 * 268435456.0));
+    fp2_mul_inj(wb, x.b, l0, [&](int i, int64_t& acc) { fp_inj(acc, x.a.a, i, c1); fp_inj(acc, other.a, i, c1); fp_inj(acc, other.b, i, o_ncross); fp_inj_p(acc, i, nqb_re); },
+                [&](int i, int64_t& acc) { fp_inj(acc, x.a.b, i, c1); fp_inj(acc, other.b, i, c1); fp_inj(acc, other.a, i, o_cross); fp_inj_p(acc, i, nqb_im); },
+                C12381_INJB(0.502, x.a.a.lb + other.a.lb + other.b.lb + 64.0 * 268435456.0), C12381_INJB(0.502, x.a.b.lb + other.a.lb + other.b.lb + 64.0 * 268435456.0));
+    x.a = wa; x.b = wb;
+}
+#else
 // the same for a line whose s-coefficient is 1 (l1 = 1: the lines of a fixed G2 argument are stored divided by it, see
 // miller_lines_precompute): x (l0 + s) = (xa l0 + (1+i) xb) + (xa + xb l0) s — two Fp2 products instead of Karatsuba's three
 C12381_HD void f12t_mul_line1_core(fp4& x, const fp2& l0, const fp2& l2, const tri& t) {
@@ -410,6 +663,7 @@ C12381_HD void f12t_mul_line1_core(fp4& x, const fp2& l0, const fp2& l2, const t
     fp2_add(p.b, p.b, ib);
     fp4_weak_reduce(x, p);                                 // x passes through unmultiplied (xa, (1+i) xb): without a reduction its value bound would double per line
 }
+#endif
 C12381_HDN void f12t_mul_line(fp4& x, const fp2& l0, const fp2& l1, const fp2& l2, const tri& t) { f12t_mul_line_core(x, l0, l1, l2, t); }
 C12381_HDN void f12t_mul_line_h(fp4& H, const fp2& l0, const fp2& l1, const fp2& l2, const tri& t) {
     fp4 x;
@@ -420,16 +674,23 @@ C12381_HDN void f12t_mul_line_h(fp4& H, const fp2& l0, const fp2& l1, const fp2&
 // h <- a^x for unitary a, x < 0, computed IN the LDS slot h: the 63 squarings and 5 products move the running value with LDS
 // instructions only; `a` is read from wherever it lives (private memory in the kernels), never written.
 C12381_HDN void f12t_pow_x(fp4& h, const fp4& a, const tri& t) {
-    {
-        fp4 av = a;
-        slot_store(h, av);
+    {   // the running value is kept as y = 3 h (f12t_usqr3_h); a stays as it is: 3h * a = 3 (h a)
+        fp4 av = a, y;
+        fp4_scale3(y, av);
+        slot_store(h, y);
     }
 #pragma unroll 1
     for (int i = 62; i >= 0; --i) {
-        f12t_usqr_h(h, (i & 1) == 0, t);
+        f12t_usqr3_h(h, t);
         if ((BLS_X >> i) & 1ull) f12t_mul_h(h, a, t);
     }
-    f12t_conj_h(h, t);
+    {
+        fp4 y, x, c;
+        slot_load(y, h);
+        fp4_unscale3(x, y);
+        f12t_conj(c, x, t);
+        slot_store(h, c);
+    }
 }
 // PAIR_fexp :629-755 as six steps (the work-queue kernels schedule them as separate tasks; state between steps: r, y1
 // and — after step 4 — aux).  `h` is this lane's LDS slot: every product is h <- h * (operand in private memory).
@@ -497,10 +758,14 @@ C12381_HDN void f12t_pow_generic(fp4& H, const uint32_t (&e)[8], const tri& t) {
     slot_load(a, H);
     f12t_conj(ac, a, t);
     f12t_one(one, t);
-    slot_store(H, one);
+    {   // the accumulator in the scaled form 3 * acc (f12t_usqr3_h): y <- y^2 - 2 conj(y) is FP12_usqr's polynomial on any input
+        fp4 y;
+        fp4_scale3(y, one);
+        slot_store(H, y);
+    }
 #pragma unroll 1
     for (int i = 257; i >= 1; --i) {
-        f12t_usqr_h(H, true, t);
+        f12t_usqr3_h(H, t);
         const int b3 = (int)((e3[i >> 5] >> (i & 31)) & 1u);
         const int b1 = i < 256 ? (int)((e[i >> 5] >> (i & 31)) & 1u) : 0;
         const int bt = b3 - b1;
@@ -509,6 +774,7 @@ C12381_HDN void f12t_pow_generic(fp4& H, const uint32_t (&e)[8], const tri& t) {
         fp4_select(m, bt == 0, one, m);
         f12t_mul_h(H, m, t);
     }
+    f12t_unscale3_h(H);
 }
 // FP12_isunity: every lane tests its own coefficient, the verdict is combined over the triple
 C12381_HD bool f12t_is_one(const fp4& x, const tri& t) {

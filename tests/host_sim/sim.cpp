@@ -410,7 +410,26 @@ extern "C" int sim_g1_msm_pippenger(size_t n, const uint8_t* pts96, const uint8_
     for (size_t i = 0; i < n; ++i) {
         uint32_t rp[24], rs[8];
         load_raw(rp, pts96 + 96 * i, 24); load_raw(rs, scalars32 + 32 * i, 8);
-        if (!msm_prep_one(i, n, rp, rs, c, W, pts2, keys.data(), vals.data())) return -3;
+        if (!msm_prep_one<uint32_t>(i, n, rp, rs, c, W, pts2, keys.data(), vals.data())) return -3;
+    }
+    {   // the large-product form (16-bit digit keys, positional values) describes the same entries
+        std::vector<uint16_t> k16(E);
+        std::vector<int32_t> p2((size_t)2 * n * MSM_PT_STRIDE + 4);
+        int32_t* p2a = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(p2.data()) + 15) & ~(uintptr_t)15);
+        if (c <= 16) {
+            for (size_t i = 0; i < n; ++i) {
+                uint32_t rp[24], rs[8];
+                load_raw(rp, pts96 + 96 * i, 24); load_raw(rs, scalars32 + 32 * i, 8);
+                if (!msm_prep_one<uint16_t>(i, n, rp, rs, c, W, p2a, k16.data(), nullptr)) return -3;
+            }
+            for (int w = 0; w <= W; ++w) {
+                const size_t seg = (size_t)2 * w * n, len = w < W ? 2 * n : n;
+                for (size_t x = 0; x < len; ++x) {
+                    if (k16[seg + x] != (keys[seg + x] & ((1u << c) - 1u))) return -4;
+                    if (msm_entry_value((uint32_t)x, (uint32_t)n) != vals[seg + x]) return -5;
+                }
+            }
+        }
     }
     std::vector<size_t> order(E);
     for (size_t j = 0; j < E; ++j) order[j] = j;

@@ -169,6 +169,7 @@ def main():
     out.append(arr("FP_B3", mont(12), comment="3*b = 12 (G1), Montgomery form"))
     out.append(arr("FP_FOUR", mont(4), comment="b = 4"))
     out.append(arr("FP_HALF", mont(pow(2, -1, P)), comment="1/2"))
+    out.append(arr("FP_INV3", mont(pow(3, -1, P)), comment="1/3: leaves the scaled representation y = 3 x of the cyclotomic squarings (pairing3.hpp)"))
     # cube roots of unity: beta with beta^2+beta+1 = 0 mod p
     g = 2
     while True:
