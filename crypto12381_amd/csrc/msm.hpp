@@ -31,9 +31,9 @@ constexpr int MSM_PT_DWORDS = 2 * NL;          // affine (x, y) in Montgomery fo
 #endif
 constexpr int MSM_PT_STRIDE = C12381_MSM_PT_STRIDE;
 #ifndef C12381_MSM_CHUNK
-#define C12381_MSM_CHUNK 16
+#define C12381_MSM_CHUNK 8
 #endif
-constexpr int MSM_CHUNK = C12381_MSM_CHUNK;    // buckets per lane in the window reduction (A/B: -DC12381_MSM_CHUNK=8)
+constexpr int MSM_CHUNK = C12381_MSM_CHUNK;    // buckets per lane in the window reduction (8: measured 1.1 % faster than 16 at 2^22 terms, profiles/r04_ab_msm_front.txt; -DC12381_MSM_CHUNK=16 for the A/B)
 // entries a bucket lane sums at most: twice the mean run + 32 (uniform scalars: mean + 11 sigma or more, so nothing is
 // cut); the rest of a longer run is cut into overflow segments of half that length, one lane each (k_g1.hip).  A lane
 // with a long run finishes alone at single-wavefront latency (~9 us per addition), hence a cap relative to the mean.

@@ -306,7 +306,11 @@ C12381_HDN void f12t_mul_h(fp4& H, const fp4& y, const tri& t) {
             fp4 x, yv, xn, yn;
             slot_load(x, H);
             yv = y;
+#if C12381_SLOT_NEIGHBOUR
+            slot_load_role(xn, H, tri_next(t), t);
+#else
             tri_fetch_fp4(xn, x, tri_next(t), t);
+#endif
             tri_fetch_fp4(yn, yv, tri_next(t), t);
             fp4_addn(sx, x, xn); fp4_addn(sy, yv, yn);
         }
@@ -335,9 +339,15 @@ C12381_HDN void f12t_mul_h(fp4& H, const fp4& y, const tri& t) {
     slot_store(H, w);
 }
 // w = x^2 (FP12_sqr :190-238 as six squarings: z_r = x_r^2, (x_r + x_{r+1})^2).
-C12381_HD void f12t_sqr_body(fp4& w, const fp4& x, const tri& t) {
+// C12381_SLOT_NEIGHBOUR (A/B, round 4): where the value whose neighbour coefficient is needed sits in the LDS slots, the neighbour's is
+// read straight from ITS slot (slot_load_role: 14 ds_read_b128) instead of being shuffled out of registers (56 ds_bpermute_b32)
+#ifndef C12381_SLOT_NEIGHBOUR
+#define C12381_SLOT_NEIGHBOUR 1
+#endif
+template <bool FROM_SLOT>
+C12381_HD void f12t_sqr_body_t(fp4& w, const fp4& x, const fp4& H, const tri& t) {
     fp4 xn, z, zc, zn, e, sx;
-    tri_fetch_fp4(xn, x, tri_next(t), t);
+    if (FROM_SLOT) slot_load_role(xn, H, tri_next(t), t); else tri_fetch_fp4(xn, x, tri_next(t), t);
     fp4_sqr_core(z, x);
     fp4_add(sx, x, xn);                                    // limbs < 2^29 + slack: within the operand bound of the Fp2 products (host simulation asserts it)
     fp4_sqr_core_raw(zc, sx);                           // un-normalised: zc only enters e, which gets its own carry round
@@ -345,8 +355,9 @@ C12381_HD void f12t_sqr_body(fp4& w, const fp4& x, const tri& t) {
     fp4_sub(e, zc, z); fp4_sub(e, e, zn); fp4_norm1(e, e);
     f12t_combine(w, z, zn, e, t);
 }
+C12381_HD void f12t_sqr_body(fp4& w, const fp4& x, const tri& t) { f12t_sqr_body_t<false>(w, x, x, t); }
 C12381_HDN void f12t_sqr(fp4& w, const fp4& x, const tri& t) { fp4 xv = x, r; f12t_sqr_body(r, xv, t); w = r; }      // w may alias x
-C12381_HDN void f12t_sqr_h(fp4& H, const tri& t) { fp4 x, r; slot_load(x, H); f12t_sqr_body(r, x, t); slot_store(H, r); }
+C12381_HDN void f12t_sqr_h(fp4& H, const tri& t) { fp4 x, r; slot_load(x, H); f12t_sqr_body_t<C12381_SLOT_NEIGHBOUR != 0>(r, x, H, t); slot_store(H, r); }
 // Granger-Scott unitary squaring (FP12_usqr :147-186): one Fp4 squaring per lane.
 //   w_a = 3 xa^2 - 2 conj(xa),  w_b = 3 s xc^2 + 2 conj(xb),  w_c = 3 xb^2 - 2 conj(xc)
 C12381_HD void f12t_usqr_tail(fp4& w, const fp4& q, const fp4& x, bool reduce, const tri& t) {
@@ -873,7 +884,11 @@ C12381_HD void miller3_iter_body(fp2& tc, fp4& F, int info) {
         {
             fp4 x, xn, sx;
             slot_load(x, F);
+#if C12381_SLOT_NEIGHBOUR
+            slot_load_role(xn, F, tri_next(t), t);
+#else
             tri_fetch_fp4(xn, x, tri_next(t), t);
+#endif
             fp4_add(sx, x, xn);                            // limbs < 2^29 + slack: within the operand bound of the Fp2 products
             C12381_PHASE();
             fp4_sqr_core_raw(zc, sx);                           // un-normalised: zc only enters e, which gets its own carry round
