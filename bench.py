@@ -274,6 +274,7 @@ def main():
 
     def timed(fn, steps, warmup):
         """W untimed + K timed steps bracketed by barrier + synchronize; MAX over ranks."""
+        torch.cuda.synchronize(dev)                         # inputs produced by torch kernels on torch's stream are complete before the library reads them
         for _ in range(warmup):
             fn()
         torch.cuda.synchronize(dev)
@@ -345,7 +346,8 @@ def main():
         p1 = pts[: npair * 96] if npair <= n else pts.repeat((npair + n - 1) // n)[: npair * 96].contiguous()
         torch.cuda.synchronize(dev)
         ctx.g2_mul_fixed_dev(npair, gen2.data_ptr(), t_sc.data_ptr(), q2.data_ptr(), 192)   # Q_i = G2^{t_i} (untimed)
-        ctx.sync()
+        if ctx.sync() != 0:
+            raise SystemExit("bench: the fixed-base G2 multiplication reported an invalid point")
         for _ in range(max(1, args.warmup)):
             ctx.pair_dev(npair, p1.data_ptr(), q2.data_ptr(), gt.data_ptr())
         torch.cuda.synchronize(dev)
@@ -353,6 +355,8 @@ def main():
         pel = timed(lambda: ctx.pair_dev(npair, p1.data_ptr(), q2.data_ptr(), gt.data_ptr()), max(1, args.steps), 0)
         pk_ms, pk_launches = ctx.profile_read(3)
         ctx.profile(False)
+        if ctx.sync() != 0:
+            raise SystemExit("bench: invalid input reported by the pairing kernel")
         probe_clock("pair", lambda: ctx.pair_dev(npair, p1.data_ptr(), q2.data_ptr(), gt.data_ptr()))
         pair = {"npair": npair, "steps": max(1, args.steps), "elapsed": pel, "kernel_ms": pk_ms, "launches": pk_launches,
                 "p1": p1, "q2": q2, "gt": gt}
@@ -370,8 +374,15 @@ def main():
         g2_out = torch.empty(ng2 * 192, dtype=torch.uint8, device=dev)
         mil = torch.empty(npair * 576, dtype=torch.uint8, device=dev)
         fex = torch.empty(npair * 576, dtype=torch.uint8, device=dev)
+        # g2_in may be the output of a torch kernel (repeat / contiguous) on torch's current stream, the library enqueues on ITS stream: without
+        # this the first launch can read g2_in before it is written — seen as "invalid input" on one of three 2-rank runs sharing a GPU
+        torch.cuda.synchronize(dev)
         ctx.g2_mul_dev(ng2, g2_in.data_ptr(), g2_sc.data_ptr(), g2_out.data_ptr(), 192)
+        if ctx.sync() != 0:
+            raise SystemExit("bench: invalid input reported by the G2 multiplication kernel")
         ctx.miller_dev(npair, pair["p1"].data_ptr(), pair["q2"].data_ptr(), mil.data_ptr())
+        if ctx.sync() != 0:
+            raise SystemExit("bench: invalid input reported by the Miller-loop kernel")
         ctx.gt_op_dev("fexp", npair, mil.data_ptr(), None, fex.data_ptr())
         torch.cuda.synchronize(dev)
         ctx.profile(True)
@@ -401,6 +412,7 @@ def main():
         ms_ = torch.from_numpy(ms_h).to(dev)
         mo_ = torch.empty(96, dtype=torch.uint8, device=dev)
         msteps = min(max(1, args.steps), 5)
+        torch.cuda.synchronize(dev)                         # mp_ may come from a torch kernel on torch's stream
         ctx.g1_msm_dev(nm, mp_.data_ptr(), ms_.data_ptr(), mo_.data_ptr(), 96)
         torch.cuda.synchronize(dev)
         ctx.profile(True)
@@ -422,6 +434,7 @@ def main():
             gfull = gpts.repeat(reps).contiguous()[: nm * 96] if reps > 1 else gpts[: nm * 96]
             lo, hi = shard_bounds(nm, rank, world)
             sp_, ss_ = gfull[96 * lo:96 * hi], torch.from_numpy(gs_h[lo:hi]).to(dev)
+            torch.cuda.synchronize(dev)
 
             def local_t(p, s, fmt):
                 o = torch.empty(fmt, dtype=torch.uint8, device=dev)
@@ -492,6 +505,7 @@ def main():
         dA, dx, dr, dm = (torch.from_numpy(a).to(dev) for a in (A_h, xs_h, rs_h, mm_h))
         dpub = [dev_bytes(b, dev) for b in (pub_g1, g2p, pub_h0, pub_h, w)]
         okb = torch.empty(nb, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize(dev)
 
         def bbs_step(count=nb, A=dA, x=dx, r=dr, m=dm, ok=okb):
             ctx.bbs_plus_verify_dev(count, 1, dpub[0].data_ptr(), dpub[1].data_ptr(), dpub[2].data_ptr(), dpub[3].data_ptr(), dpub[4].data_ptr(),
@@ -515,6 +529,7 @@ def main():
         # pp.h (49 B each), pk (97 B), signatures A || x || r as 49 + 48 + 48 B, raw messages.  Serialized on the device, untimed.
         one32 = torch.zeros(nb, 32, dtype=torch.uint8, device=dev); one32[:, 31] = 1
         A49 = torch.empty(nb * 49, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize(dev)                         # one32 was filled by torch kernels
         ctx.g1_mul_flags_dev(nb, dA.data_ptr(), one32.data_ptr(), A49.data_ptr(), 49, 1)           # 1 x A in the compressed form (C12381_F_IN_SUBGROUP)
         sig = torch.zeros(nb, 145, dtype=torch.uint8, device=dev)
         ctx.sync()
@@ -526,6 +541,7 @@ def main():
         draw = torch.from_numpy(raw_h).to(dev)
         okw = torch.empty(nb, dtype=torch.uint8, device=dev)
         del one32, A49
+        torch.cuda.synchronize(dev)                         # sig was assembled by torch kernels on torch's stream
 
         def wire_step():
             ctx.bbs_plus_verify_wire_dev(nb, 1, BBS_MSG_LEN, dwire[0].data_ptr(), dwire[1].data_ptr(), dwire[2].data_ptr(), sig.data_ptr(), draw.data_ptr(),
@@ -544,6 +560,7 @@ def main():
             lo, hi = shard_bounds(nb, rank, world)
             sA, sx, sr, sm = (torch.from_numpy(np.ascontiguousarray(a[lo:hi])).to(dev) for a in (gA, gx, gr, gm))
             sok = torch.empty(max(hi - lo, 1), dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize(dev)
             sel = timed(lambda: bbs_step(hi - lo, sA, sx, sr, sm, sok), bsteps, 1)
             ctx.sync()
             cnt = torch.tensor([int(sok[: hi - lo].sum().item())], dtype=torch.int64, device=comm_dev)

@@ -135,6 +135,28 @@ def test_msm_bucket_method_vs_naive_and_oracle(ctx, oracle_port):
     assert ctx.g1_msm(off * reps, osc * reps, 96) == oracle_port.g1_msm(off * reps, osc * reps, 96, 16)
 
 
+def test_msm_large_product_path_vs_oracle(ctx, oracle_port):
+    """From 2^15 terms on the product sorts 16-bit digit keys per window segment with positional values (c12381_hip.hip, msm.hpp
+    msm_entry_value / msm_ranges_seg); below that one sort over 32-bit keys.  Both sides of the switch against the oracle's chain of
+    multiply() results, with the inputs that take the special routes: infinity, zero and small scalars (the [r]phi(S) bucket), points
+    outside the subgroup, a run of equal scalars long enough to be cut into overflow segments."""
+    g = golden("g1")
+    g1 = bytes.fromhex(g["generator"])
+    for n in ((1 << 15) - 1, (1 << 15) + 3):
+        base = ctx.g1_mul(g1 * 4096, scalars(641, 4096), 96)
+        pts = bytearray((base * (n // 4096 + 1))[:96 * n])
+        sc = bytearray(scalars(642 + n, n, 1 << 256))
+        pts[96 * 5:96 * 6] = bytes(96)                                        # infinity
+        sc[32 * 9:32 * 10] = bytes(32)                                        # zero scalar
+        off, osc = cat(g["offsubgroup_small_points"]), cat(g["offsubgroup_small_scalars"])
+        m = len(off) // 96
+        pts[96 * 100:96 * (100 + m)] = off; sc[32 * 100:32 * (100 + m)] = osc  # small scalars on points outside G1
+        eq = scalars(643, 1)
+        sc[32 * 2000:32 * 3000] = eq * 1000                                   # 1000 equal scalars: one long run per window
+        got = ctx.g1_msm(bytes(pts), bytes(sc), 96)
+        assert got == oracle_port.g1_msm(bytes(pts), bytes(sc), 96, 16), n
+
+
 def test_msm_skewed_scalars(ctx, oracle_port):
     """Scalars that put thousands of terms into one bucket (all equal, all small, 128-bit, one giant value among zeros):
     runs longer than the per-lane cap are cut into overflow segments and recombined — same point as the oracle's sum."""
