@@ -3,7 +3,7 @@
 // routine: wall time, SIMD cycles per call (at the clock the chip held, measured with s_memtime / s_memrealtime) — to be
 // compared with the static instruction mix of the routine (tools/isa_stats.py): issue cycles vs stall cycles.
 //
-// Build:  hipcc -O3 --offload-arch=gfx950 -std=c++17 -fno-optimize-sibling-calls -mllvm -amdgpu-sched-strategy=max-ilp pair_routines.hip -o pair_routines
+// Build:  hipcc -O3 --offload-arch=gfx950 -std=c++17 -fno-optimize-sibling-calls -mllvm -amdgpu-sched-strategy=max-ilp -mllvm -opt-disable=reassociate pair_routines.hip -o pair_routines
 // Run:    ./pair_routines [waves_per_simd=2] [iters=200]
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -60,6 +60,7 @@ __global__ void __launch_bounds__(BLOCK, PR_WAVES) routine_kernel(int iters, con
         if constexpr (KIND == 0) f12t_sqr_h(H, t);
         else if constexpr (KIND == 1) miller3_dbl_line(H, tc, px, py, false, t);
         else if constexpr (KIND == 2) f12t_usqr_h(H, (it & 1) == 0, t);
+        else if constexpr (KIND == 16) f12t_usqr3_h(H, t);                                       // round 4: scaled form, injected linear terms
         else if constexpr (KIND == 3) f12t_mul_h(H, a, t);
         else if constexpr (KIND == 10) { fp4 w; f12t_mul(w, a, a, t); a = w; }
         else if constexpr (KIND == 4) f12t_mul_line_h(H, tc, a.a, a.b, t);
@@ -139,6 +140,7 @@ int main(int argc, char** argv) {
     if (run<14>("range2_fixed raw", iters / 20, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
     if (run<15>("range2_fixed l1 = 1", iters / 20, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
     if (run<2>("f12t_usqr_h", iters * 2, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
+    if (run<16>("f12t_usqr3_h", iters * 2, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
     if (run<3>("f12t_mul_h (LDS)", iters, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
     if (run<10>("f12t_mul (private)", iters, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
     if (run<4>("f12t_mul_line_h", iters, blocks, d_seed, d_sink, d_stamps, wps)) return 1;
