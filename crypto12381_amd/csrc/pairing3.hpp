@@ -134,7 +134,8 @@ static_assert(sizeof(pair_slot) == 304, "pair_slot stride");
 // same Fp4 is 56 ds_bpermute_b32 (24 issue cycles each, profiles/r03_issue_mix.txt).  The slot must be an element of a pair_slot array
 // indexed by the lane (every kernel's is).
 C12381_HD void slot_load_role(fp4& r, const fp4& slot, int src_role, const tri& t) {
-    slot_rd(r, (const c12381_lds_v4i*)(&slot) + 19 * (src_role - t.role));
+    const int delta = t.base == 63 ? 0 : src_role - t.role;        // lane 63 (no triple of its own, results discarded) stays inside its own record
+    slot_rd(r, (const c12381_lds_v4i*)(&slot) + 19 * delta);
 }
 #else
 // host simulation: the three threads of a triple exchange their slot contents through the mailbox
