@@ -88,7 +88,13 @@ C12381_HD void msm_store_pt(int32_t* dst, const fp& x, const fp& y) {
 }
 C12381_HD void msm_load_pt(fp& x, fp& y, const int32_t* src) {
     int32_t w[MSM_PT_DWORDS];
+#if defined(__HIP_DEVICE_COMPILE__) && (!defined(C12381_EXPLICIT_AS) || C12381_EXPLICIT_AS)
+    // the records live in global memory (point array of the MSM, line tables of a fixed G2 argument): said explicitly, because an
+    // out-of-line routine sees a generic pointer and would use flat loads, whose every wait is a full vmcnt(0) + lgkmcnt(0) drain
+    const __attribute__((address_space(1))) q4* s = (const __attribute__((address_space(1))) q4*)(const void*)src;
+#else
     const q4* s = reinterpret_cast<const q4*>(src);
+#endif
 #pragma unroll
     for (int i = 0; i < MSM_PT_DWORDS / 4; ++i) { q4 t = s[i]; w[4 * i] = t.v[0]; w[4 * i + 1] = t.v[1]; w[4 * i + 2] = t.v[2]; w[4 * i + 3] = t.v[3]; }
 #pragma unroll

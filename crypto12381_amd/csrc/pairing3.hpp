@@ -299,6 +299,22 @@ C12381_HDN void f12t_mul(fp4& w, const fp4& x, const fp4& y, const tri& t) {
 // budget (x has been read back from the slot by then), and read back for the combination.  f12t_mul exchanges
 // its operands and both products with the out-of-line fp4_mul_call through private memory — four dependent store -> load round
 // trips to HBM per product (measured: 64.7 K cycles per call against 37.7 K of issue, profiles/r02_pair_routines_2waves.txt).
+// y is ALWAYS an object in the caller's private memory (a local of the exponentiation routines / the kernels): said explicitly — through the
+// generic reference the two reads of y are flat loads, whose every wait drains vmcnt AND lgkmcnt (the routine's LDS traffic with it)
+#ifndef C12381_EXPLICIT_AS
+#define C12381_EXPLICIT_AS 1                  // A/B: 0 = generic pointers (flat loads) as in round 3
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && C12381_EXPLICIT_AS
+C12381_HD void fp4_load_private(fp4& r, const fp4* p) {
+    typedef __attribute__((address_space(5))) const c12381_v4i priv_v4i;
+    priv_v4i* q = (priv_v4i*)(const void*)p;
+    int32_t* w = reinterpret_cast<int32_t*>(&r);
+#pragma unroll
+    for (int i = 0; i < 14; ++i) { const c12381_v4i v = q[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
+}
+#else
+C12381_HD void fp4_load_private(fp4& r, const fp4* p) { r = *p; }
+#endif
 C12381_HDN void f12t_mul_h(fp4& H, const fp4& y, const tri& t) {
     fp4 z, zc, zn, e, w;
     {   // (x + x')(y + y') first: its operands are sums, so x and y need not stay in registers while it runs
@@ -306,7 +322,7 @@ C12381_HDN void f12t_mul_h(fp4& H, const fp4& y, const tri& t) {
         {
             fp4 x, yv, xn, yn;
             slot_load(x, H);
-            yv = y;
+            fp4_load_private(yv, &y);
 #if C12381_SLOT_NEIGHBOUR
             slot_load_role(xn, H, tri_next(t), t);
 #else
@@ -328,7 +344,7 @@ C12381_HDN void f12t_mul_h(fp4& H, const fp4& y, const tri& t) {
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("" : "+v"(yp));
 #endif
-        yv = *yp;
+        fp4_load_private(yv, yp);
         C12381_PHASE();
         fp4_mul_core(z, x, yv);
         C12381_PHASE();
@@ -1205,12 +1221,10 @@ C12381_HDN void miller3_fixed_line_raw(fp4& F, const int32_t* tab, int k, const 
 // alone (l0 = l2 = 0) instead of by 1: a factor in Fp4 is removed by the final exponentiation just like one in Fp2 ((p^12 - 1)/r
 // is a multiple of p^4 - 1), and f keeps going through the same reduction as every other lane's.
 C12381_HDN void miller3_fixed_line1(fp4& F, const int32_t* tab, int k, const fp& px, const fp& py, bool skip, const tri& t) {
-    fp2 c0, c2, l0, l2, cs, prod, zero2;
+    fp2 l0, l2, cs, prod, zero2;
     fp ps;
     const int32_t* rec = tab + (size_t)k * FQ_LINE_DWORDS;
-    msm_load_pt(c0.a, c0.b, rec);
-    msm_load_pt(c2.a, c2.b, rec + 2 * NL);
-    fp2_select(cs, t.role == 0, c0, c2);
+    msm_load_pt(cs.a, cs.b, rec + (t.role == 0 ? 0 : 2 * NL));      // role 0 needs c0 / c1, the others c2 / c1: one record, chosen by address
     fp_select(ps, t.role == 0, py, px);
     fp2_mul_fp(prod, cs, ps);
     tri_fetch_fp2(l0, prod, 0, t);
