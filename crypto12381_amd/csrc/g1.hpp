@@ -280,12 +280,20 @@ C12381_HD void glv_bias(uint32_t (&kb)[5], const uint32_t (&k)[4]) {
         kb[4] = (uint32_t)c + B[4];
     }
 }
-// q = sign(d) * T[|d|], or its image under the endomorphism; d == 0 gives the point at infinity (same instruction stream)
-C12381_HD void g1_digit_point(g1p& r, const int32_t* lane_tab, int d, bool endo) {
+// the table record a digit selects (|d| = 0 reads entry 1 and is replaced by the point at infinity afterwards)
+C12381_HD const int32_t* g1_digit_entry(const int32_t* lane_tab, int d) {
     const int mag = d < 0 ? -d : d;
-    const int idx = mag == 0 ? 1 : mag;
+    return lane_tab + ((mag == 0 ? 1 : mag) - 1) * G1_ENT_DWORDS;
+}
+// q = sign(d) * T[|d|], or its image under the endomorphism; d == 0 gives the point at infinity (same instruction stream)
+C12381_HD void g1_digit_fix(g1p& r, g1p q, int d, bool endo);
+C12381_HD void g1_digit_point(g1p& r, const int32_t* lane_tab, int d, bool endo) {
     g1p q;
-    tab_load_g1(q, lane_tab + (idx - 1) * G1_ENT_DWORDS);
+    tab_load_g1(q, g1_digit_entry(lane_tab, d));
+    g1_digit_fix(r, q, d, endo);
+}
+C12381_HD void g1_digit_fix(g1p& r, g1p q, int d, bool endo) {
+    const int mag = d < 0 ? -d : d;
     fp ny, zero, one;
     fp_neg(ny, q.y);
     fp_select(q.y, d < 0, ny, q.y);
@@ -402,12 +410,39 @@ C12381_HD void g1_scalar_mul(g1p& acc, const fp& px, const fp& py, bool p_is_inf
         acc = n;
     }
     g1_add_digit(acc, lane_tab, glv_digit(kb1, G1_WINDOWS - 1), true);
+    // C12381_G1_PREFETCH (round 4): the record of an addition is requested one operation ahead — the first digit's before the window's
+    // doublings (44 registers across them), with 2 also the second digit's before the first addition — instead of at the head of the
+    // addition that needs it, where the whole latency of the gather (a 176-byte record somewhere in a slab of gigabytes) was exposed
+    // twice per window (ISA: 11 loads, then vmcnt waits within 20 instructions).  0 = the round-3 order.
+#ifndef C12381_G1_PREFETCH
+#define C12381_G1_PREFETCH 2
+#endif
 #pragma unroll 1
     for (int w = G1_WINDOWS - 2; w >= 0; --w) {
+#if C12381_G1_PREFETCH && defined(__HIP_DEVICE_COMPILE__)
+        const int d0 = glv_digit(kb0, w), d1 = glv_digit(kb1, w);
+        g1p q0, q1, e;
+        tab_load_g1(q0, g1_digit_entry(lane_tab, d0));
+        __builtin_amdgcn_sched_barrier(0);               // the loads stay in front of the doublings
+        g1_dbl(acc); g1_dbl(acc); g1_dbl(acc); g1_dbl(acc);
+        if (G1_WIN == 5) g1_dbl(acc);
+#if C12381_G1_PREFETCH >= 2
+        tab_load_g1(q1, g1_digit_entry(lane_tab, d1));
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        g1_digit_fix(e, q0, d0, false);
+        g1_add(acc, e);
+#if C12381_G1_PREFETCH < 2
+        tab_load_g1(q1, g1_digit_entry(lane_tab, d1));
+#endif
+        g1_digit_fix(e, q1, d1, true);
+        g1_add(acc, e);
+#else
         g1_dbl(acc); g1_dbl(acc); g1_dbl(acc); g1_dbl(acc);
         if (G1_WIN == 5) g1_dbl(acc);
         g1_add_digit(acc, lane_tab, glv_digit(kb0, w), false);
         g1_add_digit(acc, lane_tab, glv_digit(kb1, w), true);
+#endif
     }
 }
 // k mod r < x^2, i.e. k div x^2 == 0: the lanes that owe g1_glv_small_scalar_term (evaluated by a separate, almost always

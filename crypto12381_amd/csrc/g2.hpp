@@ -82,6 +82,10 @@ template <class F> C12381_HDN void g2_add(g2pt<F>& p, const g2pt<F>& q) { g2_add
 // window loop (like g1_scalar_mul) instead of out-of-line routines that take the point through private memory.  Pays where the
 // whole addition fits the register file — the two-lane form (fp2h.hpp specialises this to true).
 template <class F> struct g2_inline_loop { static constexpr bool value = false; };
+#ifndef C12381_G2_PREFETCH
+#define C12381_G2_PREFETCH 0                   // A/B, OFF: requesting the records one operation ahead (as G1 does) costs the two-lane loop 51 more spill
+                                               // instructions and 2 % (15.15 vs 14.85 ms per 2^18, profiles/r04_ab_g1_prefetch.txt); 0 = loaded at the head of the addition
+#endif
 
 // ------------------------------------------------------------------ SoA access
 C12381_HD void soa_store_fp2(int32_t* base, size_t stride, size_t idx, const fp2& a) {
@@ -227,12 +231,23 @@ C12381_HD void gs_bias(uint32_t (&ub)[3], const uint32_t (&u)[2]) {
     c += (uint64_t)u[1] + b1; ub[1] = (uint32_t)c; ub[2] = (uint32_t)(c >> 32) + (G2_WIN == 4 ? 0u : gs_bias_word5(2));
 }
 // e = (-1)^I sign(d) psi^I(T[|d|]); d == 0 gives the point at infinity
+// the table record a digit selects (|d| = 0 reads entry 1 and is replaced by the point at infinity afterwards)
+template <class F>
+C12381_HD void g2_digit_load(g2pt<F>& q, const int32_t* lane_tab, int d) {
+    const int mag = d < 0 ? -d : d;
+    tab_load_g2(q, lane_tab + ((mag == 0 ? 1 : mag) - 1) * g2_ent_dwords(q));
+}
+template <int I, class F> C12381_HD void g2_digit_fix(g2pt<F>& e, const g2pt<F>& q, int d);
 template <int I, class F>
 C12381_HD void g2_digit_point(g2pt<F>& e, const int32_t* lane_tab, int d) {
+    g2pt<F> q;
+    g2_digit_load(q, lane_tab, d);
+    g2_digit_fix<I>(e, q, d);
+}
+template <int I, class F>
+C12381_HD void g2_digit_fix(g2pt<F>& e, const g2pt<F>& q, int d) {
     const int mag = d < 0 ? -d : d;
-    const int idx = mag == 0 ? 1 : mag;
-    g2pt<F> q, inf;
-    tab_load_g2(q, lane_tab + (idx - 1) * g2_ent_dwords(q));
+    g2pt<F> inf;
     g2_psi_signed<I>(e, q, (d < 0) != ((I & 1) != 0));
     g2_set_inf(inf);
     const bool isz = mag == 0;
@@ -345,6 +360,29 @@ template <class F> C12381_HDN void g2_scalar_mul(g2pt<F>& acc, const F& qx, cons
     g2_set_inf(run);
 #pragma unroll 1
     for (int w = G2_WINDOWS - 1; w >= 0; --w) {
+#if defined(__HIP_DEVICE_COMPILE__) && C12381_G2_PREFETCH
+        // round 4 (as g1_scalar_mul): in the register-resident two-lane form the record of an addition is requested one operation ahead —
+        // before the window's doublings / before the previous addition — instead of at the head of the addition that needs it
+        if (g2_inline_loop<F>::value && w != G2_WINDOWS - 1) {
+            const int d0 = gs_digit(ub[0], w), d1 = gs_digit(ub[1], w), d2 = gs_digit(ub[2], w), d3 = gs_digit(ub[3], w);
+            g2pt<F> qa, qb, e;
+            g2_digit_load(qa, lane_tab, d0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+            for (int i = 0; i < G2_WIN; ++i) { F a, b, c; g2_dbl_core(run, a, b, c); }
+            g2_digit_load(qb, lane_tab, d1);
+            __builtin_amdgcn_sched_barrier(0);
+            g2_digit_fix<0>(e, qa, d0); g2_add_core(run, e);
+            g2_digit_load(qa, lane_tab, d2);
+            __builtin_amdgcn_sched_barrier(0);
+            g2_digit_fix<1>(e, qb, d1); g2_add_core(run, e);
+            g2_digit_load(qb, lane_tab, d3);
+            __builtin_amdgcn_sched_barrier(0);
+            g2_digit_fix<2>(e, qa, d2); g2_add_core(run, e);
+            g2_digit_fix<3>(e, qb, d3); g2_add_core(run, e);
+            continue;
+        }
+#endif
         if (w != G2_WINDOWS - 1) {
             if (g2_inline_loop<F>::value) {
 #pragma unroll 1
