@@ -33,7 +33,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # big out-of-line field routines do not save ~65 callee-saved VGPRs in their prologues (130 scratch instructions a call)
 # max-ilp scheduling: every kernel here runs at a FIXED occupancy (launch bounds: 2 waves per SIMD), so the default strategy's
 # effort to raise occupancy buys nothing, while scheduling for ILP shortens the dependent multiply-add chains (A/B on MI355X,
-# tools/ab_all.sh: pairing kernel 22.8 -> 22.1 ms).  NOT combined with -amdgpu-use-amdgpu-trackers=1: that (experimental)
+# round 1: pairing kernel 22.8 -> 22.1 ms).  NOT combined with -amdgpu-use-amdgpu-trackers=1: that (experimental)
 # option gained another 1 %, but together with max-ilp an experimental variant of the pairing routines (Fp4 squarings as
 # calls) returned wrong values for a few lanes of a full-size batch while passing every small test — not worth the risk.
 # -opt-disable=reassociate (round 4): LLVM's Reassociate pass orders the operands of every column sum by rank and therefore adds the
