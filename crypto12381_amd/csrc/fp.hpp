@@ -7,9 +7,8 @@
 //   * limbs are carried lazily: add/sub/neg are 14 independent v_add/v_sub with no carry
 //     chain and no conditional subtraction; values may be negative or exceed p.
 //   * a product is scanned column by column into ONE 64-bit accumulator with
-//     v_mad_i64_i32 (measured on MI355X, profiles/r03_valu_rates.txt: HALF the v_add_u32 rate — 56 against 110 lanes per
-//     clock and CU with eight wavefronts per SIMD, 46 with the two that a 256-register kernel has; the same rate as
-//     v_mul_lo_u32, a 64-bit shift or an add-with-carry pair),
+//     v_mad_i64_i32 (measured inside the kernel, profiles/r03_issue_mix.txt: one per 4.125 cycles and SIMD — and so is every other
+//     vector instruction of a mixed stream at two wavefronts per SIMD: what counts is the NUMBER of instructions),
 //     Montgomery reduction interleaved in the same columns — no carry flags anywhere.
 //   * invariants are tracked as two bounds per element: LB = max |limb| and VB = |value|/p.
 //     fp_mul needs 14*LBa*LBb + 14*2^56 + 2^40 < 2^63 and returns limbs 0..12 in [0,2^28) with
@@ -43,17 +42,16 @@ namespace c12381 { __device__ __forceinline__ int32_t limb_opaque(int32_t v) { a
 #else
 #define C12381_LIMB(x) (x)
 #endif
-// A/B switch, OFF (profiles/r03_ab_acc_fence_g2_inline.txt).  Left alone, LLVM computes every column of a product from zero and adds the carry
-// of the previous column afterwards (one v_lshl_add_u64 per column, ~1 instruction per 15 multiply-adds), and it splits the signed limb
-// products and the non-negative m * p products into two chains.  -DC12381_ACC_FENCE=1 puts an empty asm on the accumulator after every
-// multiply-add, which forces ONE linear chain per column sequence: the adds disappear (g1_mul_kernel: -20 % non-multiply instructions,
-// no spill), but the hazard recognizer puts one wait state (s_nop 0, a full 4-cycle issue slot) between a vector instruction and an inline
-// asm that reads its result — the empty asm could hold a v_readlane — wherever the scheduler left the two adjacent: 345 s_nop for 208
-// adds saved in the bucket kernel.  Measured: G1 -1 %, G2 +5 %, MSM +2 %, pairing kernel 18.1 -> 24.4 ms (the linear chains also make
-// the max-ilp scheduler interleave five reductions: spills).  A second use of every partial sum (__builtin_assume) instead of the asm
-// keeps the carry first but splits the m * p terms off into a chain of their own: two adds per column instead of one, and 3 x the
-// compile time.  A hand-written multiplier in one asm statement is out of reach in HIP C++: 42 register operands against the limit of
-// 30, and a 16-dword tuple operand cannot be indexed inside the asm string.  The compiler's two-chain form stays.
+// How the column sums reach the hardware as ONE linear v_mad_i64_i32 chain (round 4): left alone, LLVM's Reassociate pass sums every column
+// from zero and adds the carry of the previous column afterwards (one v_lshl_add_u64 "join" per column, 26-30 per reduction) and splits the signed
+// limb products and the non-negative m * p products into two chains.  The build switches that pass off (-mllvm -opt-disable=reassociate,
+// crypto12381_amd/build.py): the source order below — carry first, then the products — survives to instruction selection, fp_mul is 463
+// instructions (hand count 460) and needs 44 registers instead of 84.
+// What did NOT work: C12381_ACC_FENCE=1 (round 3, kept as an A/B switch, OFF: profiles/r03_ab_acc_fence_g2_inline.txt) puts an empty asm on the
+// accumulator after every multiply-add — same chain, but the hazard recognizer pads every edge from an inline asm that defines a VGPR to the
+// instruction that reads it with one s_nop (345 s_nop for 208 joins saved in the bucket kernel; pairing kernel 18.1 -> 24.4 ms); round 4 tried
+// every step as its own one-instruction asm statement: exactly the hand-written stream and one s_nop after EVERY instruction (asm -> asm edges
+// are padded too).  A whole multiplier in one asm statement is out of reach in HIP C++ (42 register operands against the limit of 30).
 #ifndef C12381_ACC_FENCE
 #define C12381_ACC_FENCE 0
 #endif
