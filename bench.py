@@ -146,7 +146,7 @@ def sum_of_products_mod_r(a: np.ndarray, b: np.ndarray) -> int:
 def compact(o):
     """floats to 6 significant digits, recursively (the line has to fit a log tail)"""
     if isinstance(o, float):
-        return float("%.6g" % o)
+        return int(o) if o.is_integer() and abs(o) < 1e15 else float("%.6g" % o)     # counts stay exact
     if isinstance(o, dict):
         return {k: compact(v) for k, v in o.items()}
     if isinstance(o, (list, tuple)):
