@@ -45,6 +45,16 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # way to pin the chain, cost one s_nop per instruction: the hazard recognizer pads every asm -> dependent-instruction edge.)
 CFLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-fno-optimize-sibling-calls",
           "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-opt-disable=reassociate"]
+# With the linear chains of -opt-disable=reassociate the G1 scalar-multiplication kernels no longer gain from max-ilp: the default
+# strategy is 1.2 % faster there (three interleaved rounds, digests equal, profiles/r04_ab_sched_per_unit.txt: G1 2^20 24.63 -> 24.33 ms
+# mean, MSM unchanged), while G2 (+1.4 %), the Miller loop and the final exponentiation (+1.6 %) still lose without it.
+DEFAULT_SCHED_UNITS = ("k_g1.hip",)
+
+
+def unit_cflags(unit: str):
+    if unit in DEFAULT_SCHED_UNITS:
+        return [f for i, f in enumerate(CFLAGS) if "amdgpu-sched-strategy" not in f and not (f == "-mllvm" and "amdgpu-sched-strategy" in CFLAGS[i + 1])]
+    return list(CFLAGS)
 # Round 2 reproduced the wrong-values event with a rebuilt variant: whole wavefront groups wrong, plain grid as
 # well as queue, only with -amdgpu-use-amdgpu-trackers=1; the same source without it is exact on every lane.  The option is
 # refused outright — in CFLAGS and in every environment variable through which hipcc / clang accept extra flags — and the
@@ -102,7 +112,7 @@ def _obj_name(unit: str, exp: bool) -> str:
 def _stamp(unit: str, exp: bool) -> str:
     """hash of everything besides the sources that decides what the object contains"""
     _check_flags()
-    return hashlib.sha256("\0".join([HIPCC, *CFLAGS, "exp" if exp else "", unit, _flag_env(), _hipcc_version() or ""]).encode()).hexdigest()
+    return hashlib.sha256("\0".join([HIPCC, *unit_cflags(unit), "exp" if exp else "", unit, _flag_env(), _hipcc_version() or ""]).encode()).hexdigest()
 
 
 def _stamp_ok(unit: str, exp: bool) -> bool:
@@ -132,7 +142,7 @@ def _compile(unit: str, exp: bool, force: bool, verbose: bool) -> str:
     src = os.path.join(CSRC, unit)
     obj = os.path.join(OBJ, _obj_name(unit, exp) + ".o")
     if force or _stale(obj, _headers() + [src]) or not _stamp_ok(unit, exp):
-        cmd = [HIPCC, *CFLAGS, *(["-DC12381_EXPERIMENTS"] if exp else []), "-c", "-o", obj, src]
+        cmd = [HIPCC, *unit_cflags(unit), *(["-DC12381_EXPERIMENTS"] if exp else []), "-c", "-o", obj, src]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)

@@ -12,7 +12,10 @@ FLAGS=${BASEFLAGS:-"-O3 --offload-arch=gfx950 -fPIC -std=c++17 -fno-optimize-sib
 for f in "$@"; do case "$f" in *amdgpu-use-amdgpu-trackers*) echo "refused: $f (DESIGN.md 5b)"; exit 2;; esac; done
 pids=""
 for u in c12381_hip k_g1 k_g2gt k_g2h k_pair3 k_hash_zp k_fixed; do
-  /opt/rocm/bin/hipcc $FLAGS "$@" -c -o $OBJ/$u.o $ROOT/crypto12381_amd/csrc/$u.hip 2> $OBJ/$u.err &
+  UF=$FLAGS
+  # the product builds k_g1.hip with the default scheduling strategy (crypto12381_amd/build.py: DEFAULT_SCHED_UNITS)
+  if [ $u = k_g1 ] && [ -z "$BASEFLAGS" ]; then UF=${FLAGS/-mllvm -amdgpu-sched-strategy=max-ilp/}; fi
+  /opt/rocm/bin/hipcc $UF "$@" -c -o $OBJ/$u.o $ROOT/crypto12381_amd/csrc/$u.hip 2> $OBJ/$u.err &
   pids="$pids $!"
 done
 for p in $pids; do wait $p; done
