@@ -70,7 +70,7 @@ struct c12381_ctx {
     std::vector<hipEvent_t> ev_chunk;     // one per chunk of a scalar-mul batch (main -> side dependencies)
     char err[256] = {0};
     enum { WS_TAB, WS_PROJ, WS_PREF, WS_IN0, WS_IN1, WS_OUT, WS_RED0, WS_RED1, WS_BBS_Q, WS_BBS_B, WS_BBS_IN, WS_BBS_WIRE, WS_BBS_WIRE_IN,
-           WS_PAIR_ST, WS_FQ_W, WS_FQ_G, WS_FQ_GATE, WS_FQ_P, WS_FB_G2, WS_FB_G1_0, WS_FB_G1_1, WS_FB_G1_2, WS_FB_G1_3, WS_MSM_PTS, WS_MSM_K0, WS_MSM_K1, WS_MSM_V0, WS_MSM_V1, WS_MSM_TMP, WS_MSM_RNG, WS_MSM_BK, WS_MSM_ORD, WS_MSM_OVF, WS_DEC1, WS_DEC2, WS_COUNT };
+           WS_PAIR_ST, WS_FQ_W, WS_FQ_G, WS_FQ_GATE, WS_FQ_P, WS_FB_G2, WS_FB_G1_0, WS_FB_G1_1, WS_FB_G1_2, WS_FB_G1_3, WS_MSM_PTS, WS_MSM_K0, WS_MSM_K1, WS_MSM_V0, WS_MSM_V1, WS_MSM_TMP, WS_MSM_RNG, WS_MSM_BK, WS_MSM_ORD, WS_MSM_OVF, WS_DEC1, WS_DEC2, WS_GT_POW, WS_COUNT };
     void* ws[WS_COUNT] = {nullptr};
     size_t ws_bytes[WS_COUNT] = {0};
     int* d_flag = nullptr;
@@ -1179,7 +1179,21 @@ static int launch_gt_op(c12381_ctx* c, int op, size_t n, const uint8_t* a, const
         uint4* st; unsigned int *fl, *ct; unsigned blocks; int rc;
         if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
         hipLaunchKernelGGL(fexp3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, a, out, c->d_flag, st, fl, ct, pair_spin_limit());
-    } else hipLaunchKernelGGL(gt3_op_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, op, n, a, b, out);
+    } else if (op == 2) {
+        // the power: launches of at most GT_POW_WAVES wavefronts, each with its table of x^0 .. x^15 behind it (224 KB per wavefront; the
+        // same workspace serves every launch: they are ordered on the stream)
+        constexpr size_t GT_POW_WAVES = 4096;
+        const size_t waves = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE, per = waves < GT_POW_WAVES ? waves : GT_POW_WAVES;
+        int rc;
+        if ((rc = ensure(c, c12381_ctx::WS_GT_POW, per * GT_POW_TAB_BYTES_PER_WAVE))) return rc;
+        for (size_t w0 = 0; w0 < waves; w0 += per) {
+            const size_t i0 = w0 * TRI_PER_WAVE, m = n - i0 < per * TRI_PER_WAVE ? n - i0 : per * TRI_PER_WAVE;
+            hipLaunchKernelGGL(gt3_op_kernel, dim3(grid_tri(m)), dim3(BLOCK), 0, c->stream, op, m, a + 576 * i0, b + 32 * i0, out + 576 * i0,
+                               (uint4*)c->ws[c12381_ctx::WS_GT_POW]);
+            HIPCK(c, hipGetLastError());
+        }
+        return 0;
+    } else hipLaunchKernelGGL(gt3_op_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, op, n, a, b, out, (uint4*)nullptr);
     HIPCK(c, hipGetLastError());
     return 0;
 }

@@ -65,6 +65,8 @@ __device__ __forceinline__ void gt_load_coeff(fp4& x, const uint8_t* p576, int r
 
 // ---- work-queue variant: state of a group of 21 pairings between two phases, as rows of 64 x 16 bytes (one per lane)
 constexpr int ST_ROWS_F = 14, ST_ROWS_TC = 7;                 // Fp4 = 56 dwords, Fp2 = 28 dwords
+constexpr int GT_POW_TAB_ROWS = 16 * ST_ROWS_F;               // gt3_op_kernel's table of x^0 .. x^15 per wavefront
+static_assert(GT_POW_TAB_BYTES_PER_WAVE == (size_t)GT_POW_TAB_ROWS * 64 * 16, "kernels.hpp: size of the power table per wavefront");
 constexpr int ST_F = 0, ST_TC1 = ST_ROWS_F, ST_TC2 = ST_TC1 + ST_ROWS_TC, ST_Y1 = ST_TC2 + ST_ROWS_TC;
 
 template <class T, int ROWS>
@@ -669,7 +671,9 @@ __global__ void __launch_bounds__(BLOCK, 2) miller3_kernel(size_t n, const uint8
     }
 }
 // op 0: a*b (FP12_mul), 1: conj(a), 2: a^e (FP12_pow, e = 32-byte exponent used as given), 3: final exponentiation
-__global__ void __launch_bounds__(BLOCK, 2) gt3_op_kernel(int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+// pow_tab (op 2; may be null): 16 Fp4 rows of 64 lanes per wavefront of THIS launch (GT_POW_TAB_ROWS x 64 x 16 bytes each) — the table of
+// the windowed ladder, taken when every triple of the wavefront holds a member of the cyclotomic subgroup (pairing3.hpp f12t_pow_window)
+__global__ void __launch_bounds__(BLOCK, 2) gt3_op_kernel(int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out, uint4* pow_tab) {
     if ((((size_t)blockIdx.x * BLOCK + threadIdx.x) >> 6) * TRI_PER_WAVE >= n) return;
     tri t; size_t i; bool active;
     tri_setup(t, i, active, n);
@@ -679,7 +683,23 @@ __global__ void __launch_bounds__(BLOCK, 2) gt3_op_kernel(int op, size_t n, cons
     gt_load_coeff(x, a + 576 * i, t.role);
     if (op == 0) { fp4 y; gt_load_coeff(y, b + 576 * i, t.role); f12t_mul(r, x, y, t); }
     else if (op == 1) { f12t_conj(r, x, t); }
-    else if (op == 2) { uint32_t raw[8], e[8]; load_raw32(raw, b + 32 * i); scalar_from_raw32(e, raw); slot_store(H, x); f12t_pow_generic(H, e, t); slot_load(r, H); }
+    else if (op == 2) {
+        uint32_t raw[8], e[8];
+        load_raw32(raw, b + 32 * i); scalar_from_raw32(e, raw);
+        bool windows = false;
+        if (pow_tab) {                                             // wave-uniform
+            const bool member = f12t_is_cyclotomic(H, x, t);
+            windows = __builtin_amdgcn_ballot_w64(active && !member) == 0;
+        }
+        if (windows) {
+            const unsigned lane = threadIdx.x & 63u;
+            uint4* tab = wave_uniform(pow_tab + (((size_t)blockIdx.x * BLOCK + threadIdx.x) >> 6) * (size_t)(GT_POW_TAB_ROWS * 64));
+            f12t_pow_window(H, x, e, t,
+                            [&](int k, const fp4& v) { st_store<fp4, ST_ROWS_F>(tab + (size_t)k * (ST_ROWS_F * 64), lane, v); },
+                            [&](fp4& m, int k) { st_load<fp4, ST_ROWS_F>(m, tab + (size_t)k * (ST_ROWS_F * 64), lane); });
+        } else { slot_store(H, x); f12t_pow_generic(H, e, t); }
+        slot_load(r, H);
+    }
     else { r = x; f12t_final_exp_ws(r, H, t); }
     if (active) gt_store_coeff(out + 576 * i, r, t.role);
 }

@@ -804,6 +804,55 @@ C12381_HDN void f12t_pow_generic(fp4& H, const uint32_t (&e)[8], const tri& t) {
     }
     f12t_unscale3_h(H);
 }
+// ------------------------------------------------------------------ FP12_pow on the cyclotomic subgroup: fixed 4-bit windows
+// x^(p^4 - p^2 + 1) = 1 — every pairing value: the easy part of the final exponentiation maps into that subgroup — makes the Granger-Scott
+// squaring a true squaring and conj the inverse, so EVERY addition chain returns the field element FP12_pow :736-774 returns for (x, e),
+// and the canonical bytes with it.  Only there: on any other input the reference's value depends on its own digit sequence, which
+// f12t_pow_generic reproduces; the kernels test membership (f12t_is_cyclotomic, one product and four Frobenius maps) and take the windowed
+// ladder only when every triple of the wavefront passes.  x = 0 passes the test as well and gives 0 (e != 0) or 1 (e = 0) on both routes.
+//   table x^0 .. x^15 (14 products; `store(k, v)` / `load(r, k)`: one Fp4 per lane and entry, k may differ from lane to lane),
+//   then 64 windows from the top: four squarings in the scaled form, one product with the digit's entry (x^0 = 1 for a zero digit, so all
+//   triples run the same instructions) — 78 products against the 257 of the signed-digit ladder, the 256 squarings stay.
+C12381_HD bool f12t_is_cyclotomic(fp4& H, const fp4& x, const tri& t) {
+    fp4 f2, f4, r, d;
+    f12t_frob(f2, x, t); f12t_frob(f2, f2, t);                 // x^(p^2)
+    f12t_frob(f4, f2, t); f12t_frob(f4, f4, t);                // x^(p^4)
+    slot_store(H, f4);
+    f12t_mul_h(H, x, t);
+    slot_load(r, H);
+    fp4_sub(d, r, f2);
+    const int mine = (fp_is_zero(d.a.a) & fp_is_zero(d.a.b) & fp_is_zero(d.b.a) & fp_is_zero(d.b.b)) ? 1 : 0;
+    const int a = tri_fetch_int(mine, 0, t), b = tri_fetch_int(mine, 1, t), c = tri_fetch_int(mine, 2, t);
+    return (a & b & c) != 0;
+}
+// H: the lane's slot (any content on entry, x^e on return); x: the base, in private memory
+template <class Store, class Load>
+C12381_HD void f12t_pow_window(fp4& H, const fp4& x, const uint32_t (&e)[8], const tri& t, Store store, Load load) {
+    {
+        fp4 one, r;
+        f12t_one(one, t);
+        store(0, one); store(1, x);
+        slot_store(H, x);
+#pragma unroll 1
+        for (int k = 2; k < 16; ++k) {
+            f12t_mul_h(H, x, t);
+            slot_load(r, H);
+            store(k, r);
+        }
+        fp4 y;
+        fp4_scale3(y, one);                                    // the accumulator in the scaled form of f12t_usqr3_h
+        slot_store(H, y);
+    }
+#pragma unroll 1
+    for (int w = 63; w >= 0; --w) {
+        if (w != 63) { f12t_usqr3_h(H, t); f12t_usqr3_h(H, t); f12t_usqr3_h(H, t); f12t_usqr3_h(H, t); }
+        const int digit = (int)((e[w >> 3] >> ((w & 7) * 4)) & 15u);
+        fp4 m;
+        load(m, digit);
+        f12t_mul_h(H, m, t);
+    }
+    f12t_unscale3_h(H);
+}
 // FP12_isunity: every lane tests its own coefficient, the verdict is combined over the triple
 C12381_HD bool f12t_is_one(const fp4& x, const tri& t) {
     fp d, one;

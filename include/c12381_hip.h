@@ -200,7 +200,10 @@ int c12381_fexp_batch(c12381_ctx* ctx, size_t n, const uint8_t* in576, uint8_t* 
 int c12381_fexp_batch_dev(c12381_ctx* ctx, size_t n, const uint8_t* in576, uint8_t* out576);
 /* op 0: multiply(fp12& r, fp12& v) r*=v (:193 -> 256-259 -> FP12_mul); 1: conjugate (:191 -> 251-254);
  * 2: pow(fp12&, fp12& base, const big&) (:195 -> 261-264 -> FP12_pow; b = 32-byte exponents, used as given,
- *    unitary squarings exactly like the reference); 3: final exponentiation. */
+ *    unitary squarings exactly like the reference: bases outside the cyclotomic subgroup go through the reference's
+ *    own digit sequence, members — every pairing value — through a 4-bit windowed ladder that returns the same
+ *    bytes; the device holds 224 KB of table per wavefront of 21 elements, at most 0.94 GB);
+ * 3: final exponentiation. */
 int c12381_gt_op_batch(c12381_ctx* ctx, int op, size_t n, const uint8_t* a576, const uint8_t* b, uint8_t* out576);
 int c12381_gt_op_batch_dev(c12381_ctx* ctx, int op, size_t n, const uint8_t* a576, const uint8_t* b, uint8_t* out576);
 /* is_unity(fp12&) (:197 -> 271-274 -> FP12_isunity): out[i] = 1 / 0. */

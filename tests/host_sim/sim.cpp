@@ -307,6 +307,7 @@ void c12381_tri_exchange(void* out, const void* in, size_t bytes, int src_role, 
 }
 }
 namespace {
+int g_pow_route = 0, g_pow_windowed = 0;
 struct Tri3Job { TriBox* box; int role; size_t n; const uint8_t *a1, *a2, *b1, *b2; uint8_t* out; int mode; const int32_t *tab1, *tab2; };
 void gt_store_coeff(uint8_t* o576, const fp4& x, int role) {
     // FP12_toOctet order c | b | a, each Fp4 as b.b, b.a, a.b, a.a
@@ -330,7 +331,17 @@ void* tri3_worker(void* arg) {
             gt_load_coeff(x, jb->a1 + 576 * i, jb->role);
             if (op == 0) { fp4 y; gt_load_coeff(y, jb->b1 + 576 * i, jb->role); f12t_mul(r, x, y, t); }
             else if (op == 1) f12t_conj(r, x, t);
-            else if (op == 2) { uint32_t raw[8], e[8]; load_raw(raw, jb->b1 + 32 * i, 8); scalar_from_raw32(e, raw); r = x; f12t_pow_generic(r, e, t); }
+            else if (op == 2) {
+                // as gt3_op_kernel: the windowed ladder for members of the cyclotomic subgroup, the reference's digit sequence otherwise
+                // (g_pow_route: 0 = as the kernel decides, 1 = always the generic ladder; g_pow_windowed counts the elements that took the windows)
+                uint32_t raw[8], e[8]; load_raw(raw, jb->b1 + 32 * i, 8); scalar_from_raw32(e, raw);
+                const bool cyc = f12t_is_cyclotomic(h, x, t);
+                if (cyc && g_pow_route == 0) {
+                    fp4 tab[16];
+                    f12t_pow_window(r, x, e, t, [&](int k, const fp4& v) { tab[k] = v; }, [&](fp4& m, int k) { m = tab[k]; });
+                    if (jb->role == 0) ++g_pow_windowed;
+                } else { r = x; f12t_pow_generic(r, e, t); }
+            }
             else if (op == 3) { r = x; f12t_final_exp_ws(r, h, t); }
             else { const bool one = f12t_is_one(x, t); if (jb->role == 0) jb->out[i] = one ? 1 : 0; continue; }
             gt_store_coeff(jb->out + 576 * i, r, jb->role);
@@ -681,3 +692,5 @@ extern "C" int sim_pair2_fixed_batch(size_t n, const uint8_t* a96, const uint8_t
 extern "C" int sim_miller3_batch(size_t n, const uint8_t* g1_96, const uint8_t* g2_192, uint8_t* out576) { return run_tri3(n, g1_96, g2_192, nullptr, nullptr, out576, 3); }
 // op: 0 mul, 1 conj, 2 pow, 3 final exponentiation, 4 is-unity (out = n bytes)
 extern "C" int sim_gt3_op_batch(int op, size_t n, const uint8_t* a576, const uint8_t* b, uint8_t* out) { return run_tri3(n, a576, nullptr, b, nullptr, out, 10 + op); }
+// route of the power on triples: 0 = the kernel's choice, 1 = generic ladder only; returns the number of elements that took the windowed ladder so far
+extern "C" int sim_gt3_pow_route(int route) { g_pow_route = route; const int v = g_pow_windowed; g_pow_windowed = 0; return v; }

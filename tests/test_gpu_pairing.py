@@ -176,6 +176,33 @@ def test_gt_ops_and_split_pairing(ctx, oracle_port):
     assert ctx.gt_op("pow", gt * reps, eb) == oracle_port.gt_op("pow", gt * reps, eb)
 
 
+def test_gt_power_routes(ctx, oracle_port):
+    """gt3_op_kernel takes the 4-bit windowed ladder for a wavefront (21 elements) whose bases are all in the cyclotomic subgroup and the
+    reference's own digit sequence otherwise: wavefronts of either kind and mixed ones in one batch, zero bases, edge exponents, and a batch
+    longer than one launch of the power (4096 wavefronts = 86 016 elements) — every element against the oracle."""
+    g = golden("pairing")
+    gt = cat(g["gt"])
+    ng = len(gt) // 576
+    mil = ctx.miller(cat(g["g1"]), cat(g["g2"]))           # not in the subgroup
+    exps = [0, 1, 2, 15, 16, 17, 255, R - 1, R, R + 1, (1 << 256) - 1, 1 << 255, (1 << 255) + 1, 0x0f << 252, 0xf0f0f0f0 << 100] + [prng(437, i, 32) for i in range(48)]
+    bases = []
+    for i in range(63):                                    # three wavefronts: members only | one Miller value in the middle | zero and members
+        if i == 21 + 9:
+            bases.append(mil[:576])
+        elif i == 42 + 4:
+            bases.append(bytes(576))
+        else:
+            bases.append(gt[576 * (i % ng):576 * (i % ng) + 576])
+    a = b"".join(bases)
+    e = b"".join(int(v).to_bytes(32, "big") for v in exps)
+    want = oracle_port.gt_op("pow", a, e)
+    assert ctx.gt_op("pow", a, e) == want
+    big = 4096 * 21 + 100                                  # the second launch starts at element 86 016
+    reps = big // 63 + 1
+    got = ctx.gt_op("pow", (a * reps)[:576 * big], (e * reps)[:32 * big])
+    assert got == (want * reps)[:576 * big]
+
+
 def test_pair_fixed_g2(ctx, oracle_port):
     """One G2 argument for the batch: table-driven Miller loop, identical GT bytes to the general entry point."""
     g = golden("pairing")

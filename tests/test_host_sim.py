@@ -374,6 +374,41 @@ def test_sim_fixed_g2_lines(sim, oracle_port):
     assert out.raw == oracle_port.pair2(a, w * n, c, q * n)
 
 
+def test_sim_gt_power_windowed_and_generic_routes(sim, oracle_port):
+    """gt3_op_kernel's power: pairing values (cyclotomic subgroup) take the 4-bit windowed ladder, anything else the reference's own
+    digit sequence; both against the oracle, edge exponents included, with the bounds checker on (C12381_CHECK_BOUNDS build)"""
+    from util import prng
+    g = golden("pairing")
+    gt = cat(g["gt"])                                  # pairing values
+    mil = oracle_port.miller(cat(g["g1"])[:96 * 2], cat(g["g2"])[:192 * 2])          # Miller values: NOT in the subgroup, not even unitary
+    R = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    exps = [0, 1, 2, 15, 16, 17, R - 1, R, R + 1, (1 << 256) - 1, 1 << 255, 0x8000000000000000000000000000000080000000000000000000000000000001,
+            0xf0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0, prng(77, 1, 32), prng(77, 2, 32)]
+    n = len(exps)
+    a = b"".join(gt[576 * (i % (len(gt) // 576)):576 * (i % (len(gt) // 576)) + 576] for i in range(n))
+    e = b"".join(x.to_bytes(32, "big") for x in exps)
+    want = oracle_port.gt_op("pow", a, e)
+    from oracle.bindings import Oracle, have_reference
+    if have_reference():                               # the compiled reference itself, where it is present
+        ref = Oracle("reference")
+        assert ref.gt_op("pow", a, e) == want and ref.gt_op("pow", mil, e[32 * 3:32 * 5]) == oracle_port.gt_op("pow", mil, e[32 * 3:32 * 5])
+    out = ctypes.create_string_buffer(576 * n)
+    sim.sim_gt3_pow_route(0)
+    assert sim.sim_gt3_op_batch(2, sz(n), a, e, out) == 0 and out.raw == want
+    assert sim.sim_gt3_pow_route(1) == n               # every pairing value took the windows
+    assert sim.sim_gt3_op_batch(2, sz(n), a, e, out) == 0 and out.raw == want      # the generic ladder agrees on them
+    assert sim.sim_gt3_pow_route(0) == 0
+    # outside the subgroup: the kernel's choice must be the generic ladder, value as the reference's sequence gives it
+    e2 = e[32 * 3:32 * 5]
+    o2 = ctypes.create_string_buffer(576 * 2)
+    assert sim.sim_gt3_op_batch(2, sz(2), mil, e2, o2) == 0 and o2.raw == oracle_port.gt_op("pow", mil, e2)
+    # zero passes the membership test and is 0 (e != 0) / 1 (e = 0) on both routes
+    z = bytes(576 * 2)
+    ez = (5).to_bytes(32, "big") + bytes(32)
+    assert sim.sim_gt3_op_batch(2, sz(2), z, ez, o2) == 0 and o2.raw == oracle_port.gt_op("pow", z, ez)
+    assert sim.sim_gt3_pow_route(0) == 2
+
+
 def test_sim_three_lane_miller_and_gt_ops(sim, oracle_port):
     """miller3_kernel / gt3_op_kernel bodies: the Miller VALUE (not only the pairing) and the GT operators on triples"""
     g = golden("pairing")
