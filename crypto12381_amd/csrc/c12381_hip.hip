@@ -68,6 +68,8 @@ struct c12381_ctx {
     hipStream_t side = nullptr;           // rare fix-up passes run here, overlapped with the next chunk on `stream`
     hipEvent_t ev_side = nullptr;
     std::vector<hipEvent_t> ev_chunk;     // one per chunk of a scalar-mul batch (main -> side dependencies)
+    std::vector<hipStream_t> sort_streams; // further streams for the segment sorts of the bucket product (created on first use)
+    std::vector<hipEvent_t> sort_events;
     char err[256] = {0};
     enum { WS_TAB, WS_PROJ, WS_PREF, WS_IN0, WS_IN1, WS_OUT, WS_RED0, WS_RED1, WS_BBS_Q, WS_BBS_B, WS_BBS_IN, WS_BBS_WIRE, WS_BBS_WIRE_IN,
            WS_PAIR_ST, WS_FQ_W, WS_FQ_G, WS_FQ_GATE, WS_FQ_P, WS_FB_G2, WS_FB_G1_0, WS_FB_G1_1, WS_FB_G1_2, WS_FB_G1_3, WS_MSM_PTS, WS_MSM_K0, WS_MSM_K1, WS_MSM_V0, WS_MSM_V1, WS_MSM_TMP, WS_MSM_RNG, WS_MSM_BK, WS_MSM_ORD, WS_MSM_OVF, WS_DEC1, WS_DEC2, WS_GT_POW, WS_COUNT };
@@ -192,6 +194,11 @@ static int msm_c(size_t n) {
     static const int forced = [] { const char* e = tuning_env("C12381_MSM_C"); const int v = e ? std::atoi(e) : 0; return v >= 4 && v <= 16 ? v : 0; }();
     return forced ? forced : msm_window_bits(n);
 }
+#ifndef C12381_MSM_SORT_STREAMS
+#define C12381_MSM_SORT_STREAMS 2
+#endif
+constexpr int MSM_SORT_STREAMS = C12381_MSM_SORT_STREAMS;      // streams the window segments are sorted on (>= 2: the context's and its side stream)
+static_assert(MSM_SORT_STREAMS >= 2 && MSM_SORT_STREAMS <= 8, "MSM_SORT_STREAMS");
 // the unsorted value of entry x of a window segment, as the sort's input iterator reads it (msm_entry_value)
 struct msm_value_fn { uint32_t n; __host__ __device__ uint32_t operator()(uint32_t x) const { return msm_entry_value(x, n); } };
 // Bucket-method MSM (msm.hpp): prep -> radix sort -> bucket sums -> window reduction -> Horner -> affine.
@@ -228,18 +235,40 @@ int g1_msm_pippenger(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t*
         HIPCK(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, q0, q1, vin, v1, 2 * n, 0, cb, c->stream));
         HIPCK(c, rocprim::radix_sort_pairs(nullptr, tb, q0, q1, vin, v1, n, 0, 1, c->stream));
         if (tb > tmp_bytes) tmp_bytes = tb;
-        if ((rc = ensure(c, c12381_ctx::WS_MSM_TMP, tmp_bytes + 256))) return rc;
-        void* tmp = c->ws[c12381_ctx::WS_MSM_TMP];
-        for (int w = 0; w < W; ++w) {
+        // The segments are sorted alternately on the context's stream and on the side stream (own temporary storage each): one sort is
+        // six small launches around two passes that reach 1.7 TB/s, two at a time fill the gaps and the memory system better.
+        const size_t tmp_half = round_up(tmp_bytes + 256, 256);
+        if ((rc = ensure(c, c12381_ctx::WS_MSM_TMP, MSM_SORT_STREAMS * tmp_half))) return rc;
+        uint8_t* tmp = (uint8_t*)c->ws[c12381_ctx::WS_MSM_TMP];
+        if (c->ev_chunk.empty()) {
+            hipEvent_t e;
+            HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c->ev_chunk.push_back(e);
+        }
+        while ((int)c->sort_streams.size() < MSM_SORT_STREAMS - 2) {       // beyond the context's stream and its side stream
+            hipStream_t st; hipEvent_t e;
+            HIPCK(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            c->sort_streams.push_back(st);
+            HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c->sort_events.push_back(e);
+        }
+        auto sort_stream = [&](int k) { return k == 0 ? c->stream : (k == 1 ? c->side : c->sort_streams[(size_t)k - 2]); };
+        HIPCK(c, hipEventRecord(c->ev_chunk[0], c->stream));               // the keys are written
+        for (int k = 1; k < MSM_SORT_STREAMS; ++k) HIPCK(c, hipStreamWaitEvent(sort_stream(k), c->ev_chunk[0], 0));
+        for (int w = 0; w <= W; ++w) {                                     // segment W: the small-scalar entries, one key bit
             const size_t off = (size_t)2 * w * n;
             size_t sz = tmp_bytes;
-            HIPCK(c, rocprim::radix_sort_pairs(tmp, sz, q0 + off, q1 + off, vin, v1 + off, 2 * n, 0, cb, c->stream));
+            const int k = w % MSM_SORT_STREAMS;
+            HIPCK(c, rocprim::radix_sort_pairs(tmp + (size_t)k * tmp_half, sz, q0 + off, q1 + off, vin, v1 + off, w < W ? 2 * n : n, 0, w < W ? cb : 1, sort_stream(k)));
         }
-        const size_t off = (size_t)2 * W * n;
-        size_t sz = tmp_bytes;
-        HIPCK(c, rocprim::radix_sort_pairs(tmp, sz, q0 + off, q1 + off, vin, v1 + off, n, 0, 1, c->stream));
+        for (int k = 1; k < MSM_SORT_STREAMS; ++k) {
+            hipEvent_t e = k == 1 ? c->ev_side : c->sort_events[(size_t)k - 2];
+            HIPCK(c, hipEventRecord(e, sort_stream(k)));
+            HIPCK(c, hipStreamWaitEvent(c->stream, e, 0));
+        }
         HIPCK(c, hipMemsetAsync(lo, 0, (nbx + 1) * 8, c->stream));
-        hipLaunchKernelGGL(msm_ranges16_kernel, dim3(grid_for(2 * n), W + 1), dim3(BLOCK), 0, c->stream, n, (const uint16_t*)q1, cb, W, lo, hi);
+        hipLaunchKernelGGL(msm_ranges16_kernel, dim3(grid_for((2 * n + MSM_RANGES_PER_THREAD - 1) / MSM_RANGES_PER_THREAD), W + 1), dim3(BLOCK), 0, c->stream,
+                           n, (const uint16_t*)q1, cb, W, lo, hi);
         HIPCK(c, hipGetLastError());
     } else {
         hipLaunchKernelGGL(msm_prep_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, pts, in_fmt, sc, cb, W, pts2, k0, v0, c->d_flag);
@@ -277,7 +306,20 @@ int g1_msm_pippenger(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t*
     uint4* ovf_big = (uint4*)(ovf + o_big);
     int32_t* ovf_part = (int32_t*)(ovf + o_part);
     HIPCK(c, hipMemsetAsync(ovf_cnt, 0, 16, c->stream));
-    hipLaunchKernelGGL(msm_sizes_kernel, dim3(grid_for(nbx)), dim3(BLOCK), 0, c->stream, nbx, lo, hi, k0, v0, run_cap, ovf_cnt, ovf_seg, ovf_big);
+    // The small-scalar bucket (index nbk) and the [r]phi(S) it owes, on the side stream while this one goes on to the bucket sums: ranges and
+    // sorted values are final here.  ovf_cnt[2] = "term written"; longer buckets are left to the bucket kernel and msm_small_term_kernel.
+    int32_t* small_term = (int32_t*)(ovf + 64);
+    if (c->ev_chunk.empty()) {
+        hipEvent_t e;
+        HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->ev_chunk.push_back(e);
+    }
+    HIPCK(c, hipEventRecord(c->ev_chunk[0], c->stream));
+    HIPCK(c, hipStreamWaitEvent(c->side, c->ev_chunk[0], 0));
+    hipLaunchKernelGGL(msm_small_early_kernel, dim3(1), dim3(64), 0, c->side, (const uint32_t*)lo, (const uint32_t*)hi, (uint32_t)nbk, MSM_SMALL_EARLY_MAX,
+                       (const uint32_t*)v1, (const int32_t*)pts2, small_term, ovf_cnt + 2);
+    HIPCK(c, hipGetLastError());
+    hipLaunchKernelGGL(msm_sizes_kernel, dim3(grid_for(nbx)), dim3(BLOCK), 0, c->stream, nbx, lo, hi, k0, v0, run_cap, ovf_cnt, ovf_seg, ovf_big, MSM_SMALL_EARLY_MAX);
     HIPCK(c, hipGetLastError());
     {   // run-length keys are below 2^bits(cap): one or two passes instead of four
         int kb = 1;
@@ -289,7 +331,7 @@ int g1_msm_pippenger(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t*
     }
     {
         timed tm(c, 5);
-        hipLaunchKernelGGL(msm_bucket_kernel, dim3(grid_for(nbx)), dim3(BLOCK), 0, c->stream, nbx, lo, hi, v1, pts2, bk, order, run_cap);
+        hipLaunchKernelGGL(msm_bucket_kernel, dim3(grid_for(nbx)), dim3(BLOCK), 0, c->stream, nbx, lo, hi, v1, pts2, bk, order, run_cap, MSM_SMALL_EARLY_MAX);
         HIPCK(c, hipGetLastError());
     }
     // uniform scalars register no overflow segment: both grids leave after reading the counters
@@ -299,17 +341,11 @@ int g1_msm_pippenger(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t*
     hipLaunchKernelGGL(msm_overflow_combine_kernel, dim3(ovf_cap < 4096 ? (unsigned)((ovf_cap + 3) / 4) : 1024u), dim3(BLOCK), 0, c->stream,
                        (const uint32_t*)ovf_cnt, (const uint4*)ovf_big, (const int32_t*)ovf_part, bk);
     HIPCK(c, hipGetLastError());
-    // the [r]phi(S) owed by scalars below x^2 (record in the counters' page): one quad, ~0.5 ms when any scalar was small —
-    // on the side stream, behind the window reductions that the Horner lane has to wait for anyway
-    int32_t* small_term = (int32_t*)(ovf + 64);
-    if (c->ev_chunk.empty()) {
-        hipEvent_t e;
-        HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        c->ev_chunk.push_back(e);
-    }
+    // a small-scalar bucket too long for the early kernel: its term from the bucket sum, on the side stream beside the window reductions
+    // (returns at once when the early kernel has written the term)
     HIPCK(c, hipEventRecord(c->ev_chunk[0], c->stream));
     HIPCK(c, hipStreamWaitEvent(c->side, c->ev_chunk[0], 0));
-    hipLaunchKernelGGL(msm_small_term_kernel, dim3(1), dim3(64), 0, c->side, (const int32_t*)(bk + nbk * G1_ENT_DWORDS), small_term);
+    hipLaunchKernelGGL(msm_small_term_kernel, dim3(1), dim3(64), 0, c->side, (const int32_t*)(bk + nbk * G1_ENT_DWORDS), small_term, (const uint32_t*)(ovf_cnt + 2));
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipEventRecord(c->ev_side, c->side));
     const uint32_t chunks = (uint32_t)((nb + MSM_CHUNK - 1) / MSM_CHUNK);
@@ -378,6 +414,8 @@ void c12381_destroy(c12381_ctx* c) {
     if (c->stamps) (void)hipFree(c->stamps);
     if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->h_flag) (void)hipHostFree(c->h_flag);
+    for (hipStream_t st : c->sort_streams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (hipEvent_t e : c->sort_events) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     if (c->side) (void)hipStreamDestroy(c->side);
     for (hipEvent_t e : c->ev_chunk) (void)hipEventDestroy(e);

@@ -306,18 +306,37 @@ __global__ void __launch_bounds__(BLOCK, 2) msm_ranges_kernel(size_t E, const ui
     msm_ranges_one(j, E, keys, c, W, lo, hi);
 }
 // digit-only keys: blockIdx.y = the window segment (W = the small-scalar segment of n entries)
+// MSM_RANGES_PER_THREAD consecutive entries per thread, all their keys requested before the first is looked at: with one entry per thread the
+// kernel was bound by the latency of one 2-byte load per wavefront of work (220 us for 2^26 entries)
 __global__ void __launch_bounds__(BLOCK, 2) msm_ranges16_kernel(size_t n, const uint16_t* keys, int c, int W, uint32_t* lo, uint32_t* hi) {
+    constexpr int T = MSM_RANGES_PER_THREAD;
     const uint32_t w = blockIdx.y;
     const uint32_t len = (uint32_t)(w < (uint32_t)W ? 2 * n : n);
-    const uint32_t x = blockIdx.x * BLOCK + threadIdx.x;
-    if (x >= len) return;
-    msm_ranges_seg(x, len, (size_t)2 * w * n, w, keys, c, W, lo, hi);
+    const uint32_t x0 = (blockIdx.x * BLOCK + threadIdx.x) * (uint32_t)T;
+    if (x0 >= len) return;
+    const size_t seg = (size_t)2 * w * n;
+    uint32_t k[T + 2];                                    // keys of x0 - 1 .. x0 + T; 0x10000 = no such entry (never equal to a key)
+#pragma unroll
+    for (int j = 0; j < T + 2; ++j) {
+        const uint32_t x = x0 + (uint32_t)j;              // entry x - 1
+        k[j] = (x >= 1 && x - 1 < len) ? (uint32_t)keys[seg + x - 1] : 0x10000u;
+    }
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        const uint32_t x = x0 + (uint32_t)j, d = k[j + 1];
+        if (x >= len || d == 0) continue;
+        const uint32_t b = w < (uint32_t)W ? ((w << c) | d) : ((uint32_t)W << c);
+        if (k[j] != d) lo[b] = (uint32_t)(seg + x);
+        if (k[j + 2] != d) hi[b] = (uint32_t)(seg + x + 1);
+    }
 }
+// the last bucket (nbk - 1: the small-scalar bucket) counts as empty while it has at most `early_max` entries: msm_small_early_kernel sums it
 __global__ void __launch_bounds__(BLOCK, 2) msm_sizes_kernel(size_t nbk, const uint32_t* lo, const uint32_t* hi, uint32_t* key, uint32_t* ident,
-                                                          uint32_t cap, uint32_t* cnt, uint2* seg, uint4* big) {
+                                                          uint32_t cap, uint32_t* cnt, uint2* seg, uint4* big, uint32_t early_max) {
     const size_t b = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (b >= nbk) return;
-    const uint32_t len = hi[b] - lo[b];
+    uint32_t len = hi[b] - lo[b];
+    if (b == nbk - 1 && len <= early_max) len = 0;
     key[b] = cap - (len < cap ? len : cap);              // 0 = longest: ascending order of this key is decreasing run length; < 2^bits(cap)
     ident[b] = (uint32_t)b;
     if (len > cap) {
@@ -329,12 +348,14 @@ __global__ void __launch_bounds__(BLOCK, 2) msm_sizes_kernel(size_t nbk, const u
     }
 }
 __global__ void __launch_bounds__(BLOCK, C12381_MSM_OCC) msm_bucket_kernel(size_t nbk, const uint32_t* lo, const uint32_t* hi, const uint32_t* vals,
-                                                           const int32_t* pts2, int32_t* bk, const uint32_t* order, uint32_t cap) {
+                                                           const int32_t* pts2, int32_t* bk, const uint32_t* order, uint32_t cap, uint32_t early_max) {
     const size_t slot = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (slot >= nbk) return;
     const size_t b = order[slot];
     g1p acc, nn;
-    const size_t l = lo[b], h = hi[b];
+    const size_t l = lo[b];
+    size_t h = hi[b];
+    if (b == nbk - 1 && h - l <= early_max) h = l;                 // summed by msm_small_early_kernel (see msm_sizes_kernel)
     msm_bucket_one(acc, l, h - l > cap ? l + cap : h, vals, pts2);
     g1_norm1(nn, acc);
     tab_store_g1(bk + b * G1_ENT_DWORDS, nn);
@@ -536,12 +557,10 @@ __device__ __forceinline__ void g1_mul_absx_quad(g1p& p, int r) {
 // term = [r]phi(S) for S = bucket `sbucket`, the sum of the points whose scalar is below x^2 (msm.hpp) — g1_glv_small_scalar_term's
 // sequence on ONE QUAD: a membership test of 126 doublings (phi(phi(S)) = [-x^2]phi(S) iff S is in G1) when any scalar was small,
 // the 255-bit multiple only for S outside G1, an immediate return for an empty bucket.  A single lane took 1.57 ms for the test —
-// longer than the window reductions it hides behind on the side stream; the quad takes a third of that.
-__global__ void __launch_bounds__(BLOCK, 2) msm_small_term_kernel(const int32_t* sbucket, int32_t* term_out) {
-    if (threadIdx.x >= 4 || blockIdx.x != 0) return;
-    const int r = (int)(threadIdx.x & 3u);
-    g1p S, term, nn;
-    tab_load_g1(S, sbucket);
+// longer than the window reductions it hides behind on the side stream; the quad takes a third of that.  One wavefront of 64 with the
+// whole register file (like msm_horner_kernel): under the 256-register budget of the other kernels its seven live points spilled (101
+// registers) and the test took 0.87 ms — it then ran on beside the first fold of the window sums and slowed that one from 80 to 360 us.
+__device__ __forceinline__ void msm_small_term_quad(g1p& term, const g1p& S, int r) {
     g1_set_inf(term);
     if (!g1_is_inf(S)) {                                       // quad-uniform
         fp beta;
@@ -568,8 +587,57 @@ __global__ void __launch_bounds__(BLOCK, 2) msm_small_term_kernel(const int32_t*
             term = s2;
         }
     }
+}
+// after the bucket kernel: the term for a small-scalar bucket too long for msm_small_early_kernel (which has otherwise done the work: *done != 0)
+__global__ void __launch_bounds__(64, 1) msm_small_term_kernel(const int32_t* sbucket, int32_t* term_out, const uint32_t* done) {
+    if (threadIdx.x >= 4 || blockIdx.x != 0 || *done != 0u) return;
+    const int r = (int)(threadIdx.x & 3u);
+    g1p S, term, nn;
+    tab_load_g1(S, sbucket);
+    msm_small_term_quad(term, S, r);
     g1_norm1(nn, term);
     if (r == 0) tab_store_g1(term_out, nn);
+}
+// The same BEFORE the bucket kernel, on the side stream, for a small-scalar bucket of at most `early_max` entries (the usual case: none, or
+// the odd scalar 0 < k < x^2 of a batch): one wavefront adds the entries up (lane-strided, then six shuffle steps) and its first quad runs
+// the membership test while the bucket kernel works — the 0.9 ms of the test are hidden instead of standing between the window reductions
+// and the Horner chain (and slowing the first fold they ran beside from 80 to 300 us).  msm_sizes_kernel / msm_bucket_kernel treat that
+// bucket as empty under the same condition.  *done = 1 when the term has been written.
+__global__ void __launch_bounds__(64, 1) msm_small_early_kernel(const uint32_t* lo, const uint32_t* hi, uint32_t small_bucket, uint32_t early_max,
+                                                             const uint32_t* vals, const int32_t* pts2, int32_t* term_out, uint32_t* done) {
+    if (blockIdx.x != 0) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t l = lo[small_bucket], h = hi[small_bucket];
+    if (h - l > early_max) { if (lane == 0) *done = 0u; return; }      // wave-uniform
+    g1p acc, t, nn;
+    g1_set_inf(acc);
+    if (h > l) {
+#pragma unroll 1
+        for (uint32_t j = l + lane; j < h; j += 64u) {
+            fp x, y;
+            msm_load_pt(x, y, pts2 + (size_t)vals[j] * MSM_PT_STRIDE);
+            g1_add_affine(acc, x, y);
+        }
+        g1_norm1(nn, acc); acc = nn;
+#pragma unroll 1
+        for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                t.x.l[i] = __shfl_down(acc.x.l[i], off, 64); t.y.l[i] = __shfl_down(acc.y.l[i], off, 64); t.z.l[i] = __shfl_down(acc.z.l[i], off, 64);
+            }
+            g1_add(acc, t);
+            g1_norm1(nn, acc); acc = nn;
+        }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {                                 // the sum sits in lane 0: replicate it over the first quad
+            acc.x.l[i] = __shfl(acc.x.l[i], 0, 64); acc.y.l[i] = __shfl(acc.y.l[i], 0, 64); acc.z.l[i] = __shfl(acc.z.l[i], 0, 64);
+        }
+    }
+    if (lane >= 4u) return;
+    g1p term;
+    msm_small_term_quad(term, acc, (int)lane);
+    g1_norm1(nn, term);
+    if (lane == 0) { tab_store_g1(term_out, nn); *done = 1u; }
 }
 
 // R = sum_w 2^(c w) R_w + term: the Horner chain on one quad (lanes 0..3 of a wavefront), doublings spread over its lanes

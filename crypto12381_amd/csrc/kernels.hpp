@@ -52,15 +52,18 @@ __global__ void __launch_bounds__(BLOCK, 2) msm_prep_kernel(size_t n, const uint
 __global__ void __launch_bounds__(BLOCK, 2) msm_ranges_kernel(size_t E, const uint32_t* keys, int c, int W, uint32_t* lo, uint32_t* hi);
 __global__ void __launch_bounds__(BLOCK, 2) msm_prep16_kernel(size_t n, const uint8_t* pts, int in_fmt, const uint8_t* scalars, int c, int W, int32_t* pts2, uint16_t* keys, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) msm_ranges16_kernel(size_t n, const uint16_t* keys, int c, int W, uint32_t* lo, uint32_t* hi);
-__global__ void __launch_bounds__(BLOCK, C12381_MSM_OCC) msm_bucket_kernel(size_t nbk, const uint32_t* lo, const uint32_t* hi, const uint32_t* vals, const int32_t* pts2, int32_t* bk, const uint32_t* order, uint32_t cap);
-__global__ void __launch_bounds__(BLOCK, 2) msm_sizes_kernel(size_t nbk, const uint32_t* lo, const uint32_t* hi, uint32_t* key, uint32_t* ident, uint32_t cap, uint32_t* cnt, uint2* seg, uint4* big);
+constexpr int MSM_RANGES_PER_THREAD = 8;           // entries per thread of msm_ranges16_kernel (the host sizes its grid with it)
+__global__ void __launch_bounds__(BLOCK, C12381_MSM_OCC) msm_bucket_kernel(size_t nbk, const uint32_t* lo, const uint32_t* hi, const uint32_t* vals, const int32_t* pts2, int32_t* bk, const uint32_t* order, uint32_t cap, uint32_t early_max);
+__global__ void __launch_bounds__(BLOCK, 2) msm_sizes_kernel(size_t nbk, const uint32_t* lo, const uint32_t* hi, uint32_t* key, uint32_t* ident, uint32_t cap, uint32_t* cnt, uint2* seg, uint4* big, uint32_t early_max);
 __global__ void __launch_bounds__(BLOCK, 2) msm_overflow_kernel(const uint32_t* cnt, const uint2* seg, const uint32_t* lo, const uint32_t* hi, const uint32_t* vals, const int32_t* pts2, int32_t* part, uint32_t cap);
 __global__ void __launch_bounds__(BLOCK, 2) msm_overflow_combine_kernel(const uint32_t* cnt, const uint4* big, const int32_t* part, int32_t* bk);
 __global__ void __launch_bounds__(BLOCK, 2) msm_wreduce_kernel(int W, uint32_t nb, uint32_t chunks, const int32_t* bk, int32_t* out, size_t out_stride);
 __global__ void __launch_bounds__(BLOCK, 2) g1_decompress_kernel(size_t n, const uint8_t* in, uint8_t* out, uint8_t* status, int mark_invalid);
 __global__ void __launch_bounds__(64, 1) msm_horner_kernel(const int32_t* rw, size_t stride, int W, int c, int32_t* out, size_t out_stride, const int32_t* term_in);
 __global__ void __launch_bounds__(BLOCK, 2) g1_wave_reduce_kernel(size_t groups, int W, const int32_t* in, size_t in_stride, int32_t* outp, size_t out_stride);
-__global__ void __launch_bounds__(BLOCK, 2) msm_small_term_kernel(const int32_t* sbucket, int32_t* term_out);
+__global__ void __launch_bounds__(64, 1) msm_small_term_kernel(const int32_t* sbucket, int32_t* term_out, const uint32_t* done);
+__global__ void __launch_bounds__(64, 1) msm_small_early_kernel(const uint32_t* lo, const uint32_t* hi, uint32_t small_bucket, uint32_t early_max, const uint32_t* vals, const int32_t* pts2, int32_t* term_out, uint32_t* done);
+constexpr uint32_t MSM_SMALL_EARLY_MAX = 4096;     // longest small-scalar bucket msm_small_early_kernel takes (64 additions per lane)
 __global__ void __launch_bounds__(BLOCK, 2) g2_mul_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab, size_t tab_stride, uint8_t* out, int fmt, int* bad_flag, const int32_t* skip_if, int32_t* proj, size_t proj_stride, size_t proj_off, int in_g2);
 __global__ void __launch_bounds__(BLOCK, C12381_G2H_OCC) g2_mul2_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab, int* bad_flag, const int32_t* skip_if, int32_t* proj, size_t proj_stride, size_t proj_off, int in_g2);
 __global__ void __launch_bounds__(BLOCK, 2) g2_finish_kernel(size_t n, const int32_t* proj, size_t stride, int32_t* pref, uint8_t* out, int fmt, size_t T);

@@ -175,14 +175,6 @@ C12381_HD void msm_ranges_one(size_t j, size_t E, const uint32_t* keys, int c, i
     if (j == 0 || keys[j - 1] != k) lo[b] = (uint32_t)j;
     if (j + 1 == E || keys[j + 1] != k) hi[b] = (uint32_t)(j + 1);
 }
-// the same for digit-only keys: entry x of window segment w (w = W: the small-scalar segment); seg = the segment's first entry, len its length
-C12381_HD void msm_ranges_seg(uint32_t x, uint32_t len, size_t seg, uint32_t w, const uint16_t* keys, int c, int W, uint32_t* lo, uint32_t* hi) {
-    const uint32_t d = keys[seg + x];
-    if (d == 0) return;
-    const uint32_t b = w < (uint32_t)W ? ((w << c) | d) : ((uint32_t)W << c);
-    if (x == 0 || keys[seg + x - 1] != d) lo[b] = (uint32_t)(seg + x);
-    if (x + 1 == len || keys[seg + x + 1] != d) hi[b] = (uint32_t)(seg + x + 1);
-}
 // bucket: sum of the points whose (sorted) entries lie in [lo, hi)
 // The gather (index -> 112-byte record somewhere in a table of 2n records) is a two-step dependent load of a few
 // microseconds; it is software-pipelined: while point j is added, point j+1 and index j+2 are already in flight.

@@ -137,7 +137,7 @@ def test_msm_bucket_method_vs_naive_and_oracle(ctx, oracle_port):
 
 def test_msm_large_product_path_vs_oracle(ctx, oracle_port):
     """From 2^15 terms on the product sorts 16-bit digit keys per window segment with positional values (c12381_hip.hip, msm.hpp
-    msm_entry_value / msm_ranges_seg); below that one sort over 32-bit keys.  Both sides of the switch against the oracle's chain of
+    msm_entry_value, k_g1.hip msm_ranges16_kernel); below that one sort over 32-bit keys.  Both sides of the switch against the oracle's chain of
     multiply() results, with the inputs that take the special routes: infinity, zero and small scalars (the [r]phi(S) bucket), points
     outside the subgroup, a run of equal scalars long enough to be cut into overflow segments."""
     g = golden("g1")

@@ -19,7 +19,10 @@ nm = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 22)
 p = c.g1_mul(G1 * 1024, sc(6, 1024), 96)
 pm = (p * ((nm * 96 + len(p) - 1) // len(p)))[: nm * 96]
 dpm = torch.frombuffer(bytearray(pm), dtype=torch.uint8).to(dev)
-dkm = torch.frombuffer(bytearray(sc(8, nm)), dtype=torch.uint8).to(dev)
+ks = bytearray(sc(8, nm))
+if len(sys.argv) > 2 and sys.argv[2] == "edge":          # scalar 1 in lane 1: the small-scalar bucket is in use (as on bench.py's edge lanes)
+    ks[32:64] = (1).to_bytes(32, "big")
+dkm = torch.frombuffer(ks, dtype=torch.uint8).to(dev)
 om = torch.empty(96, dtype=torch.uint8, device=dev)
 for rep in range(4):
     t0 = time.perf_counter()
