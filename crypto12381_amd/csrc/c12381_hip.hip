@@ -145,11 +145,21 @@ int g1_mul_to_proj(c12381_ctx* c, size_t n, const uint8_t* d_pts, const uint8_t*
     }
     return 0;
 }
+// Lanes of the simultaneous inversion (g1_finish_kernel / g2_finish_kernel: lane t converts elements t, t + T, ...): one lane per element up
+// to one machine round of single wavefronts (65 536 lanes), then up to FINISH_M elements per lane.  The kernels are latency-bound — an
+// inversion is a chain of 28 K dependent instructions whatever the number of lanes running it — so idle SIMDs are cheaper than long lanes:
+// 2^18 G2 elements at 16 per lane took 0.50 ms (a quarter wavefront per SIMD, 16 x 15 products behind each inversion).
+static size_t finish_lanes(size_t n) {
+    size_t per = (n + 65535) / 65536;
+    if (per > (size_t)FINISH_M) per = FINISH_M;
+    if (per < 1) per = 1;
+    const size_t T = round_up((n + per - 1) / per, 64);
+    return T > n ? n : T;
+}
 int g1_finish(c12381_ctx* c, size_t n, const int32_t* proj, size_t stride, uint8_t* d_out, int fmt) {
     int rc;
     if ((rc = ensure(c, c12381_ctx::WS_PREF, (size_t)NL * stride * 4))) return rc;
-    size_t T = round_up((n + FINISH_M - 1) / FINISH_M, 64);
-    if (T > n) T = n;
+    const size_t T = finish_lanes(n);
     timed tm(c, 1);
     hipLaunchKernelGGL(g1_finish_kernel, dim3(grid_for(T)), dim3(BLOCK), 0, c->stream, n, proj, stride,
                        (int32_t*)c->ws[c12381_ctx::WS_PREF], d_out, fmt, T);
@@ -698,8 +708,7 @@ static int g2_finish(c12381_ctx* c, size_t n, uint8_t* d_out, int fmt) {
     int rc;
     const size_t stride = round_up(n, 64);
     if ((rc = ensure(c, c12381_ctx::WS_PREF, (size_t)2 * NL * stride * 4))) return rc;
-    size_t T = round_up((n + FINISH_M - 1) / FINISH_M, 64);
-    if (T > n) T = n;
+    const size_t T = finish_lanes(n);
     hipLaunchKernelGGL(g2_finish_kernel, dim3(grid_for(T)), dim3(BLOCK), 0, c->stream, n, (const int32_t*)c->ws[c12381_ctx::WS_PROJ], stride,
                        (int32_t*)c->ws[c12381_ctx::WS_PREF], d_out, fmt, T);
     HIPCK(c, hipGetLastError());

@@ -15,7 +15,7 @@
 namespace c12381 {
 
 constexpr int BLOCK = 256;
-constexpr int FINISH_M = 16;                     // elements per lane in the simultaneous inversion
+constexpr int FINISH_M = 16;                     // most elements per lane in the simultaneous inversion (c12381_hip.hip finish_lanes)
 constexpr int TRI_PER_WAVE = 21;                 // pairings per 64-lane wavefront in the three-lane kernels (lane 63 idles along)
 // Header words in front of a device-built table (fixed-base multiples, line coefficients) and of a gate buffer
 constexpr int HDR_VALID = 48;                    // 1 = table usable / this path runs; kernels of the other path return at once

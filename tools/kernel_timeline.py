@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Timeline of the LAST bucket product in a rocprofv3 --kernel-trace of tools/msm_only.py: start offset, duration and the idle gap before
-every kernel (both streams).   python3 tools/msm_timeline.py <trace dir>"""
+"""Timeline of the LAST call of an entry point in a rocprofv3 --kernel-trace: start offset, duration and the idle gap before every kernel
+(all streams), from the last launch of the kernel whose name contains <first-kernel> (default msm_prep: one bucket product of tools/msm_only.py).
+    python3 tools/kernel_timeline.py <trace dir> [first-kernel substring]"""
 import csv
 import glob
 import re
@@ -9,7 +10,8 @@ import sys
 path = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(path)))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Stream_Id", r.get("Queue_Id", "?"))) for r in rows))
-starts = [i for i, e in enumerate(ev) if "msm_prep" in e[2]]
+FIRST = sys.argv[2] if len(sys.argv) > 2 else "msm_prep"
+starts = [i for i, e in enumerate(ev) if FIRST in e[2]]
 first = starts[-1]
 t0 = ev[first][0]
 end_prev = t0
