@@ -1,5 +1,5 @@
 # kernel trace of a few 2^22-term bucket products (tools/msm_only.py): where the time between the kernels goes
-#   bash tools/msm_trace.sh <tag> [edge]      -> gpurun_out/<tag>/msm_timeline.txt  ("edge": scalar 1 in lane 1, so the small-scalar bucket is used)
+#   [C12381_LIB=<variant .so>] bash tools/msm_trace.sh <tag> [edge]      -> gpurun_out/<tag>/msm_timeline.txt  ("edge": scalar 1 in lane 1, so the small-scalar bucket is used)
 TAG=${1:-msmtrace}
 ROOT=$GRAFT_REPO_ROOT
 mkdir -p $ROOT/gpurun_out/$TAG
