@@ -202,6 +202,14 @@ def test_msm_small_scalars_outside_the_subgroup(ctx, oracle_port):
     # unit scalars on points outside G1: every term owes [r]phi(P)
     ones = (1).to_bytes(32, "big") * (len(off) // 96) * reps
     assert ctx.g1_msm(off * reps, ones, 96) == oracle_port.g1_msm(off * reps, ones, 96, 16)
+    # the small-scalar bucket is summed by a wavefront of its own in front of the bucket kernel up to 4 096 entries (msm_small_early_kernel)
+    # and by the bucket kernel beyond: both sides of the switch, a count that leaves lanes of that wavefront empty, and a single entry
+    m = len(off) // 96
+    for small in (1, 100, 4096, 4097):
+        sp = (off * (small // m + 1))[:96 * small]
+        ss = (osc * (small // m + 1))[:32 * small]
+        p2, s2 = sp + norm_pts, ss + scalars(633 + small, n_norm, 1 << 256)
+        assert ctx.g1_msm(p2, s2, 96) == oracle_port.g1_msm(p2, s2, 96, 16), small
 
 
 def test_fixed_base_entry_points(ctx, oracle_port):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Parity soak: fresh random inputs every iteration, EVERY lane of every batch against the compiled reference (oracle/_ref, all host
 threads), for a time budget.  Not a rerun of one input set: each iteration draws new points and scalars from its own seed, so the run
-widens the set of inputs the GPU path has been compared on (G1 / G2 scalar multiplications, pairings incl. the split forms, bucket MSM).
+widens the set of inputs the GPU path has been compared on (G1 / G2 scalar multiplications, pairings incl. the split forms, GT powers on both routes, bucket MSM).
 
     python tools/parity_soak.py [--minutes 6] [--log2-g1 17] [--log2-g2 15] [--log2-pair 14] [--log2-msm 15]
 """
@@ -45,7 +45,7 @@ def main():
     n1, n2, n3, n4 = 1 << a.log2_g1, 1 << a.log2_g2, 1 << a.log2_pair, 1 << a.log2_msm
     t0 = time.time()
     it = 0
-    lanes = {"g1_mul": 0, "g2_mul": 0, "pair": 0, "miller": 0, "fexp": 0, "msm_terms": 0}
+    lanes = {"g1_mul": 0, "g2_mul": 0, "pair": 0, "miller": 0, "fexp": 0, "gt_pow": 0, "msm_terms": 0}
     while time.time() - t0 < a.minutes * 60:
         rng = np.random.Generator(np.random.PCG64(a.seed + it))
         # inputs: random multiples of the generators made on the GPU; the reference decodes them itself (a point off the curve fails there)
@@ -67,6 +67,14 @@ def main():
         lanes["pair"] += n3
         lanes["miller"] += n3
         lanes["fexp"] += n3
+        # GT powers: pairing values (windowed ladder) with one Miller value per 64 elements spliced in (its wavefront takes the reference's digit
+        # sequence); exponents = the G1 scalars, edge values in front
+        n5 = min(n3, 2048)
+        base = bytearray(gt[:576 * n5])
+        for j in range(31, n5, 64):
+            base[576 * j:576 * j + 576] = mil[576 * j:576 * j + 576]
+        assert c.gt_op("pow", bytes(base), k1[:32 * n5]) == ref.gt_op("pow", bytes(base), k1[:32 * n5]), ("gt_pow", it)
+        lanes["gt_pow"] += n5
         m1, mk = p1[:96 * n4], k1[:32 * n4]
         assert c.g1_msm(m1, mk, 96) == ref.g1_msm(m1, mk, 96, cores), ("msm", it)
         lanes["msm_terms"] += n4
