@@ -22,6 +22,27 @@ __device__ __forceinline__ size_t queue_direct_groups(size_t ngroups, size_t nwa
     if (ov > 0) queued = (size_t)ov < ngroups ? (size_t)ov : ngroups;
     return ngroups - queued;
 }
+// Issue priority of the two kinds of work (s_setprio) — an experiment, OFF (profiles/r04_ab_queue_priority.txt).  A SIMD serves the older of its two
+// wavefronts first, so a wavefront that has finished its whole groups and moved on to queue tasks keeps the younger one's whole group waiting.
+// 1: whole groups at a raised priority, tasks at the default ("longest job first") — 2^16 pairings 16.9 -> 33.2 ms: a task wavefront that cannot
+// issue at all holds its group's chain up, and the wavefronts that claimed the following phases spin behind it.  2: everything raised, 3: the
+// tasks raised — both within 0.5 % of no priorities at all (what the age order already does).
+#ifndef C12381_QUEUE_PRIO
+#define C12381_QUEUE_PRIO 0
+#endif
+#if C12381_QUEUE_PRIO == 1
+#define C12381_QUEUE_PRIO_WHOLE() __builtin_amdgcn_s_setprio(2)
+#define C12381_QUEUE_PRIO_TASKS() __builtin_amdgcn_s_setprio(0)
+#elif C12381_QUEUE_PRIO == 2      // experiment: everything at the raised priority
+#define C12381_QUEUE_PRIO_WHOLE() __builtin_amdgcn_s_setprio(2)
+#define C12381_QUEUE_PRIO_TASKS() __builtin_amdgcn_s_setprio(2)
+#elif C12381_QUEUE_PRIO == 3      // experiment: the tasks first
+#define C12381_QUEUE_PRIO_WHOLE() __builtin_amdgcn_s_setprio(0)
+#define C12381_QUEUE_PRIO_TASKS() __builtin_amdgcn_s_setprio(2)
+#else
+#define C12381_QUEUE_PRIO_WHOLE() ((void)0)
+#define C12381_QUEUE_PRIO_TASKS() ((void)0)
+#endif
 namespace c12381 {
 int set_queue_groups_override(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(g_queue_groups_override), &v, sizeof(int)) == hipSuccess ? 0 : -1; }
 }
@@ -238,6 +259,7 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
     // ndirect = 0 when the batch fits the grid (queue forced on for a small batch: tests of the queue path).
     const size_t nwaves = (size_t)gridDim.x * (BLOCK / 64);
     const size_t ndirect = queue_direct_groups(ngroups, nwaves);
+    C12381_QUEUE_PRIO_WHOLE();
     for (;;) {
         const unsigned int gc = atomicAdd(counter + 1, lane == 0 ? 1u : 0u);
         const size_t g = (size_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)gc);
@@ -245,6 +267,7 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
         const size_t e = g * TRI_PER_WAVE + (lane == 63u ? TRI_PER_WAVE - 1 : trip);
         pair3_whole_group<EQ>(e < n ? e : n - 1, lane < 63u && e < n, a1, a2, b1, b2, b2_stride, out, bad_flag, H, t);
     }
+    C12381_QUEUE_PRIO_TASKS();
     const size_t nq = ngroups - ndirect;                       // queued groups: ndirect .. ngroups - 1
     const size_t ntasks = nq * TASKS;
     for (;;) {
@@ -386,6 +409,7 @@ __device__ __forceinline__ void split3_queue_body(size_t n, const uint8_t* in1, 
     constexpr int ROWS = ST_Y1 + ST_ROWS_F;
     const size_t nwaves = (size_t)gridDim.x * (BLOCK / 64);
     const size_t ndirect = queue_direct_groups(ngroups, nwaves);
+    C12381_QUEUE_PRIO_WHOLE();
     for (;;) {                                                 // whole groups first
         const unsigned int gc = atomicAdd(counter + 1, lane == 0 ? 1u : 0u);
         const size_t g = (size_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)gc);
@@ -409,6 +433,7 @@ __device__ __forceinline__ void split3_queue_body(size_t n, const uint8_t* in1, 
             if (active) gt_store_coeff(out + 576 * i, r, t.role);
         }
     }
+    C12381_QUEUE_PRIO_TASKS();
     const size_t nq = ngroups - ndirect;
     const size_t ntasks = nq * TASKS;
     for (;;) {
@@ -533,6 +558,7 @@ __device__ __forceinline__ void pair3_fixed_queue_body(size_t n, const uint8_t* 
     // whole groups first, the last third of the groups through the queue (see pair3_queue_body)
     const size_t nwaves = (size_t)gridDim.x * (BLOCK / 64);
     const size_t ndirect = queue_direct_groups(ngroups, nwaves);
+    C12381_QUEUE_PRIO_WHOLE();
     for (;;) {
         const unsigned int gc = atomicAdd(counter + 1, lane == 0 ? 1u : 0u);
         const size_t g = (size_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)gc);
@@ -566,6 +592,7 @@ __device__ __forceinline__ void pair3_fixed_queue_body(size_t n, const uint8_t* 
             else gt_store_coeff(out + 576 * e, F, t.role);
         }
     }
+    C12381_QUEUE_PRIO_TASKS();
     const size_t nq = ngroups - ndirect;
     const size_t ntasks = nq * TASKS;
     for (;;) {
