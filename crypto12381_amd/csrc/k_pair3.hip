@@ -183,6 +183,7 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_kernel(size_t n, const uint8_t
     tri t; size_t i; bool active;
     tri_setup(t, i, active, n);
     __shared__ fp4_slot slots[BLOCK];
+    slot_fair_set(slots[threadIdx.x].v, 1);                      // plain grid: the two wavefronts of a SIMD take turns (pairing3.hpp C12381_FAIR_SHARE)
     pair3_whole_group<false>(i, active, g1, g2, nullptr, nullptr, 0, gt, bad_flag, slots[threadIdx.x].v, t);
 }
 
@@ -193,6 +194,7 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_kernel(size_t n, const uint
     tri t; size_t i; bool active;
     tri_setup(t, i, active, n);
     __shared__ fp4_slot slots[BLOCK];
+    slot_fair_set(slots[threadIdx.x].v, 1);                      // plain grid: the two wavefronts of a SIMD take turns (pairing3.hpp C12381_FAIR_SHARE)
     pair3_whole_group<true>(i, active, a1, a2, b1, b2, b2_stride, out, bad_flag, slots[threadIdx.x].v, t);
 }
 
@@ -205,6 +207,7 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_prod_kernel(size_t n, int k, c
     tri t; size_t i; bool active;
     tri_setup(t, i, active, n);
     __shared__ fp4_slot slots[BLOCK];
+    slot_fair_set(slots[threadIdx.x].v, 1);                      // plain grid: the two wavefronts of a SIMD take turns (pairing3.hpp C12381_FAIR_SHARE)
     fp4& H = slots[threadIdx.x].v;
     miller3_pair pr[MAX_PROD];
     bool ok = true;
@@ -259,13 +262,20 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
     // ndirect = 0 when the batch fits the grid (queue forced on for a small batch: tests of the queue path).
     const size_t nwaves = (size_t)gridDim.x * (BLOCK / 64);
     const size_t ndirect = queue_direct_groups(ngroups, nwaves);
+    const unsigned long long ts_entry = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     C12381_QUEUE_PRIO_WHOLE();
     for (;;) {
         const unsigned int gc = atomicAdd(counter + 1, lane == 0 ? 1u : 0u);
         const size_t g = (size_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)gc);
         if (g >= ndirect) break;
         const size_t e = g * TRI_PER_WAVE + (lane == 63u ? TRI_PER_WAVE - 1 : trip);
+        const unsigned long long ts_g0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
         pair3_whole_group<EQ>(e < n ? e : n - 1, lane < 63u && e < n, a1, a2, b1, b2, b2_stride, out, bad_flag, H, t);
+        if (stamps && lane == 0) {                             // diagnostic: whole groups behind the queued groups' tasks (entry 10 nq + g)
+            unsigned long long* o = stamps + 4 * ((ngroups - ndirect) * (size_t)TASKS + g);
+            o[0] = ts_entry; o[1] = ts_g0; o[2] = __builtin_amdgcn_s_memtime();
+            o[3] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+        }
     }
     C12381_QUEUE_PRIO_TASKS();
     const size_t nq = ngroups - ndirect;                       // queued groups: ndirect .. ngroups - 1
@@ -381,6 +391,7 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
 __global__ void __launch_bounds__(BLOCK, 2) pair3_queue_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag, uint4* state,
                                                             unsigned int* flags, unsigned int* counter, int spin_limit, unsigned long long* stamps) {
     __shared__ fp4_slot slots[BLOCK];
+    slot_fair_set(slots[threadIdx.x].v, 0);
     pair3_queue_body<false>(n, g1, g2, nullptr, nullptr, 0, gt, bad_flag, state, flags, counter, spin_limit, slots[threadIdx.x].v, stamps);
 }
 __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_queue_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2,
@@ -388,6 +399,7 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_queue_kernel(size_t n, cons
                                                                unsigned int* counter, const int32_t* skip_if, int spin_limit) {
     if (skip_if && skip_if[HDR_VALID] != 0) return;
     __shared__ fp4_slot slots[BLOCK];
+    slot_fair_set(slots[threadIdx.x].v, 0);
     pair3_queue_body<true>(n, a1, a2, b1, b2, b2_stride, out, bad_flag, state, flags, counter, spin_limit, slots[threadIdx.x].v);
 }
 
@@ -501,11 +513,13 @@ __device__ __forceinline__ void split3_queue_body(size_t n, const uint8_t* in1, 
 __global__ void __launch_bounds__(BLOCK, 2) miller3_queue_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* out, int* bad_flag, uint4* state,
                                                               unsigned int* flags, unsigned int* counter, int spin_limit) {
     __shared__ fp4_slot slots[BLOCK];
+    slot_fair_set(slots[threadIdx.x].v, 0);
     split3_queue_body<true>(n, g1, g2, out, bad_flag, state, flags, counter, spin_limit, slots[threadIdx.x].v);
 }
 __global__ void __launch_bounds__(BLOCK, 2) fexp3_queue_kernel(size_t n, const uint8_t* in576, uint8_t* out, int* bad_flag, uint4* state,
                                                             unsigned int* flags, unsigned int* counter, int spin_limit) {
     __shared__ fp4_slot slots[BLOCK];
+    slot_fair_set(slots[threadIdx.x].v, 0);
     split3_queue_body<false>(n, in576, nullptr, out, bad_flag, state, flags, counter, spin_limit, slots[threadIdx.x].v);
 }
 
@@ -671,12 +685,14 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_prod_fixed_queue_kernel(size_t
                                                                        unsigned int* flags, unsigned int* counter, const int32_t* run_if, int spin_limit) {
     if (run_if[HDR_VALID] == 0) return;
     __shared__ fp4_slot slots[BLOCK];
+    slot_fair_set(slots[threadIdx.x].v, 0);
     pair3_fixed_queue_body<true>(n, a96, c96, tabw, tabg, out, bad_flag, state, flags, counter, spin_limit, true, slots[threadIdx.x].v);
 }
 // gt[i] = e(P_i, Q) for ONE Q given by its coefficient table (header at `buf`, lines behind it)
 __global__ void __launch_bounds__(BLOCK, 2) pair3_fixed_queue_kernel(size_t n, const uint8_t* g1_96, const int32_t* buf, uint8_t* gt, int* bad_flag,
                                                                   uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit) {
     __shared__ fp4_slot slots[BLOCK];
+    slot_fair_set(slots[threadIdx.x].v, 0);
     pair3_fixed_queue_body<false>(n, g1_96, nullptr, buf + HDR_DWORDS, nullptr, gt, bad_flag, state, flags, counter, spin_limit, buf[HDR_VALID] != 0, slots[threadIdx.x].v);
 }
 
@@ -690,6 +706,7 @@ __global__ void __launch_bounds__(BLOCK, 2) miller3_kernel(size_t n, const uint8
     pair_inputs(px, py, pinf, qx, qy, qinf, ok, g1 + 96 * i, g2 + 192 * i);
     if (!ok) { if (active) *bad_flag = 1; pinf = true; qinf = true; }
     __shared__ fp4_slot slots[BLOCK];
+    slot_fair_set(slots[threadIdx.x].v, 1);                      // plain grid: the two wavefronts of a SIMD take turns (pairing3.hpp C12381_FAIR_SHARE)
     fp4& H = slots[threadIdx.x].v;
     miller3_loop(H, px, py, pinf, qx, qy, qinf, t);
     if (active) {
@@ -705,6 +722,7 @@ __global__ void __launch_bounds__(BLOCK, 2) gt3_op_kernel(int op, size_t n, cons
     tri t; size_t i; bool active;
     tri_setup(t, i, active, n);
     __shared__ fp4_slot slots[BLOCK];
+    slot_fair_set(slots[threadIdx.x].v, 1);                      // plain grid: the two wavefronts of a SIMD take turns (pairing3.hpp C12381_FAIR_SHARE)
     fp4& H = slots[threadIdx.x].v;
     fp4 x, r;
     gt_load_coeff(x, a + 576 * i, t.role);

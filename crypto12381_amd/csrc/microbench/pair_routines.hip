@@ -41,6 +41,7 @@ __device__ __forceinline__ void store_fp4(int32_t* p, const fp4& r) {
 template <int KIND>
 __global__ void __launch_bounds__(BLOCK, PR_WAVES) routine_kernel(int iters, const int32_t* seed, int32_t* sink, uint64_t* stamps) {
     __shared__ fp4_slot slots[BLOCK];
+    slot_fair_set(slots[threadIdx.x].v, 0);
     fp4& H = slots[threadIdx.x].v;
     const unsigned lane = threadIdx.x & 63u;
     const unsigned trip = lane / 3u;

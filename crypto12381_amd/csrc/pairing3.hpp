@@ -74,6 +74,23 @@ C12381_HD int wave_uniform(int v) { return v; }
 // C12381_PHASE(): a scheduling fence.  The build schedules for instruction-level parallelism (build.py), and two independent Fp4
 // products in one routine are exactly what such a scheduler interleaves — doubling the live registers and spilling hundreds of
 // dwords.  The fence keeps the phases of a routine apart (no instruction crosses it), as a call boundary used to.
+// C12381_FAIR_SHARE(i, slot), once per iteration of the long loops, in the kernels that ask for it (slot_fair_set: the plain grids): the wavefront in
+// an ODD hardware slot of its SIMD raises its issue priority in every other iteration.  A SIMD serves the older of its two wavefronts first
+// whenever both can issue: the one in slot 0 ran a whole pairing in 15.0 M cycles, its partner in 37.7 M (tools/queue_whole_groups.py) — in a
+// launch that just fills the machine the partner then finishes alone, at the issue efficiency of a single wavefront.  Alternating the younger
+// one's priority evens the pair out: 2048 wavefronts of pairings 11.87 -> 11.35 ms.  NOT in the work-queue kernels: there the older wavefront's
+// head start is what the queued tasks fill, and a task holder that is held back stalls the wavefronts waiting for its hand-over (2^16
+// pairings 17.5 -> 20.3 ms with the alternation on; profiles/r04_ab_fair_share.txt).
+#ifndef C12381_FAIR
+#define C12381_FAIR 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && C12381_FAIR
+// (the conditions as scalars: on per-lane values the two branches become two exec-masked regions and BOTH s_setprio execute)
+#define C12381_FAIR_SHARE(i, slot) do { if ((__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1u) && __builtin_amdgcn_readfirstlane(slot_fair(slot)) != 0) { \
+        if (__builtin_amdgcn_readfirstlane((int)(i)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } } while (0)
+#else
+#define C12381_FAIR_SHARE(i, slot) do { } while (0)
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define C12381_PHASE() __builtin_amdgcn_sched_barrier(0)
 #else
@@ -97,6 +114,10 @@ C12381_HD void slot_load(fp4& r, const fp4& slot) { slot_rd(r, (const c12381_lds
 C12381_HD void slot_store(fp4& slot, const fp4& r) { slot_wr((c12381_lds_v4i*)(&slot), r); }
 C12381_HD void slot_unpark(fp4& r, const fp4& slot) { slot_rd(r, (const volatile c12381_lds_v4i*)(&slot)); }
 C12381_HD void slot_park(fp4& slot, const fp4& r) { slot_wr((volatile c12381_lds_v4i*)(&slot), r); }
+// the last row of the lane's pair_slot (pad[2]): "alternate the issue priority" (C12381_FAIR_SHARE); every kernel that declares slots sets it
+typedef __attribute__((address_space(3))) int32_t c12381_lds_i32;
+C12381_HD void slot_fair_set(fp4& slot, int on) { ((volatile c12381_lds_i32*)(&slot))[72] = on; }
+C12381_HD int slot_fair(const fp4& slot) { return ((const volatile c12381_lds_i32*)(&slot))[72]; }
 // one Fp2 half of the slot's Fp4 (half 0 = .a: rows 0..6, half 1 = .b: rows 7..13); `half` may differ from lane to lane (an LDS
 // address is per lane anyway): a role-dependent placement of two results costs an address, not 56 selects
 static_assert(sizeof(fp2) == 7 * 16, "an fp2 is 7 rows of 16 bytes");
@@ -117,6 +138,8 @@ C12381_HD void slot_load(fp4& r, const fp4& slot) { r = slot; }
 C12381_HD void slot_store(fp4& slot, const fp4& r) { slot = r; }
 C12381_HD void slot_unpark(fp4& r, const fp4& slot) { r = slot; }
 C12381_HD void slot_park(fp4& slot, const fp4& r) { slot = r; }
+C12381_HD void slot_fair_set(fp4&, int) {}
+C12381_HD int slot_fair(const fp4&) { return 0; }
 C12381_HD void slot_load_half(fp2& r, const fp4& slot, int half) { r = half ? slot.b : slot.a; }
 C12381_HD void slot_store_half(fp4& slot, int half, const fp2& r) { (half ? slot.b : slot.a) = r; }
 #endif
@@ -709,6 +732,7 @@ C12381_HDN void f12t_pow_x(fp4& h, const fp4& a, const tri& t) {
     }
 #pragma unroll 1
     for (int i = 62; i >= 0; --i) {
+        C12381_FAIR_SHARE(i, h);
         f12t_usqr3_h(h, t);
         if ((BLS_X >> i) & 1ull) f12t_mul_h(h, a, t);
     }
@@ -793,6 +817,7 @@ C12381_HDN void f12t_pow_generic(fp4& H, const uint32_t (&e)[8], const tri& t) {
     }
 #pragma unroll 1
     for (int i = 257; i >= 1; --i) {
+        C12381_FAIR_SHARE(i, H);
         f12t_usqr3_h(H, t);
         const int b3 = (int)((e3[i >> 5] >> (i & 31)) & 1u);
         const int b1 = i < 256 ? (int)((e[i >> 5] >> (i & 31)) & 1u) : 0;
@@ -845,6 +870,7 @@ C12381_HD void f12t_pow_window(fp4& H, const fp4& x, const uint32_t (&e)[8], con
     }
 #pragma unroll 1
     for (int w = 63; w >= 0; --w) {
+        C12381_FAIR_SHARE(w, H);
         if (w != 63) { f12t_usqr3_h(H, t); f12t_usqr3_h(H, t); f12t_usqr3_h(H, t); f12t_usqr3_h(H, t); }
         const int digit = (int)((e[w >> 3] >> ((w & 7) * 4)) & 15u);
         fp4 m;
@@ -1126,6 +1152,7 @@ C12381_HDN void miller3_range(fp4& F, fp2& tc, const fp& px, const fp& py, bool 
     miller3_regs R = m3r_pack(tc, F, info);
 #pragma unroll 1
     for (int i = hi; i >= lo; --i) {
+        C12381_FAIR_SHARE(i, F);
         R = miller3_iter(R);
         const int bt = (int)((N3 >> i) & 1) - (int)((N1 >> i) & 1);
         if (bt != 0) {                                         // wave-uniform: the 5 addition steps
@@ -1140,6 +1167,7 @@ C12381_HDN void miller3_range2(fp4& F, fp2& tc1, const fp& px1, const fp& py1, b
                                fp2& tc2, const fp& px2, const fp& py2, bool skip2, const g2p& Q2, int hi, int lo, const tri& t) {
 #pragma unroll 1
     for (int i = hi; i >= lo; --i) {
+        C12381_FAIR_SHARE(i, F);
         f12t_sqr_h(F, t);
         miller3_pair_step(F, tc1, px1, py1, skip1, Q1, i, t);
         miller3_pair_step(F, tc2, px2, py2, skip2, Q2, i, t);
@@ -1155,6 +1183,7 @@ struct miller3_pair { fp px, py; fp2 tc; g2p Q; bool skip; };
 C12381_HDN void miller3_rangeK(fp4& F, miller3_pair* pr, int K, int hi, int lo, const tri& t) {
 #pragma unroll 1
     for (int i = hi; i >= lo; --i) {
+        C12381_FAIR_SHARE(i, F);
         f12t_sqr_h(F, t);
 #pragma unroll 1
         for (int j = 0; j < K; ++j) miller3_pair_step(F, pr[j].tc, pr[j].px, pr[j].py, pr[j].skip, pr[j].Q, i, t);
@@ -1303,6 +1332,7 @@ C12381_HDN void miller3_range_fixed(fp4& F, const fp& px_, const fp& py_, bool s
     for (int j = 64; j > hi; --j) k += 1 + ((((N3 >> j) & 1) != ((N1 >> j) & 1)) ? 1 : 0);
 #pragma unroll 1
     for (int i = hi; i >= lo; --i) {
+        C12381_FAIR_SHARE(i, F);
         f12t_sqr_h(F, t);
         miller3_fixed_line(F, tab, norm, k++, px, py, skip, t);
         if (((N3 >> i) & 1) != ((N1 >> i) & 1)) miller3_fixed_line(F, tab, norm, k++, px, py, skip, t);
@@ -1324,6 +1354,7 @@ C12381_HDN void miller3_range2_fixed(fp4& F, const fp& px1_, const fp& py1_, boo
     for (int j = 64; j > hi; --j) k += 1 + ((((N3 >> j) & 1) != ((N1 >> j) & 1)) ? 1 : 0);
 #pragma unroll 1
     for (int i = hi; i >= lo; --i) {
+        C12381_FAIR_SHARE(i, F);
         f12t_sqr_h(F, t);
         miller3_fixed_line(F, tab1, norm1, k, px1, py1, skip1, t);
         miller3_fixed_line(F, tab2, norm2, k, px2, py2, skip2, t);
