@@ -31,6 +31,18 @@
 #define C12381_CONST constexpr
 #endif
 
+// C12381_FAIR_TURN(i), once per iteration of a kernel's main loop (experiment, off: profiles/r04_ab_fair_share.txt): the wavefront in an odd hardware
+// slot of its SIMD alternates its issue priority, so that the two wavefronts of a SIMD advance together instead of oldest first.
+#ifndef C12381_FAIR_GRID
+#define C12381_FAIR_GRID 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && C12381_FAIR_GRID
+#define C12381_FAIR_TURN(i) do { if (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1u) { \
+        if (__builtin_amdgcn_readfirstlane((int)(i)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } } while (0)
+#else
+#define C12381_FAIR_TURN(i) do { } while (0)
+#endif
+
 // A normalised limb (x & LMASK) is known to be non-negative, and LLVM then canonicalises its sign extension to a ZERO
 // extension; once such a value crosses a basic-block boundary (every accumulator of a loop does) instruction
 // selection no longer sees that bit 31 is clear, cannot use v_mad_i64_i32 for sext(a) * zext(b) and emits TWO

@@ -419,6 +419,7 @@ C12381_HD void g1_scalar_mul(g1p& acc, const fp& px, const fp& py, bool p_is_inf
 #endif
 #pragma unroll 1
     for (int w = G1_WINDOWS - 2; w >= 0; --w) {
+        C12381_FAIR_TURN(w);
 #if C12381_G1_PREFETCH && defined(__HIP_DEVICE_COMPILE__)
         const int d0 = glv_digit(kb0, w), d1 = glv_digit(kb1, w);
         g1p q0, q1, e;

@@ -360,6 +360,7 @@ template <class F> C12381_HDN void g2_scalar_mul(g2pt<F>& acc, const F& qx, cons
     g2_set_inf(run);
 #pragma unroll 1
     for (int w = G2_WINDOWS - 1; w >= 0; --w) {
+        C12381_FAIR_TURN(w);
 #if defined(__HIP_DEVICE_COMPILE__) && C12381_G2_PREFETCH
         // round 4 (as g1_scalar_mul): in the register-resident two-lane form the record of an addition is requested one operation ahead —
         // before the window's doublings / before the previous addition — instead of at the head of the addition that needs it

@@ -186,6 +186,7 @@ C12381_HD void msm_bucket_one(g1p& acc, size_t lo, size_t hi, const uint32_t* va
     uint32_t idx_next = lo + 1 < hi ? vals_sorted[lo + 1] : 0u;
 #pragma unroll 1
     for (size_t j = lo; j < hi; ++j) {
+        C12381_FAIR_TURN(j >> 2);
         const fp x = xn, y = yn;
         if (j + 1 < hi) {
             msm_load_pt(xn, yn, pts2 + (size_t)idx_next * MSM_PT_STRIDE);
