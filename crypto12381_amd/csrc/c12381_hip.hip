@@ -199,6 +199,15 @@ int stage_out(c12381_ctx* c, const staged& s, void* hout, size_t bout) {
     return 0;
 }
 
+// ev_chunk[0]: the event the bucket product forks its side-stream work from (the scalar-multiplication batches use the same vector per chunk)
+static int ensure_fork_event(c12381_ctx* c) {
+    if (c->ev_chunk.empty()) {
+        hipEvent_t e;
+        HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->ev_chunk.push_back(e);
+    }
+    return 0;
+}
 // window width: msm_window_bits(n), or C12381_MSM_C = 4..16 (tuning runs)
 static int msm_c(size_t n) {
     static const int forced = [] { const char* e = tuning_env("C12381_MSM_C"); const int v = e ? std::atoi(e) : 0; return v >= 4 && v <= 16 ? v : 0; }();
@@ -250,11 +259,7 @@ int g1_msm_pippenger(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t*
         const size_t tmp_half = round_up(tmp_bytes + 256, 256);
         if ((rc = ensure(c, c12381_ctx::WS_MSM_TMP, MSM_SORT_STREAMS * tmp_half))) return rc;
         uint8_t* tmp = (uint8_t*)c->ws[c12381_ctx::WS_MSM_TMP];
-        if (c->ev_chunk.empty()) {
-            hipEvent_t e;
-            HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            c->ev_chunk.push_back(e);
-        }
+        if ((rc = ensure_fork_event(c))) return rc;
         while ((int)c->sort_streams.size() < MSM_SORT_STREAMS - 2) {       // beyond the context's stream and its side stream
             hipStream_t st; hipEvent_t e;
             HIPCK(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -319,11 +324,7 @@ int g1_msm_pippenger(c12381_ctx* c, size_t n, const uint8_t* pts, const uint8_t*
     // The small-scalar bucket (index nbk) and the [r]phi(S) it owes, on the side stream while this one goes on to the bucket sums: ranges and
     // sorted values are final here.  ovf_cnt[2] = "term written"; longer buckets are left to the bucket kernel and msm_small_term_kernel.
     int32_t* small_term = (int32_t*)(ovf + 64);
-    if (c->ev_chunk.empty()) {
-        hipEvent_t e;
-        HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        c->ev_chunk.push_back(e);
-    }
+    if ((rc = ensure_fork_event(c))) return rc;
     HIPCK(c, hipEventRecord(c->ev_chunk[0], c->stream));
     HIPCK(c, hipStreamWaitEvent(c->side, c->ev_chunk[0], 0));
     hipLaunchKernelGGL(msm_small_early_kernel, dim3(1), dim3(64), 0, c->side, (const uint32_t*)lo, (const uint32_t*)hi, (uint32_t)nbk, MSM_SMALL_EARLY_MAX,
@@ -855,7 +856,7 @@ static const char* pair_stamps_path() {
 }
 static unsigned long long* pair_stamps(c12381_ctx* c, size_t n) {
     if (!pair_stamps_path()) return nullptr;
-    const size_t tasks = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE * 10;
+    const size_t tasks = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE * 16;      // ten per group (up to 14 with C12381_MILLER_TASKS = 8), one more for its whole-group stamp
     if (c->stamps_tasks < tasks) {
         (void)hipStreamSynchronize(c->stream);              // a kernel of this context may still be writing the old buffer
         if (c->stamps) (void)hipFree(c->stamps);

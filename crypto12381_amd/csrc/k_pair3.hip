@@ -22,6 +22,12 @@ __device__ __forceinline__ size_t queue_direct_groups(size_t ngroups, size_t nwa
     if (ov > 0) queued = (size_t)ov < ngroups ? (size_t)ov : ngroups;
     return ngroups - queued;
 }
+// Miller-loop tasks per group in the queue kernels (the 64 iterations in equal parts)
+#ifndef C12381_MILLER_TASKS
+#define C12381_MILLER_TASKS 4
+#endif
+static_assert(64 % C12381_MILLER_TASKS == 0, "C12381_MILLER_TASKS divides 64");
+constexpr int MILLER_ITERS_PER_TASK = 64 / C12381_MILLER_TASKS;
 // Issue priority of the two kinds of work (s_setprio) — an experiment, OFF (profiles/r04_ab_queue_priority.txt).  A SIMD serves the older of its two
 // wavefronts first, so a wavefront that has finished its whole groups and moved on to queue tasks keeps the younger one's whole group waiting.
 // 1: whole groups at a raised priority, tasks at the default ("longest job first") — 2^16 pairings 16.9 -> 33.2 ms: a task wavefront that cannot
@@ -252,7 +258,7 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
     t.role = lane == 63u ? 0 : (int)(lane - 3u * trip);
     t.base = lane == 63u ? 63 : (int)(3u * trip);
     const size_t ngroups = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE;
-    constexpr unsigned int MILLER_TASKS = 4, TASKS = MILLER_TASKS + 6;
+    constexpr unsigned int MILLER_TASKS = C12381_MILLER_TASKS, TASKS = MILLER_TASKS + 6;
     constexpr int ROWS = ST_Y1 + ST_ROWS_F;
     // Hybrid schedule.  Wavefronts first claim WHOLE groups (counter[1]: no hand-over, no wait on a slower partner, the state stays
     // in registers and in the LDS slot) until only the last third of the groups (queue_direct_groups) is left; those go through the queue in tenth-length
@@ -332,7 +338,7 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
                 st_load<fp2, ST_ROWS_TC>(tc, st + ST_TC1 * 64, lane);
                 if (EQ) st_load<fp2, ST_ROWS_TC>(tc2, st + ST_TC2 * 64, lane);
             }
-            const int hi = 64 - 16 * (int)p, lo = hi - 15;
+            const int hi = 64 - MILLER_ITERS_PER_TASK * (int)p, lo = hi - (MILLER_ITERS_PER_TASK - 1);
             if (EQ) miller3_range2(H, tc, px, py, pinf, Q, tc2, px2, py2, pinf2, Q2, hi, lo, t);
             else miller3_range(H, tc, px, py, pinf, Q, hi, lo, t);
             if (p == MILLER_TASKS - 1) f12t_conj_h(H, t);
@@ -417,7 +423,7 @@ __device__ __forceinline__ void split3_queue_body(size_t n, const uint8_t* in1, 
     t.role = lane == 63u ? 0 : (int)(lane - 3u * trip);
     t.base = lane == 63u ? 63 : (int)(3u * trip);
     const size_t ngroups = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE;
-    constexpr unsigned int TASKS = MILLER ? 4u : 6u;
+    constexpr unsigned int TASKS = MILLER ? (unsigned)C12381_MILLER_TASKS : 6u;
     constexpr int ROWS = ST_Y1 + ST_ROWS_F;
     const size_t nwaves = (size_t)gridDim.x * (BLOCK / 64);
     const size_t ndirect = queue_direct_groups(ngroups, nwaves);
@@ -479,7 +485,7 @@ __device__ __forceinline__ void split3_queue_body(size_t n, const uint8_t* in1, 
                 slot_store(H, f);
                 st_load<fp2, ST_ROWS_TC>(tc, st + ST_TC1 * 64, lane);
             }
-            const int hi = 64 - 16 * (int)p, lo = hi - 15;
+            const int hi = 64 - MILLER_ITERS_PER_TASK * (int)p, lo = hi - (MILLER_ITERS_PER_TASK - 1);
             miller3_range(H, tc, px, py, pinf, Q, hi, lo, t);
             if (p == TASKS - 1) {
                 f12t_conj_h(H, t);
@@ -567,7 +573,7 @@ __device__ __forceinline__ void pair3_fixed_queue_body(size_t n, const uint8_t* 
     t.role = lane == 63u ? 0 : (int)(lane - 3u * trip);
     t.base = lane == 63u ? 63 : (int)(3u * trip);
     const size_t ngroups = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE;
-    constexpr unsigned int MILLER_TASKS = 4, TASKS = MILLER_TASKS + 6;
+    constexpr unsigned int MILLER_TASKS = C12381_MILLER_TASKS, TASKS = MILLER_TASKS + 6;
     constexpr int ROWS = ST_Y1 + ST_ROWS_F;
     // whole groups first, the last third of the groups through the queue (see pair3_queue_body)
     const size_t nwaves = (size_t)gridDim.x * (BLOCK / 64);
@@ -640,7 +646,7 @@ __device__ __forceinline__ void pair3_fixed_queue_body(size_t n, const uint8_t* 
                 if (p == 0) f12t_one(f, t); else st_load<fp4, ST_ROWS_F>(f, st + ST_F * 64, lane);
                 slot_store(H, f);
             }
-            const int hi = 64 - 16 * (int)p, lo = hi - 15;
+            const int hi = 64 - MILLER_ITERS_PER_TASK * (int)p, lo = hi - (MILLER_ITERS_PER_TASK - 1);
             if (TWO) miller3_range2_fixed(H, ax, ay, ainf, tabw, cx, cy, cinf, tabg, hi, lo, t);
             else miller3_range_fixed(H, ax, ay, ainf, tabw, hi, lo, t);
             if (p == MILLER_TASKS - 1) f12t_conj_h(H, t);
