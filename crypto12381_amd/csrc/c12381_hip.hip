@@ -1227,6 +1227,16 @@ static int launch_gt_op(c12381_ctx* c, int op, size_t n, const uint8_t* a, const
         uint4* st; unsigned int *fl, *ct; unsigned blocks; int rc;
         if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
         hipLaunchKernelGGL(fexp3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, a, out, c->d_flag, st, fl, ct, pair_spin_limit());
+    } else if (op == 2 && pair_use_queue(n)) {
+        // the power, more than one machine round: five tasks per queued group (k_pair3.hip gt3_pow_queue_kernel); one table per wavefront of the
+        // grid and one per queued group (at most 2048 + 4096 tables of 224 KB)
+        uint4* st; unsigned int *fl, *ct; unsigned blocks; int rc;
+        if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
+        const size_t groups = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE, nwaves = (size_t)blocks * (BLOCK / 64);
+        const size_t tables = nwaves + (groups - queue_direct_groups_host(groups, nwaves));
+        if ((rc = ensure(c, c12381_ctx::WS_GT_POW, tables * GT_POW_TAB_BYTES_PER_WAVE))) return rc;
+        hipLaunchKernelGGL(gt3_pow_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, a, b, out, c->d_flag, (uint4*)c->ws[c12381_ctx::WS_GT_POW], st, fl, ct,
+                           pair_spin_limit());
     } else if (op == 2) {
         // the power: launches of at most GT_POW_WAVES wavefronts, each with its table of x^0 .. x^15 behind it (224 KB per wavefront; the
         // same workspace serves every launch: they are ordered on the stream)

@@ -754,6 +754,104 @@ __global__ void __launch_bounds__(BLOCK, 2) gt3_op_kernel(int op, size_t n, cons
     else { r = x; f12t_final_exp_ws(r, H, t); }
     if (active) gt_store_coeff(out + 576 * i, r, t.role);
 }
+// The power for batches of more than one machine round: hybrid schedule and hand-over protocol of split3_queue_body, FIVE tasks per queued
+// group — 0: membership test, route, table (windowed route), 1..4: a quarter of the ladder each (16 windows, or 64 / 64 / 64 / 65 iterations
+// of the reference's digit sequence).  State between tasks: the accumulator (scaled form) and the route (word 0 of the group's second state
+// area).  Tables: pow_tab holds one per wavefront of the grid (whole groups), then one per queued group.
+constexpr unsigned int GT_POW_TASKS = 5;
+__device__ __forceinline__ void gt3_pow_whole(fp4& H, const fp4& x, const uint32_t (&e)[8], bool active, uint4* tab, unsigned lane, const tri& t) {
+    const bool member = f12t_is_cyclotomic(H, x, t);
+    if (__builtin_amdgcn_ballot_w64(active && !member) == 0) {
+        f12t_pow_window(H, x, e, t,
+                        [&](int k, const fp4& v) { st_store<fp4, ST_ROWS_F>(tab + (size_t)k * (ST_ROWS_F * 64), lane, v); },
+                        [&](fp4& m, int k) { st_load<fp4, ST_ROWS_F>(m, tab + (size_t)k * (ST_ROWS_F * 64), lane); });
+    } else { slot_store(H, x); f12t_pow_generic(H, e, t); }
+}
+__global__ void __launch_bounds__(BLOCK, 2) gt3_pow_queue_kernel(size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out, int* bad_flag, uint4* pow_tab,
+                                                              uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit) {
+    __shared__ fp4_slot slots[BLOCK];
+    fp4& H = slots[threadIdx.x].v;
+    slot_fair_set(H, 0);
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned trip = lane / 3u;
+    tri t;
+    t.role = lane == 63u ? 0 : (int)(lane - 3u * trip);
+    t.base = lane == 63u ? 63 : (int)(3u * trip);
+    const size_t ngroups = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE;
+    constexpr int ROWS = ST_Y1 + ST_ROWS_F;
+    const size_t nwaves = (size_t)gridDim.x * (BLOCK / 64);
+    const size_t wave = ((size_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    const size_t ndirect = queue_direct_groups(ngroups, nwaves);
+    uint4* own_tab = wave_uniform(pow_tab + wave * (size_t)(GT_POW_TAB_ROWS * 64));
+    for (;;) {                                                 // whole groups first
+        const unsigned int gc = atomicAdd(counter + 1, lane == 0 ? 1u : 0u);
+        const size_t g = (size_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)gc);
+        if (g >= ndirect) break;
+        const size_t el = g * TRI_PER_WAVE + (lane == 63u ? TRI_PER_WAVE - 1 : trip);
+        const bool active = lane < 63u && el < n;
+        const size_t i = el < n ? el : n - 1;
+        fp4 x, r;
+        uint32_t raw[8], e[8];
+        gt_load_coeff(x, a + 576 * i, t.role);
+        load_raw32(raw, b + 32 * i); scalar_from_raw32(e, raw);
+        gt3_pow_whole(H, x, e, active, own_tab, lane, t);
+        slot_load(r, H);
+        if (active) gt_store_coeff(out + 576 * i, r, t.role);
+    }
+    const size_t nq = ngroups - ndirect;
+    const size_t ntasks = nq * GT_POW_TASKS;
+    for (;;) {
+        const unsigned int claimed = atomicAdd(counter, lane == 0 ? 1u : 0u);
+        const unsigned int task = (unsigned int)__builtin_amdgcn_readfirstlane((int)claimed);
+        if ((size_t)task >= ntasks) break;
+        const unsigned int p = (unsigned int)(task / nq);
+        const size_t gq = task % nq, g = ndirect + gq;
+        const size_t el = g * TRI_PER_WAVE + (lane == 63u ? TRI_PER_WAVE - 1 : trip);
+        const bool active = lane < 63u && el < n;
+        const size_t i = el < n ? el : n - 1;
+        const bool poisoned = queue_wait(flags, g, p, spin_limit);
+        uint4* st = state + gq * (size_t)ROWS * 64;
+        uint4* tab = wave_uniform(pow_tab + (nwaves + gq) * (size_t)(GT_POW_TAB_ROWS * 64));
+        if (poisoned) {
+            if (p == GT_POW_TASKS - 1 && active) { bad_flag[1] = 1; gt_poison(out + 576 * el, t.role); }
+        } else {
+            fp4 x;
+            uint32_t raw[8], e[8];
+            gt_load_coeff(x, a + 576 * i, t.role);
+            load_raw32(raw, b + 32 * i); scalar_from_raw32(e, raw);
+            if (p == 0) {
+                const bool member = f12t_is_cyclotomic(H, x, t);
+                const bool windows = __builtin_amdgcn_ballot_w64(active && !member) == 0;
+                if (windows) f12t_pow_window_table(H, x, t, [&](int k, const fp4& v) { st_store<fp4, ST_ROWS_F>(tab + (size_t)k * (ST_ROWS_F * 64), lane, v); });
+                f12t_pow_acc_init(H, t);
+                if (lane == 0) st[ST_TC1 * 64] = make_uint4(windows ? 1u : 0u, 0u, 0u, 0u);
+            } else {
+                fp4 acc;
+                st_load<fp4, ST_ROWS_F>(acc, st + ST_F * 64, lane);
+                slot_store(H, acc);
+                const bool windows = __builtin_amdgcn_readfirstlane((int)st[ST_TC1 * 64].x) != 0;
+                if (windows) {
+                    const int whi = 63 - 16 * ((int)p - 1);
+                    f12t_pow_window_range(H, e, whi, whi - 15, t, [&](fp4& m, int k) { st_load<fp4, ST_ROWS_F>(m, tab + (size_t)k * (ST_ROWS_F * 64), lane); });
+                } else {
+                    const int hi = 257 - 64 * ((int)p - 1), lo = p == GT_POW_TASKS - 1 ? 1 : hi - 63;
+                    f12t_pow_generic_range(H, x, e, hi, lo, t);
+                }
+            }
+            if (p == GT_POW_TASKS - 1) {
+                f12t_unscale3_h(H);
+                fp4 r;
+                slot_load(r, H);
+                if (active) gt_store_coeff(out + 576 * el, r, t.role);
+            } else {
+                fp4 acc;
+                slot_load(acc, H);
+                st_store<fp4, ST_ROWS_F>(st + ST_F * 64, lane, acc);
+            }
+        }
+        queue_publish(flags, g, p, poisoned, lane);
+    }
+}
 __global__ void __launch_bounds__(BLOCK, 2) gt3_is_unity_kernel(size_t n, const uint8_t* a, uint8_t* out) {
     if ((((size_t)blockIdx.x * BLOCK + threadIdx.x) >> 6) * TRI_PER_WAVE >= n) return;
     tri t; size_t i; bool active;

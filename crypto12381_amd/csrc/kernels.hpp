@@ -94,6 +94,7 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_prod_fixed_queue_kernel(size_t
 __global__ void __launch_bounds__(BLOCK, 2) pair3_fixed_queue_kernel(size_t n, const uint8_t* g1_96, const int32_t* buf, uint8_t* gt, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit);
 __global__ void __launch_bounds__(BLOCK, 2) miller3_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* out, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) gt3_op_kernel(int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out, uint4* pow_tab);
+__global__ void __launch_bounds__(BLOCK, 2) gt3_pow_queue_kernel(size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out, int* bad_flag, uint4* pow_tab, uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit);
 constexpr size_t GT_POW_TAB_BYTES_PER_WAVE = (size_t)16 * 14 * 64 * 16;   // 16 entries x 14 rows (one Fp4 per lane) x 64 lanes x 16 bytes
 __global__ void __launch_bounds__(BLOCK, 2) gt3_is_unity_kernel(size_t n, const uint8_t* a, uint8_t* out);
 constexpr int PAIR_QUEUE_STATE_ROWS = 42;        // 16-byte rows x 64 lanes per group of 21 pairings (F, tc1, tc2, y1)

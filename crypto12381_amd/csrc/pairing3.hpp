@@ -798,7 +798,15 @@ C12381_HD void f12t_one(fp4& F, const tri& t);
 // are identities on 1 (usqr(1) = 1, 1 * 1 = 1), its leading digit is +1 (3e has its top bit one position above any bit of e)
 // and turns the accumulator into a — from there on the sequence is FP12_pow's, for non-unitary inputs too.  Zero digits
 // multiply by 1 (the value is unchanged; the bytes written are canonical either way).
-C12381_HDN void f12t_pow_generic(fp4& H, const uint32_t (&e)[8], const tri& t) {
+// The pieces (the work-queue kernel runs the ladder in four tasks): the accumulator's start value 3 * 1, iterations hi .. lo of the ladder on the
+// accumulator in the slot with the base `a` in private memory, and the way out (f12t_unscale3_h).
+C12381_HD void f12t_pow_acc_init(fp4& H, const tri& t) {       // the accumulator in the scaled form 3 * acc (f12t_usqr3_h)
+    fp4 one, y;
+    f12t_one(one, t);
+    fp4_scale3(y, one);
+    slot_store(H, y);
+}
+C12381_HDN void f12t_pow_generic_range(fp4& H, const fp4& a, const uint32_t (&e)[8], int hi, int lo, const tri& t) {
     uint32_t e3[9];
     {
         uint64_t c = 0;
@@ -806,19 +814,13 @@ C12381_HDN void f12t_pow_generic(fp4& H, const uint32_t (&e)[8], const tri& t) {
         for (int i = 0; i < 8; ++i) { c += (uint64_t)e[i] * 3u; e3[i] = (uint32_t)c; c >>= 32; }
         e3[8] = (uint32_t)c;
     }
-    fp4 a, ac, one;
-    slot_load(a, H);
+    fp4 ac, one;
     f12t_conj(ac, a, t);
     f12t_one(one, t);
-    {   // the accumulator in the scaled form 3 * acc (f12t_usqr3_h): y <- y^2 - 2 conj(y) is FP12_usqr's polynomial on any input
-        fp4 y;
-        fp4_scale3(y, one);
-        slot_store(H, y);
-    }
 #pragma unroll 1
-    for (int i = 257; i >= 1; --i) {
+    for (int i = hi; i >= lo; --i) {
         C12381_FAIR_SHARE(i, H);
-        f12t_usqr3_h(H, t);
+        f12t_usqr3_h(H, t);                                    // y <- y^2 - 2 conj(y) is FP12_usqr's polynomial on any input
         const int b3 = (int)((e3[i >> 5] >> (i & 31)) & 1u);
         const int b1 = i < 256 ? (int)((e[i >> 5] >> (i & 31)) & 1u) : 0;
         const int bt = b3 - b1;
@@ -827,6 +829,12 @@ C12381_HDN void f12t_pow_generic(fp4& H, const uint32_t (&e)[8], const tri& t) {
         fp4_select(m, bt == 0, one, m);
         f12t_mul_h(H, m, t);
     }
+}
+C12381_HD void f12t_pow_generic(fp4& H, const uint32_t (&e)[8], const tri& t) {
+    fp4 a;
+    slot_load(a, H);
+    f12t_pow_acc_init(H, t);
+    f12t_pow_generic_range(H, a, e, 257, 1, t);
     f12t_unscale3_h(H);
 }
 // ------------------------------------------------------------------ FP12_pow on the cyclotomic subgroup: fixed 4-bit windows
@@ -850,33 +858,38 @@ C12381_HD bool f12t_is_cyclotomic(fp4& H, const fp4& x, const tri& t) {
     const int a = tri_fetch_int(mine, 0, t), b = tri_fetch_int(mine, 1, t), c = tri_fetch_int(mine, 2, t);
     return (a & b & c) != 0;
 }
-// H: the lane's slot (any content on entry, x^e on return); x: the base, in private memory
-template <class Store, class Load>
-C12381_HD void f12t_pow_window(fp4& H, const fp4& x, const uint32_t (&e)[8], const tri& t, Store store, Load load) {
-    {
-        fp4 one, r;
-        f12t_one(one, t);
-        store(0, one); store(1, x);
-        slot_store(H, x);
+// H: the lane's slot (any content on entry, x^e on return); x: the base, in private memory.  In pieces for the work-queue kernel: the table,
+// windows whi .. wlo (63 .. 0 from the top) on the accumulator in the slot, and f12t_pow_acc_init / f12t_unscale3_h around them.
+template <class Store>
+C12381_HD void f12t_pow_window_table(fp4& H, const fp4& x, const tri& t, Store store) {
+    fp4 one, r;
+    f12t_one(one, t);
+    store(0, one); store(1, x);
+    slot_store(H, x);
 #pragma unroll 1
-        for (int k = 2; k < 16; ++k) {
-            f12t_mul_h(H, x, t);
-            slot_load(r, H);
-            store(k, r);
-        }
-        fp4 y;
-        fp4_scale3(y, one);                                    // the accumulator in the scaled form of f12t_usqr3_h
-        slot_store(H, y);
+    for (int k = 2; k < 16; ++k) {
+        f12t_mul_h(H, x, t);
+        slot_load(r, H);
+        store(k, r);
     }
+}
+template <class Load>
+C12381_HD void f12t_pow_window_range(fp4& H, const uint32_t (&e)[8], int whi, int wlo, const tri& t, Load load) {
 #pragma unroll 1
-    for (int w = 63; w >= 0; --w) {
+    for (int w = whi; w >= wlo; --w) {
         C12381_FAIR_SHARE(w, H);
-        if (w != 63) { f12t_usqr3_h(H, t); f12t_usqr3_h(H, t); f12t_usqr3_h(H, t); f12t_usqr3_h(H, t); }
+        if (w != 63) { f12t_usqr3_h(H, t); f12t_usqr3_h(H, t); f12t_usqr3_h(H, t); f12t_usqr3_h(H, t); }      // the accumulator is 1 above the top window
         const int digit = (int)((e[w >> 3] >> ((w & 7) * 4)) & 15u);
         fp4 m;
         load(m, digit);
         f12t_mul_h(H, m, t);
     }
+}
+template <class Store, class Load>
+C12381_HD void f12t_pow_window(fp4& H, const fp4& x, const uint32_t (&e)[8], const tri& t, Store store, Load load) {
+    f12t_pow_window_table(H, x, t, store);
+    f12t_pow_acc_init(H, t);
+    f12t_pow_window_range(H, e, 63, 0, t, load);
     f12t_unscale3_h(H);
 }
 // FP12_isunity: every lane tests its own coefficient, the verdict is combined over the triple

@@ -202,7 +202,7 @@ int c12381_fexp_batch_dev(c12381_ctx* ctx, size_t n, const uint8_t* in576, uint8
  * 2: pow(fp12&, fp12& base, const big&) (:195 -> 261-264 -> FP12_pow; b = 32-byte exponents, used as given,
  *    unitary squarings exactly like the reference: bases outside the cyclotomic subgroup go through the reference's
  *    own digit sequence, members — every pairing value — through a 4-bit windowed ladder that returns the same
- *    bytes; the device holds 224 KB of table per wavefront of 21 elements, at most 0.94 GB);
+ *    bytes; the device holds 224 KB of table per wavefront of 21 elements, at most 1.4 GB);
  * 3: final exponentiation. */
 int c12381_gt_op_batch(c12381_ctx* ctx, int op, size_t n, const uint8_t* a576, const uint8_t* b, uint8_t* out576);
 int c12381_gt_op_batch_dev(c12381_ctx* ctx, int op, size_t n, const uint8_t* a576, const uint8_t* b, uint8_t* out576);

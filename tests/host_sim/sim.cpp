@@ -333,10 +333,21 @@ void* tri3_worker(void* arg) {
             else if (op == 1) f12t_conj(r, x, t);
             else if (op == 2) {
                 // as gt3_op_kernel: the windowed ladder for members of the cyclotomic subgroup, the reference's digit sequence otherwise
-                // (g_pow_route: 0 = as the kernel decides, 1 = always the generic ladder; g_pow_windowed counts the elements that took the windows)
+                // (g_pow_route: 0 = as the kernel decides, 1 = always the generic ladder, 2 = in the five pieces of the work-queue kernel; g_pow_windowed counts the elements that took the windows)
                 uint32_t raw[8], e[8]; load_raw(raw, jb->b1 + 32 * i, 8); scalar_from_raw32(e, raw);
                 const bool cyc = f12t_is_cyclotomic(h, x, t);
-                if (cyc && g_pow_route == 0) {
+                if (g_pow_route == 2) {
+                    // the five tasks of gt3_pow_queue_kernel: table / start value, then four quarters of the ladder on the accumulator
+                    fp4 tab[16];
+                    if (cyc) f12t_pow_window_table(r, x, t, [&](int k, const fp4& v) { tab[k] = v; });
+                    f12t_pow_acc_init(r, t);
+                    for (int p = 1; p <= 4; ++p) {
+                        if (cyc) { const int whi = 63 - 16 * (p - 1); f12t_pow_window_range(r, e, whi, whi - 15, t, [&](fp4& m, int k) { m = tab[k]; }); }
+                        else { const int hi = 257 - 64 * (p - 1), lo = p == 4 ? 1 : hi - 63; f12t_pow_generic_range(r, x, e, hi, lo, t); }
+                    }
+                    f12t_unscale3_h(r);
+                    if (cyc && jb->role == 0) ++g_pow_windowed;
+                } else if (cyc && g_pow_route == 0) {
                     fp4 tab[16];
                     f12t_pow_window(r, x, e, t, [&](int k, const fp4& v) { tab[k] = v; }, [&](fp4& m, int k) { m = tab[k]; });
                     if (jb->role == 0) ++g_pow_windowed;
@@ -692,5 +703,5 @@ extern "C" int sim_pair2_fixed_batch(size_t n, const uint8_t* a96, const uint8_t
 extern "C" int sim_miller3_batch(size_t n, const uint8_t* g1_96, const uint8_t* g2_192, uint8_t* out576) { return run_tri3(n, g1_96, g2_192, nullptr, nullptr, out576, 3); }
 // op: 0 mul, 1 conj, 2 pow, 3 final exponentiation, 4 is-unity (out = n bytes)
 extern "C" int sim_gt3_op_batch(int op, size_t n, const uint8_t* a576, const uint8_t* b, uint8_t* out) { return run_tri3(n, a576, nullptr, b, nullptr, out, 10 + op); }
-// route of the power on triples: 0 = the kernel's choice, 1 = generic ladder only; returns the number of elements that took the windowed ladder so far
+// route of the power on triples: 0 = the kernel's choice, 1 = generic ladder only, 2 = the kernel's choice in the queue kernel's five pieces; returns the number of elements that took the windowed ladder so far
 extern "C" int sim_gt3_pow_route(int route) { g_pow_route = route; const int v = g_pow_windowed; g_pow_windowed = 0; return v; }

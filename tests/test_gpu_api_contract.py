@@ -208,6 +208,11 @@ assert rc == E_INTERNAL and ok.raw == b'\xff' * m, (rc, ok.raw)
 # one fixed G2 argument
 rc = c.lib.c12381_pair_fixed_g2_batch(c.h, n, _p(g1), _p(g2[:192]), _p(out))
 assert rc == E_INTERNAL and out.raw == b'\xff' * (576 * n), rc
+# the GT power through the queue (five tasks per group)
+k = len(g['gt_pow_exp'])
+out2 = ctypes.create_string_buffer(576 * k)
+rc = c.lib.c12381_gt_op_batch(c.h, 2, k, _p(cat(g['gt'])[:576 * k]), _p(cat(g['gt_pow_exp'])), _p(out2))
+assert rc == E_INTERNAL and out2.raw == b'\xff' * (576 * k), rc
 c.close()
 print('poison ok')
 """

@@ -397,6 +397,12 @@ def test_sim_gt_power_windowed_and_generic_routes(sim, oracle_port):
     assert sim.sim_gt3_op_batch(2, sz(n), a, e, out) == 0 and out.raw == want
     assert sim.sim_gt3_pow_route(1) == n               # every pairing value took the windows
     assert sim.sim_gt3_op_batch(2, sz(n), a, e, out) == 0 and out.raw == want      # the generic ladder agrees on them
+    assert sim.sim_gt3_pow_route(2) == 0
+    assert sim.sim_gt3_op_batch(2, sz(n), a, e, out) == 0 and out.raw == want      # ... and the ladder cut into the work-queue kernel's five tasks
+    assert sim.sim_gt3_pow_route(2) == n
+    e2q = e[32 * 3:32 * 5]
+    o2q = ctypes.create_string_buffer(576 * 2)
+    assert sim.sim_gt3_op_batch(2, sz(2), mil, e2q, o2q) == 0 and o2q.raw == oracle_port.gt_op("pow", mil, e2q)     # the generic ladder in four ranges
     assert sim.sim_gt3_pow_route(0) == 0
     # outside the subgroup: the kernel's choice must be the generic ladder, value as the reference's sequence gives it
     e2 = e[32 * 3:32 * 5]
