@@ -271,6 +271,24 @@ def main():
     ctx = Context(dev_index)
     stream = torch.cuda.Stream(device=dev)          # the library's kernels run on this torch-owned HIP stream
     ctx.set_stream(stream.cuda_stream)
+    _events = []
+
+    def inputs_ready():
+        """Device-side edge from torch's current stream (where torch kernels and copies fill the inputs) to the library's stream: an event
+        recorded there, handed to c12381_wait_event — the library cannot see a foreign stream (include/c12381_hip.h "Stream ordering");
+        no host-side wait.  (Round 4 used a device-wide synchronise here, after a 2-rank run had read half-written inputs.)"""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        ctx.wait_event(ev.cuda_event)
+        _events.append(ev)
+
+    def outputs_ready():
+        """the opposite edge: torch's current stream waits for everything the library has launched so far (c12381_record_event)"""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))               # creates the handle (lazily created events have none before a record)
+        ctx.record_event(ev.cuda_event)
+        torch.cuda.current_stream(dev).wait_event(ev)
+        _events.append(ev)
 
     def timed(fn, steps, warmup):
         """W untimed + K timed steps bracketed by barrier + synchronize; MAX over ranks."""
@@ -310,7 +328,7 @@ def main():
     gen1 = dev_bytes(G1_GEN, dev)
     pts = torch.empty(n * 96, dtype=torch.uint8, device=dev)
     out = torch.empty(n * 96, dtype=torch.uint8, device=dev)
-    torch.cuda.synchronize(dev)
+    inputs_ready()
     ctx.g1_mul_fixed_dev(n, gen1.data_ptr(), base_sc.data_ptr(), pts.data_ptr(), 96)      # P_i = G^{s_i} (untimed)
     ctx.sync()
     # lanes 0 and 1 of base_sc are 0 and 1: P_0 = infinity, P_1 = G — edge inputs stay in the batch
@@ -344,7 +362,7 @@ def main():
         q2 = torch.empty(npair * 192, dtype=torch.uint8, device=dev)
         gt = torch.empty(npair * 576, dtype=torch.uint8, device=dev)
         p1 = pts[: npair * 96] if npair <= n else pts.repeat((npair + n - 1) // n)[: npair * 96].contiguous()
-        torch.cuda.synchronize(dev)
+        inputs_ready()
         ctx.g2_mul_fixed_dev(npair, gen2.data_ptr(), t_sc.data_ptr(), q2.data_ptr(), 192)   # Q_i = G2^{t_i} (untimed)
         if ctx.sync() != 0:
             raise SystemExit("bench: the fixed-base G2 multiplication reported an invalid point")
@@ -375,8 +393,8 @@ def main():
         mil = torch.empty(npair * 576, dtype=torch.uint8, device=dev)
         fex = torch.empty(npair * 576, dtype=torch.uint8, device=dev)
         # g2_in may be the output of a torch kernel (repeat / contiguous) on torch's current stream, the library enqueues on ITS stream: without
-        # this the first launch can read g2_in before it is written — seen as "invalid input" on one of three 2-rank runs sharing a GPU
-        torch.cuda.synchronize(dev)
+        # this edge the first launch can read g2_in before it is written — seen as "invalid input" on one of three 2-rank runs sharing a GPU
+        inputs_ready()
         ctx.g2_mul_dev(ng2, g2_in.data_ptr(), g2_sc.data_ptr(), g2_out.data_ptr(), 192)
         if ctx.sync() != 0:
             raise SystemExit("bench: invalid input reported by the G2 multiplication kernel")
@@ -407,12 +425,30 @@ def main():
     if not args.no_msm:
         nm = 1 << args.log2_msm
         reps = max(1, nm // n)
-        mp_ = pts.repeat(reps).contiguous()[: nm * 96] if reps > 1 else pts[: nm * 96]
+
+        def msm_points(first_pts, first_base_h, seed):
+            """nm DISTINCT points P_i = G^{b_i} (configs[3] reads 2^22 terms g_i^x_i, not 2^20 points four times): block 0 is the G1 leg's batch
+            (edge lanes included), the further blocks of n points come from their own seeds, untimed; returns the points and the b_i"""
+            if reps == 1:
+                return first_pts[: nm * 96], first_base_h[:nm]
+            full = torch.empty(nm * 96, dtype=torch.uint8, device=dev)
+            full[: n * 96] = first_pts
+            bases = [first_base_h]
+            for j in range(1, reps):
+                b_h = make_scalars(seed + 7919 * j, n, edges=False)
+                b_d = torch.from_numpy(b_h).to(dev)
+                inputs_ready()
+                ctx.g1_mul_fixed_dev(n, gen1.data_ptr(), b_d.data_ptr(), full[j * n * 96:].data_ptr(), 96)
+                ctx.sync()
+                bases.append(b_h)
+            return full, np.concatenate(bases)[:nm]
+
+        mp_, msm_base_h = msm_points(pts, base_sc_h, 1000 + rank)
         ms_h = make_scalars(4000 + rank, nm)
         ms_ = torch.from_numpy(ms_h).to(dev)
         mo_ = torch.empty(96, dtype=torch.uint8, device=dev)
         msteps = min(max(1, args.steps), 5)
-        torch.cuda.synchronize(dev)                         # mp_ may come from a torch kernel on torch's stream
+        inputs_ready()                                      # mp_ and ms_ come from torch copies on torch's stream
         ctx.g1_msm_dev(nm, mp_.data_ptr(), ms_.data_ptr(), mo_.data_ptr(), 96)
         torch.cuda.synchronize(dev)
         ctx.profile(True)
@@ -421,7 +457,7 @@ def main():
         ctx.profile(False)
         probe_clock("msm_bucket_kernel", lambda: ctx.g1_msm_dev(nm, mp_.data_ptr(), ms_.data_ptr(), mo_.data_ptr(), 96))
         msm = {"n": nm, "steps": msteps, "elapsed": mel, "bucket_ms": bk_ms, "bucket_launches": bk_launches, "out": mo_.cpu().numpy().tobytes(),
-               "reps": reps, "scalars": ms_h}
+               "reps": reps, "scalars": ms_h, "bases": msm_base_h}
         if world > 1:
             # strong scaling: ONE product for the whole job — identical terms on every rank (seed without the rank), each rank takes its shard
             gs_h = make_scalars(4100, nm)
@@ -431,10 +467,10 @@ def main():
                 gb = torch.from_numpy(gb_h).to(dev)
                 ctx.g1_mul_fixed_dev(n, gen1.data_ptr(), gb.data_ptr(), gpts.data_ptr(), 96)
                 ctx.sync()
-            gfull = gpts.repeat(reps).contiguous()[: nm * 96] if reps > 1 else gpts[: nm * 96]
+            gfull, _ = msm_points(gpts, gb_h, 1000)                    # the same nm distinct points on every rank
             lo, hi = shard_bounds(nm, rank, world)
             sp_, ss_ = gfull[96 * lo:96 * hi], torch.from_numpy(gs_h[lo:hi]).to(dev)
-            torch.cuda.synchronize(dev)
+            inputs_ready()
 
             def local_t(p, s, fmt):
                 o = torch.empty(fmt, dtype=torch.uint8, device=dev)
@@ -505,7 +541,7 @@ def main():
         dA, dx, dr, dm = (torch.from_numpy(a).to(dev) for a in (A_h, xs_h, rs_h, mm_h))
         dpub = [dev_bytes(b, dev) for b in (pub_g1, g2p, pub_h0, pub_h, w)]
         okb = torch.empty(nb, dtype=torch.uint8, device=dev)
-        torch.cuda.synchronize(dev)
+        inputs_ready()
 
         def bbs_step(count=nb, A=dA, x=dx, r=dr, m=dm, ok=okb):
             ctx.bbs_plus_verify_dev(count, 1, dpub[0].data_ptr(), dpub[1].data_ptr(), dpub[2].data_ptr(), dpub[3].data_ptr(), dpub[4].data_ptr(),
@@ -529,10 +565,10 @@ def main():
         # pp.h (49 B each), pk (97 B), signatures A || x || r as 49 + 48 + 48 B, raw messages.  Serialized on the device, untimed.
         one32 = torch.zeros(nb, 32, dtype=torch.uint8, device=dev); one32[:, 31] = 1
         A49 = torch.empty(nb * 49, dtype=torch.uint8, device=dev)
-        torch.cuda.synchronize(dev)                         # one32 was filled by torch kernels
+        inputs_ready()                                      # one32 was filled by torch kernels
         ctx.g1_mul_flags_dev(nb, dA.data_ptr(), one32.data_ptr(), A49.data_ptr(), 49, 1)           # 1 x A in the compressed form (C12381_F_IN_SUBGROUP)
         sig = torch.zeros(nb, 145, dtype=torch.uint8, device=dev)
-        ctx.sync()
+        outputs_ready()                                     # torch assembles sig from A49 on its own stream
         sig[:, 0:49] = A49.view(nb, 49); sig[:, 65:97] = dx.view(nb, 32); sig[:, 113:145] = dr.view(nb, 32)
         one1 = (1).to_bytes(32, "big")
         pp195 = ctx.g1_mul(pub_g1, one1, 49) + ctx.g2_mul(g2p, one1, 97) + ctx.g1_mul(pub_h0, one1, 49)
@@ -541,7 +577,7 @@ def main():
         draw = torch.from_numpy(raw_h).to(dev)
         okw = torch.empty(nb, dtype=torch.uint8, device=dev)
         del one32, A49
-        torch.cuda.synchronize(dev)                         # sig was assembled by torch kernels on torch's stream
+        inputs_ready()                                      # sig was assembled by torch kernels on torch's stream
 
         def wire_step():
             ctx.bbs_plus_verify_wire_dev(nb, 1, BBS_MSG_LEN, dwire[0].data_ptr(), dwire[1].data_ptr(), dwire[2].data_ptr(), sig.data_ptr(), draw.data_ptr(),
@@ -560,7 +596,7 @@ def main():
             lo, hi = shard_bounds(nb, rank, world)
             sA, sx, sr, sm = (torch.from_numpy(np.ascontiguousarray(a[lo:hi])).to(dev) for a in (gA, gx, gr, gm))
             sok = torch.empty(max(hi - lo, 1), dtype=torch.uint8, device=dev)
-            torch.cuda.synchronize(dev)
+            inputs_ready()
             sel = timed(lambda: bbs_step(hi - lo, sA, sx, sr, sm, sok), bsteps, 1)
             ctx.sync()
             cnt = torch.tensor([int(sok[: hi - lo].sum().item())], dtype=torch.int64, device=comm_dev)
@@ -607,6 +643,17 @@ def main():
         print("bench.py: oracle/_ref/libc12381_ref.so is absent: parity is checked against the C port (parity.pinned = false)", file=sys.stderr, flush=True)
     cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)   # the GPU box gives one GPU a 16-CPU share
     do_cpu = world == 1 and not args.no_cpu_baseline
+
+    def cpu_time(fn):
+        """CPU legs: a sample shorter than 2 s rides the host's CPU-quota burst and then its throttle — such a sample is run three times and
+        the MEDIAN time counts (a longer one once); returns (output, seconds)"""
+        ts, o = [], None
+        while True:
+            t = time.perf_counter()
+            o = fn()
+            ts.append(time.perf_counter() - t)
+            if ts[0] >= 2.0 or len(ts) >= 3 or not do_cpu:         # parity-only runs (--no-cpu-baseline, N > 1): once
+                return o, float(np.median(ts))
     pts_h = pts.cpu().numpy().reshape(n, 96)
     out_h = out.cpu().numpy().reshape(n, 96)
     # G1: with the CPU baseline the first 2^16 lanes are compared in full, otherwise 64 sampled lanes incl. every edge lane
@@ -667,7 +714,9 @@ def main():
                 bound_s = insts * VALU_ISSUE_CYCLES / 1024 / (clk * 1e9)
                 # issue_secs: the launch time of the kernel the instructions were counted in, where `secs` is a longer time base (BBS+: the pipeline)
                 d["issue"] = {"valu_insts": insts, "clock_GHz_in_run": clk, "issue_ms": bound_s * 1e3, "issue_over_launch": bound_s / (issue_secs or secs),
-                              "mad_share": mac_per_unit * units / 64 / insts}
+                              # the REFERENCE's work per issued lane-instruction — not the share of multiply-adds in the
+                              # stream (that is 0.69-0.85, profiles/r05_isa_classes_*.txt)
+                              "ref_mac32_per_inst": mac_per_unit * units / 64 / insts}
             elif ik:
                 d["issue"] = {"valu_insts": ik["valu_insts_per_launch"] * units / ik["units_per_launch"], "clock_GHz_in_run": None}
             d.update(more)
@@ -686,30 +735,31 @@ def main():
         if do_cpu:
             sample = min(n, 1 << 16)
             sp, ss = pts_h[:sample].tobytes(), sc_h[:sample].tobytes()
-            t1 = time.perf_counter()
-            cpu_out = orc.g1_mul(sp, ss, 96, cores)
-            cpu_s = time.perf_counter() - t1
-            t2 = time.perf_counter()
-            orc.g1_mul(sp[:96 * 2048], ss[:32 * 2048], 96, 1)
-            cpu1_s = time.perf_counter() - t2
+            cpu_out, cpu_s = cpu_time(lambda: orc.g1_mul(sp, ss, 96, cores))
+            _, cpu1_s = cpu_time(lambda: orc.g1_mul(sp[:96 * 4096], ss[:32 * 4096], 96, 1))
             if cpu_out != out_h[:sample].tobytes():
                 raise SystemExit("bench: CPU baseline output differs from the GPU output")
             g1_checked = sample + len(idx)
             result["cpu_baseline"] = {"value": sample / cpu_s, "unit": "scalar-muls/s", "cores": cores, "kind": kind,
                                       "sample": "first %d lanes; every lane equal to the GPU output" % sample,
-                                      "single_thread_value": 2048 / cpu1_s}
+                                      "one_thread": 4096 / cpu1_s, "eff_cores": (sample / cpu_s) / (4096 / cpu1_s)}
         result["parity"] = par(checked_lanes=g1_checked)
 
-        def cpu_b(v, unit, sample):
-            return {"value": v, "cores": cores, "kind": kind, "sample": sample}      # unit = the leg's unit
+        def cpu_b(v, unit, sample, one=None, full_keys=False):
+            """one = the same routine's rate on ONE thread (its own short sample): eff_cores = what `cores` threads deliver on this box"""
+            d = {"value": v, "sample": sample}      # unit = the leg's unit; cores and kind: the headline's cpu_baseline and notes.cpu_baseline
+            if full_keys:
+                d.update(cores=cores, kind=kind)
+            if one:
+                d.update(one_thread=one, eff_cores=v / one)
+            return d
 
         # ---------------------------------------------------------------- MSM
         if msm is not None:
             nm = msm["n"]
             # full-size parity: every P_i = G^{s_i}, so the product is G^(sum s_i k_i) — one oracle multiplication
-            s_full = np.tile(base_sc_h, (msm["reps"], 1))[:nm]
-            # lanes 0..4 of base_sc are edge values (0, 1, r-1, r, 2^256-1): the exponent sum works mod r for all of them
-            e = sum_of_products_mod_r(s_full, msm["scalars"])
+            # lanes 0..4 of the first block's b_i are edge values (0, 1, r-1, r, 2^256-1): the exponent sum works mod r for all of them
+            e = sum_of_products_mod_r(msm["bases"], msm["scalars"])
             if orc.g1_mul(G1_GEN, e.to_bytes(32, "big"), 96, 1) != msm["out"]:
                 raise SystemExit("bench: MSM result differs from G^(sum s_i k_i) (CPU oracle) — number withheld")
             per = msm["elapsed"] / msm["steps"]
@@ -717,20 +767,19 @@ def main():
             result["msm"] = {
                 "metric": "G1 multi-scalar product terms/s (one product of 2^%d terms per GPU)" % args.log2_msm,
                 "value": world * nm / per, "unit": "terms/s", "steps": msm["steps"], "ms_per_step": per * 1e3,
-                "workload": "configs[3]",
+                "workload": "configs[3]: %d distinct points" % nm,
                 "parity": par(check="result == G^(sum s_i k_i) over ALL terms"),
                 # dominant kernel alone, then the whole product (sorts, preparation, reductions included) against the same peak
                 "roofline": valu(MAC32_MSM_TERM, nm, bk_s, "msm_bucket_kernel", msm_traffic, BYTES_MSM_TERM),
                 "roofline_whole_step": {"frac": MAC32_MSM_TERM * nm / per / VALU_PEAK_MAC32, "achieved": MAC32_MSM_TERM * nm / per / 1e9},
             }
             if do_cpu:
-                sm = 1 << 14
-                t7 = time.perf_counter()
-                cpu_m = orc.g1_msm(pts_h[:sm].tobytes(), msm["scalars"][:sm].tobytes(), 96, cores)
-                cm_s = time.perf_counter() - t7
+                sm = 1 << 15
+                cpu_m, cm_s = cpu_time(lambda: orc.g1_msm(pts_h[:sm].tobytes(), msm["scalars"][:sm].tobytes(), 96, cores))
+                _, cm1_s = cpu_time(lambda: orc.g1_msm(pts_h[:4096].tobytes(), msm["scalars"][:4096].tobytes(), 96, 1))
                 if cpu_m != ctx.g1_msm(pts_h[:sm].tobytes(), msm["scalars"][:sm].tobytes(), 96):
                     raise SystemExit("bench: CPU MSM baseline differs from the GPU product of the same sample")
-                result["msm"]["cpu_baseline"] = cpu_b(sm / cm_s, "terms/s", "first 2^14 terms as the reference evaluates the product; equals the GPU's")
+                result["msm"]["cpu_baseline"] = cpu_b(sm / cm_s, "terms/s", "first 2^15 terms (ECP_muln); equals the GPU's", 4096 / cm1_s)
             if "sharded" in msm:
                 sh = msm["sharded"]
                 if not sh["same_on_every_rank"] or sh["equals_single_gpu"] is False:
@@ -748,10 +797,12 @@ def main():
             q2_h = pair["q2"].cpu().numpy().reshape(npair, 192)
             gt_h = pair["gt"].cpu().numpy().reshape(npair, 576)
             full = do_cpu and not args.sampled_parity
+            pair_one = None
             if full:
-                t3 = time.perf_counter()
-                cpu_gt = np.frombuffer(orc.pair(p1_h.tobytes(), q2_h.tobytes(), cores), dtype=np.uint8).reshape(npair, 576)
-                cpu_ps = time.perf_counter() - t3
+                cpu_gt, cpu_ps = cpu_time(lambda: orc.pair(p1_h.tobytes(), q2_h.tobytes(), cores))
+                cpu_gt = np.frombuffer(cpu_gt, dtype=np.uint8).reshape(npair, 576)
+                k1 = min(npair, 512)
+                pair_one = k1 / cpu_time(lambda: orc.pair(p1_h[:k1].tobytes(), q2_h[:k1].tobytes(), 1))[1]
                 badp = np.nonzero((cpu_gt != gt_h).any(axis=1))[0]
                 if len(badp):
                     raise SystemExit("bench: %d of %d GPU pairing results differ from the CPU oracle (first lanes %s) — number withheld"
@@ -769,15 +820,20 @@ def main():
         # ---------------------------------------------------------------- G2 multiplication, Miller loop, final exponentiation alone
         if split is not None:
             npair, ng2, st = pair["npair"], split["ng2"], split["steps"]
-            ns = min(npair, 1 << 12)
+            ns = min(npair, (1 << 13) if do_cpu else (1 << 12))
             g2o_h = split["g2_out"].cpu().numpy().reshape(ng2, 192)
             g2i_h = split["g2_in"].cpu().numpy().reshape(ng2, 192)
             mil_h = split["mil"].cpu().numpy().reshape(npair, 576)
             fex_h = split["fex"].cpu().numpy().reshape(npair, 576)
             # lanes 0..4 carry the edge scalars 0, 1, r - 1, r, 2^256 - 1
-            t4 = time.perf_counter(); q_cpu = orc.g2_mul(g2i_h[:ns].tobytes(), split["g2_sc_h"][:ns].tobytes(), 192, cores); g2_s = time.perf_counter() - t4
-            t5 = time.perf_counter(); m_cpu = orc.miller_t(p1_h[:ns].tobytes(), q2_h[:ns].tobytes(), cores); mil_s = time.perf_counter() - t5
-            t6 = time.perf_counter(); f_cpu = orc.fexp_t(m_cpu, cores); fx_s = time.perf_counter() - t6
+            q_cpu, g2_s = cpu_time(lambda: orc.g2_mul(g2i_h[:ns].tobytes(), split["g2_sc_h"][:ns].tobytes(), 192, cores))
+            m_cpu, mil_s = cpu_time(lambda: orc.miller_t(p1_h[:ns].tobytes(), q2_h[:ns].tobytes(), cores))
+            f_cpu, fx_s = cpu_time(lambda: orc.fexp_t(m_cpu, cores))
+            g2_one = mil_one = fx_one = None
+            if do_cpu:                                             # one thread, own short samples
+                g2_one = 1024 / cpu_time(lambda: orc.g2_mul(g2i_h[:1024].tobytes(), split["g2_sc_h"][:1024].tobytes(), 192, 1))[1]
+                mil_one = 1024 / cpu_time(lambda: orc.miller_t(p1_h[:1024].tobytes(), q2_h[:1024].tobytes(), 1))[1]
+                fx_one = 512 / cpu_time(lambda: orc.fexp_t(m_cpu[:576 * 512], 1))[1]
             if q_cpu != g2o_h[:ns].tobytes():
                 raise SystemExit("bench: GPU G2 multiplications differ from the CPU oracle — number withheld")
             if m_cpu != mil_h[:ns].tobytes():
@@ -786,27 +842,27 @@ def main():
                 raise SystemExit("bench: GPU final exponentiations differ from the CPU oracle / the pairing outputs — number withheld")
             queued = (npair + 20) // 21 > 2048
 
-            def leg(metric, unit, units, el, kprof, mac, nbytes, kernel, workload, parity, cpu_s, tr=None, clock_key=None):
+            def leg(metric, unit, units, el, kprof, mac, nbytes, kernel, workload, parity, cpu_s, tr=None, clock_key=None, one=None):
                 k_s = kprof[0] / max(kprof[1], 1) * 1e-3
                 lps = max(kprof[1] / max(st, 1), 1)
                 d = {"metric": metric, "value": world * units * st / el, "unit": unit, "steps": st, "ms_per_step": el / st * 1e3,
                      "workload": workload, "parity": parity,
                      "roofline": valu(mac, units / lps, k_s, kernel, tr, nbytes, clock_key, units_per_launch=units / lps)}
                 if do_cpu:
-                    d["cpu_baseline"] = cpu_b(ns / cpu_s, unit, "first %d lanes of the same batch" % ns)
+                    d["cpu_baseline"] = cpu_b(ns / cpu_s, unit, "first %d lanes of the same batch" % ns, one)
                 return d
             result["g2_mul"] = leg("G2 scalar-muls/s per MI355X (batch 2^%d per GPU), bit-exact vs CPU" % args.log2_g2, "scalar-muls/s", ng2, split["g2_el"],
                                    split["g2k"], MAC32_G2_MUL, BYTES_G2_MUL, "g2_mul2_kernel",
                                    "PAIR_G2mul, 192-B affine in/out, edge scalars in lanes 0..4",
                                    par(checked_lanes=ns, of=ng2), g2_s,
-                                   None if g2_traffic is None else g2_traffic * ng2 / max(split["g2k"][1] / max(st, 1), 1))
+                                   None if g2_traffic is None else g2_traffic * ng2 / max(split["g2k"][1] / max(st, 1), 1), one=g2_one)
             result["miller"] = leg("Miller loops/s per MI355X (batch 2^%d per GPU), the reference's field element" % args.log2_pairings, "Miller loops/s", npair,
                                    split["mil_el"], split["milk"], MAC32_MILLER, 96 + 192 + 576, "miller3_queue_kernel" if queued else "miller3_kernel",
-                                   "PAIR_ate on the pairing leg's inputs", par(checked_lanes=ns, of=npair), mil_s, None, "miller")
+                                   "PAIR_ate on the pairing leg's inputs", par(checked_lanes=ns, of=npair), mil_s, None, "miller", mil_one)
             result["fexp"] = leg("final exponentiations/s per MI355X (batch 2^%d per GPU)" % args.log2_pairings, "final exponentiations/s", npair,
                                  split["fex_el"], split["fexk"], MAC32_FEXP, 2 * 576, "fexp3_queue_kernel" if queued else "gt3_op_kernel",
                                  "PAIR_fexp on those Miller values",
-                                 par(checked_lanes=ns, of=npair, check="+ every lane equals the pairing leg's output"), fx_s, None, "fexp")
+                                 par(checked_lanes=ns, of=npair, check="+ every lane equals the pairing leg's output"), fx_s, None, "fexp", fx_one)
 
         # ---------------------------------------------------------------- BBS+ (decoded inputs, then the wire formats end to end)
         if bbs is not None:
@@ -820,7 +876,7 @@ def main():
                 # the pipeline's OWN operation sequence (tools/count_ops.py -> profiles/r03_op_counts.json) over the wall time of the whole pipeline
                 "roofline": valu(MAC32_BBS_PIPELINE, nb, per, "pair3_prod_fixed_queue_kernel", bbs_traffic, BYTES_BBS_VERIFY,
                                  issue_secs=bbs["pair_ms"] / max(bbs["pair_launches"], 1) * 1e-3,
-                                 pair_kernel_avg_ms=bbs["pair_ms"] / max(bbs["pair_launches"], 1), time_base="whole pipeline (issue: the pairing kernel's own launch)"),
+                                 pair_kernel_avg_ms=bbs["pair_ms"] / max(bbs["pair_launches"], 1), time_base="whole pipeline; issue: the pairing kernel"),
                 "reference_sequence_gmac32_per_s": MAC32_BBS_VERIFY * nb / per / 1e9,
             }
             wr = bbs["wire"]
@@ -838,21 +894,21 @@ def main():
                 sb = 1 << 11
                 pg1, pg2, ph0, ph, pw = bbs["pub"]
                 sl = np.r_[0:sb - 64, nb - 64:nb]                       # includes corrupted lanes (7, 1016, ...)
-                t8 = time.perf_counter()
-                cpu_ok = orc.bbs_plus_verify(pg1, pg2, ph0, ph, pw, bbs["A"][sl].tobytes(), bbs["x"][sl].tobytes(), bbs["r"][sl].tobytes(),
-                                             bbs["m"][sl].tobytes(), cores)
-                cb_s = time.perf_counter() - t8
+                cpu_ok, cb_s = cpu_time(lambda: orc.bbs_plus_verify(pg1, pg2, ph0, ph, pw, bbs["A"][sl].tobytes(), bbs["x"][sl].tobytes(), bbs["r"][sl].tobytes(),
+                                                                    bbs["m"][sl].tobytes(), cores))
+                s1 = sl[:256]
+                cb_one = len(s1) / cpu_time(lambda: orc.bbs_plus_verify(pg1, pg2, ph0, ph, pw, bbs["A"][s1].tobytes(), bbs["x"][s1].tobytes(),
+                                                                        bbs["r"][s1].tobytes(), bbs["m"][s1].tobytes(), 1))[1]
                 if cpu_ok != bbs["ok"][sl].tobytes():
                     raise SystemExit("bench: CPU BBS+ verdicts differ from the GPU verdicts")
                 result["bbs_plus"]["parity"].update(par(oracle_lanes=int(len(sl))))
-                result["bbs_plus"]["cpu_baseline"] = cpu_b(len(sl) / cb_s, "verifications/s", "%d signatures incl. corrupted ones, bbs+.cpp:57-73 on decoded inputs; verdicts equal the GPU's" % len(sl))
-                t9 = time.perf_counter()
-                cpu_okw = orc.bbs_plus_verify_wire(wr["pp"], wr["h49"], wr["pk"], wr["sig"][sl].tobytes(), wr["raw"][sl].tobytes(), BBS_MSG_LEN, cores)
-                cw_s = time.perf_counter() - t9
+                result["bbs_plus"]["cpu_baseline"] = cpu_b(len(sl) / cb_s, "verifications/s", "%d signatures incl. corrupted ones; verdicts equal the GPU's" % len(sl), cb_one)
+                cpu_okw, cw_s = cpu_time(lambda: orc.bbs_plus_verify_wire(wr["pp"], wr["h49"], wr["pk"], wr["sig"][sl].tobytes(), wr["raw"][sl].tobytes(), BBS_MSG_LEN, cores))
+                cw_one = len(s1) / cpu_time(lambda: orc.bbs_plus_verify_wire(wr["pp"], wr["h49"], wr["pk"], wr["sig"][s1].tobytes(), wr["raw"][s1].tobytes(), BBS_MSG_LEN, 1))[1]
                 if cpu_okw != wr["ok"][sl].tobytes():
                     raise SystemExit("bench: CPU wire-format BBS+ verdicts differ from the GPU verdicts")
                 result["bbs_plus_wire"]["parity"].update(par(oracle_lanes=int(len(sl))))
-                result["bbs_plus_wire"]["cpu_baseline"] = cpu_b(len(sl) / cw_s, "verifications/s", "the same %d signatures from the same bytes (from_bytes + encode + op sequence); verdicts equal the GPU's" % len(sl))
+                result["bbs_plus_wire"]["cpu_baseline"] = cpu_b(len(sl) / cw_s, "verifications/s", "the same %d signatures from their bytes; verdicts equal the GPU's" % len(sl), cw_one)
             if "sharded" in bbs:
                 sh = bbs["sharded"]
                 if sh["accepted"] != sh["expected_accepted"]:
@@ -864,14 +920,15 @@ def main():
         if extras:
             result["extra_configs"] = extras
         result["notes"] = {
-            "roofline": "int-valu binds: algorithmic 32x32 multiply-adds (SURVEY 8(d)) / avg launch time (HIP events on the library's stream) vs the "
-                        "v_mad_i64_i32 issue rate measured in-kernel (62.06 lanes/clk/CU x 256 CUs x 2.4 GHz; theoretical 64); hbm_GBs = algorithmic "
-                        "bytes / same time (peak 8000); traffic = FETCH_SIZE x2 + WRITE_SIZE passes (profiles/traffic.json)",
-            "issue": "issue_ms = VALU instructions per launch (SQ_INSTS_VALU pass of this build, profiles/issue.json) x 4.06 cycles / 1024 SIMDs / "
-                     "the clock held inside the kernel in THIS run (one-lane probe, median)",
+            "roofline": "int-valu binds: SURVEY 8(d) 32x32 multiply-adds / avg launch time (HIP events on the library's stream) vs the v_mad_i64_i32 "
+                        "issue rate measured in-kernel (62.06 lanes/clk/CU x 256 CUs x 2.4 GHz; theoretical 64); hbm_GBs = algorithmic bytes / same "
+                        "time (peak 8000); traffic = FETCH_SIZE x2 + WRITE_SIZE passes (profiles/traffic.json)",
+            "issue": "issue_ms = SQ_INSTS_VALU per launch of this build (profiles/issue.json) x 4.06 cycles / 1024 SIMDs / the clock held inside the "
+                     "kernel in THIS run (one-lane probe); ref_mac32_per_inst = the reference's MAC32 per issued lane-instruction",
             "bbs_plus": "MAC32 = the pipeline's own op sequence (wire leg: + decode of A); reference_sequence_gmac32_per_s prices the reference's "
-                        "sequence over this wall time, not a utilisation",
-            "cpu_baseline": "%s, %d host threads of this box, same inputs" % ("oracle/_ref = the reference's sources compiled here" if pinned else "C port (oracle/_ref absent)", cores),
+                        "sequence over this wall time",
+            "cpu_baseline": "%s, %d host threads, same inputs; samples under 2 s: median of 3; one_thread = 1 thread on its own sample, eff_cores = "
+                            "value / one_thread" % ("oracle/_ref = the reference's sources compiled here" if pinned else "C port (oracle/_ref absent)", cores),
         }
         # the pairing leg goes LAST: the second half of BASELINE's metric survives any truncation of the line's head
         if pair is not None:
@@ -887,7 +944,7 @@ def main():
             }
             if do_cpu:
                 result["pairing"]["cpu_baseline"] = cpu_b(ps / cpu_ps, "pairings/s", ("the whole batch of %d pairings; every lane bit-exact vs GPU" % ps) if full
-                                                          else "%d sampled lanes" % ps)
+                                                          else "%d sampled lanes" % ps, pair_one, full_keys=True)
         line = json.dumps(compact(result), separators=(",", ":"))
         print(line, flush=True)
     if dist:

@@ -55,6 +55,8 @@ def load_library() -> ctypes.CDLL:
         lib.c12381_last_error.restype = ctypes.c_char_p
         lib.c12381_set_stream.argtypes = [vp, vp]
         lib.c12381_sync.argtypes = [vp]
+        lib.c12381_wait_event.argtypes = [vp, vp]
+        lib.c12381_record_event.argtypes = [vp, vp]
         lib.c12381_profile.argtypes = [vp, ci]
         lib.c12381_profile_read.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
         for name in ("c12381_fp_op_batch", "c12381_fp_op_batch_dev"):
@@ -161,6 +163,15 @@ class Context:
 
     def sync(self) -> int:
         return self._ck(self.lib.c12381_sync(self.h), allow_point=True)
+
+    def wait_event(self, hip_event):
+        """everything this context launches from now on waits for `hip_event` (a hipEvent_t as an integer, e.g. torch.cuda.Event.cuda_event
+        after record()): the device-side edge from the stream that produced a _dev call's inputs to the context's stream"""
+        self._ck(self.lib.c12381_wait_event(self.h, _p(hip_event)))
+
+    def record_event(self, hip_event):
+        """record `hip_event` on the context's stream behind everything launched so far: the edge to a stream that consumes the outputs"""
+        self._ck(self.lib.c12381_record_event(self.h, _p(hip_event)))
 
     def profile(self, enable: bool):
         self._ck(self.lib.c12381_profile(self.h, 1 if enable else 0))

@@ -84,6 +84,9 @@ struct c12381_ctx {
     // diagnostic (experiments builds, C12381_PAIR_STAMPS): per-task time stamps of the last queue pairing launch, on this context's device
     unsigned long long* stamps = nullptr;
     size_t stamps_tasks = 0;
+    // ... followed by 8 words per wavefront of the grid (k_pair3.hip queue_wave_stats) for the last queue launch of pairings, Miller loops or
+    // final exponentiations; c12381_sync() writes both regions to the file
+    static constexpr size_t STAMP_WAVES = 4096;
 };
 
 namespace {
@@ -451,6 +454,22 @@ int c12381_sync(c12381_ctx* c) {
     rc = read_flag(c);
     pair_stamps_dump(c);
     return rc;
+}
+
+// Ordering against the caller's other streams without blocking the host (include/c12381_hip.h "Stream ordering").  Side-stream work of
+// earlier calls is always joined back into the context's stream by the call that started it (ev_side), so the context's stream alone
+// carries the completion of everything launched so far.
+int c12381_wait_event(c12381_ctx* c, void* hip_event) {
+    int rc = bind(c); if (rc) return rc;
+    if (!hip_event) return C12381_E_ARG;
+    HIPCK(c, hipStreamWaitEvent(c->stream, (hipEvent_t)hip_event, 0));
+    return 0;
+}
+int c12381_record_event(c12381_ctx* c, void* hip_event) {
+    int rc = bind(c); if (rc) return rc;
+    if (!hip_event) return C12381_E_ARG;
+    HIPCK(c, hipEventRecord((hipEvent_t)hip_event, c->stream));
+    return 0;
 }
 
 #ifdef C12381_EXPERIMENTS
@@ -860,15 +879,20 @@ static unsigned long long* pair_stamps(c12381_ctx* c, size_t n) {
     if (c->stamps_tasks < tasks) {
         (void)hipStreamSynchronize(c->stream);              // a kernel of this context may still be writing the old buffer
         if (c->stamps) (void)hipFree(c->stamps);
-        if (hipMalloc((void**)&c->stamps, tasks * 32) != hipSuccess) { c->stamps = nullptr; c->stamps_tasks = 0; return nullptr; }
+        if (hipMalloc((void**)&c->stamps, tasks * 32 + c12381_ctx::STAMP_WAVES * 64) != hipSuccess) { c->stamps = nullptr; c->stamps_tasks = 0; return nullptr; }
         c->stamps_tasks = tasks;
     }
-    (void)hipMemsetAsync(c->stamps, 0, tasks * 32, c->stream);
+    (void)hipMemsetAsync(c->stamps, 0, c->stamps_tasks * 32 + c12381_ctx::STAMP_WAVES * 64, c->stream);
     return c->stamps;
+}
+// the per-wavefront region behind the per-task stamps (null when the diagnostic is off)
+static unsigned long long* pair_wave_stats(c12381_ctx* c, size_t n) {
+    unsigned long long* s = pair_stamps(c, n);
+    return s ? s + c->stamps_tasks * 4 : nullptr;
 }
 static void pair_stamps_dump(c12381_ctx* c) {
     if (!pair_stamps_path() || !c->stamps) return;
-    std::vector<unsigned long long> h(c->stamps_tasks * 4);
+    std::vector<unsigned long long> h(c->stamps_tasks * 4 + c12381_ctx::STAMP_WAVES * 8);
     if (hipMemcpy(h.data(), c->stamps, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
     if (FILE* f = std::fopen(pair_stamps_path(), "wb")) { std::fwrite(h.data(), 8, h.size(), f); std::fclose(f); }
 }
@@ -911,7 +935,8 @@ static int launch_pair(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8_t
     if (pair_use_queue(n)) {
         uint4* st; unsigned int *fl, *ct; unsigned blocks; int rc;
         if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
-        hipLaunchKernelGGL(pair3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag, st, fl, ct, pair_spin_limit(), pair_stamps(c, n));
+        unsigned long long* const stp = pair_stamps(c, n);
+        hipLaunchKernelGGL(pair3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag, st, fl, ct, pair_spin_limit(), stp, stp ? stp + c->stamps_tasks * 4 : nullptr);
     } else hipLaunchKernelGGL(pair3_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag);
     HIPCK(c, hipGetLastError());
     return 0;
@@ -937,7 +962,8 @@ int c12381_pair_batch_dev(c12381_ctx* c, size_t n, const uint8_t* g1, const uint
         uint4* st; unsigned int *fl, *ct; unsigned blocks;
         if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
         timed tm(c, 3);
-        hipLaunchKernelGGL(pair3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag, st, fl, ct, pair_spin_limit(), pair_stamps(c, n));
+        unsigned long long* const stp = pair_stamps(c, n);
+        hipLaunchKernelGGL(pair3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag, st, fl, ct, pair_spin_limit(), stp, stp ? stp + c->stamps_tasks * 4 : nullptr);
         HIPCK(c, hipGetLastError());
         return 0;
     }
@@ -1214,7 +1240,7 @@ static int launch_miller(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8
     if (pair_use_queue(n)) {              // more than one machine round of wavefront tasks: quarter-loop tasks from the work queue
         uint4* st; unsigned int *fl, *ct; unsigned blocks; int rc;
         if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
-        hipLaunchKernelGGL(miller3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, g1, g2, out, c->d_flag, st, fl, ct, pair_spin_limit());
+        hipLaunchKernelGGL(miller3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, g1, g2, out, c->d_flag, st, fl, ct, pair_spin_limit(), pair_wave_stats(c, n));
     } else hipLaunchKernelGGL(miller3_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, g1, g2, out, c->d_flag);
     HIPCK(c, hipGetLastError());
     return 0;
@@ -1226,7 +1252,7 @@ static int launch_gt_op(c12381_ctx* c, int op, size_t n, const uint8_t* a, const
     if (op == 3 && pair_use_queue(n)) {   // final exponentiations alone, more than one machine round: its six steps as queue tasks
         uint4* st; unsigned int *fl, *ct; unsigned blocks; int rc;
         if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
-        hipLaunchKernelGGL(fexp3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, a, out, c->d_flag, st, fl, ct, pair_spin_limit());
+        hipLaunchKernelGGL(fexp3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, a, out, c->d_flag, st, fl, ct, pair_spin_limit(), pair_wave_stats(c, n));
     } else if (op == 2 && pair_use_queue(n)) {
         // the power, more than one machine round: five tasks per queued group (k_pair3.hip gt3_pow_queue_kernel); one table per wavefront of the
         // grid and one per queued group (at most 2048 + 4096 tables of 224 KB)

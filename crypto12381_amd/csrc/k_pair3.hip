@@ -140,6 +140,26 @@ __device__ __forceinline__ void gt_poison(uint8_t* o576, int role) {
     for (int j = 0; j < 12; ++j) q[j] = make_uint4(~0u, ~0u, ~0u, ~0u);
 }
 
+// Diagnostic (experiments runs, C12381_PAIR_STAMPS): what ONE wavefront of a queue kernel spent its launch on, in shader-clock cycles
+// (s_memtime) — whole groups, queue tasks from start to publish (state loads and stores included), hand-over waits (claim to start) —
+// written once at exit as 8 words per wavefront (tools/queue_wave_stats.py).  Everything is wave-uniform (SGPRs); null pointer = off.
+struct queue_wave_stats {
+    unsigned long long* out;
+    unsigned long long t_entry = 0, whole = 0, task = 0, wait = 0, t0 = 0;
+    unsigned int n_whole = 0, n_task = 0;
+    __device__ __forceinline__ explicit queue_wave_stats(unsigned long long* wstats) : out(wstats) { if (out) t_entry = __builtin_amdgcn_s_memtime(); }
+    __device__ __forceinline__ void mark() { if (out) t0 = __builtin_amdgcn_s_memtime(); }
+    __device__ __forceinline__ void whole_done() { if (out) { whole += __builtin_amdgcn_s_memtime() - t0; ++n_whole; } }
+    __device__ __forceinline__ void wait_done() { if (out) { const unsigned long long t = __builtin_amdgcn_s_memtime(); wait += t - t0; t0 = t; } }
+    __device__ __forceinline__ void task_done() { if (out) { task += __builtin_amdgcn_s_memtime() - t0; ++n_task; } }
+    __device__ __forceinline__ void finish() {
+        if (!out || (threadIdx.x & 63u) != 0) return;
+        unsigned long long* o = out + 8 * (((size_t)blockIdx.x * BLOCK + threadIdx.x) >> 6);
+        o[0] = t_entry; o[1] = __builtin_amdgcn_s_memtime(); o[2] = whole; o[3] = n_whole; o[4] = task; o[5] = n_task; o[6] = wait;
+        o[7] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);      // HW_ID | XCC_ID
+    }
+};
+
 }  // namespace
 
 namespace c12381 {
@@ -251,7 +271,8 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_prod_kernel(size_t n, int k, c
 template <bool EQ>
 __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, size_t b2_stride,
                                                  uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit, fp4& H,
-                                                 unsigned long long* stamps = nullptr) {
+                                                 unsigned long long* stamps = nullptr, unsigned long long* wstats = nullptr) {
+    queue_wave_stats ws(wstats);
     const unsigned lane = threadIdx.x & 63u;
     const unsigned trip = lane / 3u;
     tri t;
@@ -276,7 +297,9 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
         if (g >= ndirect) break;
         const size_t e = g * TRI_PER_WAVE + (lane == 63u ? TRI_PER_WAVE - 1 : trip);
         const unsigned long long ts_g0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+        ws.mark();
         pair3_whole_group<EQ>(e < n ? e : n - 1, lane < 63u && e < n, a1, a2, b1, b2, b2_stride, out, bad_flag, H, t);
+        ws.whole_done();
         if (stamps && lane == 0) {                             // diagnostic: whole groups behind the queued groups' tasks (entry 10 nq + g)
             unsigned long long* o = stamps + 4 * ((ngroups - ndirect) * (size_t)TASKS + g);
             o[0] = ts_entry; o[1] = ts_g0; o[2] = __builtin_amdgcn_s_memtime();
@@ -302,7 +325,9 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
         // diagnostic time stamps (C12381_PAIR_STAMPS, tools/queue_phase_times.py): claim, start after the wait, end — per task
         unsigned long long ts_claim = 0, ts_start = 0;
         if (stamps) ts_claim = __builtin_amdgcn_s_memtime();
+        ws.mark();
         const bool poisoned = queue_wait(flags, g, p, spin_limit);
+        ws.wait_done();
         if (stamps) ts_start = __builtin_amdgcn_s_memtime();
         uint4* st = state + (g - ndirect) * (size_t)ROWS * 64;        // only the queued groups own a state block (pair_queue_setup)
         if (poisoned) {
@@ -386,19 +411,21 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
             }
         }
         queue_publish(flags, g, p, poisoned, lane);
+        ws.task_done();
         if (stamps && lane == 0) {
             unsigned long long* o = stamps + 4 * (size_t)task;
             o[0] = ts_claim; o[1] = ts_start; o[2] = __builtin_amdgcn_s_memtime();
             o[3] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);      // HW_ID | XCC_ID
         }
     }
+    ws.finish();
 }
 
 __global__ void __launch_bounds__(BLOCK, 2) pair3_queue_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag, uint4* state,
-                                                            unsigned int* flags, unsigned int* counter, int spin_limit, unsigned long long* stamps) {
+                                                            unsigned int* flags, unsigned int* counter, int spin_limit, unsigned long long* stamps, unsigned long long* wstats) {
     __shared__ fp4_slot slots[BLOCK];
     slot_fair_set(slots[threadIdx.x].v, 0);
-    pair3_queue_body<false>(n, g1, g2, nullptr, nullptr, 0, gt, bad_flag, state, flags, counter, spin_limit, slots[threadIdx.x].v, stamps);
+    pair3_queue_body<false>(n, g1, g2, nullptr, nullptr, 0, gt, bad_flag, state, flags, counter, spin_limit, slots[threadIdx.x].v, stamps, wstats);
 }
 __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_queue_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2,
                                                                size_t b2_stride, uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags,
@@ -416,7 +443,9 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_queue_kernel(size_t n, cons
 // schedule and hand-over protocol as pair3_queue_body; a separate body, so that the pairing kernels' code is untouched.
 template <bool MILLER>
 __device__ __forceinline__ void split3_queue_body(size_t n, const uint8_t* in1, const uint8_t* in2, uint8_t* out, int* bad_flag, uint4* state,
-                                                  unsigned int* flags, unsigned int* counter, int spin_limit, fp4& H) {
+                                                  unsigned int* flags, unsigned int* counter, int spin_limit, fp4& H,
+                                                  unsigned long long* wstats) {
+    queue_wave_stats ws(wstats);
     const unsigned lane = threadIdx.x & 63u;
     const unsigned trip = lane / 3u;
     tri t;
@@ -435,6 +464,7 @@ __device__ __forceinline__ void split3_queue_body(size_t n, const uint8_t* in1, 
         const size_t e = g * TRI_PER_WAVE + (lane == 63u ? TRI_PER_WAVE - 1 : trip);
         const bool active = lane < 63u && e < n;
         const size_t i = e < n ? e : n - 1;
+        ws.mark();
         if (MILLER) {
             fp px, py; fp2 qx, qy; bool pinf, qinf, ok;
             pair_inputs(px, py, pinf, qx, qy, qinf, ok, in1 + 96 * i, in2 + 192 * i);
@@ -450,6 +480,7 @@ __device__ __forceinline__ void split3_queue_body(size_t n, const uint8_t* in1, 
             f12t_final_exp_ws(r, H, t);
             if (active) gt_store_coeff(out + 576 * i, r, t.role);
         }
+        ws.whole_done();
     }
     C12381_QUEUE_PRIO_TASKS();
     const size_t nq = ngroups - ndirect;
@@ -463,7 +494,9 @@ __device__ __forceinline__ void split3_queue_body(size_t n, const uint8_t* in1, 
         const size_t e = g * TRI_PER_WAVE + (lane == 63u ? TRI_PER_WAVE - 1 : trip);
         const bool active = lane < 63u && e < n;
         const size_t i = e < n ? e : n - 1;
+        ws.mark();
         const bool poisoned = queue_wait(flags, g, p, spin_limit);
+        ws.wait_done();
         uint4* st = state + (g - ndirect) * (size_t)ROWS * 64;
         if (poisoned) {
             if (p == TASKS - 1 && active) { bad_flag[1] = 1; gt_poison(out + 576 * e, t.role); }
@@ -514,19 +547,21 @@ __device__ __forceinline__ void split3_queue_body(size_t n, const uint8_t* in1, 
             } else if (active) gt_store_coeff(out + 576 * e, r, t.role);
         }
         queue_publish(flags, g, p, poisoned, lane);
+        ws.task_done();
     }
+    ws.finish();
 }
 __global__ void __launch_bounds__(BLOCK, 2) miller3_queue_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* out, int* bad_flag, uint4* state,
-                                                              unsigned int* flags, unsigned int* counter, int spin_limit) {
+                                                              unsigned int* flags, unsigned int* counter, int spin_limit, unsigned long long* wstats) {
     __shared__ fp4_slot slots[BLOCK];
     slot_fair_set(slots[threadIdx.x].v, 0);
-    split3_queue_body<true>(n, g1, g2, out, bad_flag, state, flags, counter, spin_limit, slots[threadIdx.x].v);
+    split3_queue_body<true>(n, g1, g2, out, bad_flag, state, flags, counter, spin_limit, slots[threadIdx.x].v, wstats);
 }
 __global__ void __launch_bounds__(BLOCK, 2) fexp3_queue_kernel(size_t n, const uint8_t* in576, uint8_t* out, int* bad_flag, uint4* state,
-                                                            unsigned int* flags, unsigned int* counter, int spin_limit) {
+                                                            unsigned int* flags, unsigned int* counter, int spin_limit, unsigned long long* wstats) {
     __shared__ fp4_slot slots[BLOCK];
     slot_fair_set(slots[threadIdx.x].v, 0);
-    split3_queue_body<false>(n, in576, nullptr, out, bad_flag, state, flags, counter, spin_limit, slots[threadIdx.x].v);
+    split3_queue_body<false>(n, in576, nullptr, out, bad_flag, state, flags, counter, spin_limit, slots[threadIdx.x].v, wstats);
 }
 
 // ------------------------------------------------------------------ both G2 arguments fixed for the batch

@@ -84,9 +84,9 @@ __global__ void __launch_bounds__(BLOCK, 2) gt_is_unity_kernel(size_t n, const u
 __global__ void __launch_bounds__(BLOCK, 2) pair3_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) pair3_prod_kernel(size_t n, int k, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag, int miller_only);
 __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, size_t b2_stride, uint8_t* out, int* bad_flag, const int32_t* skip_if);
-__global__ void __launch_bounds__(BLOCK, 2) miller3_queue_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit);
-__global__ void __launch_bounds__(BLOCK, 2) fexp3_queue_kernel(size_t n, const uint8_t* in576, uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit);
-__global__ void __launch_bounds__(BLOCK, 2) pair3_queue_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit, unsigned long long* stamps);
+__global__ void __launch_bounds__(BLOCK, 2) miller3_queue_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit, unsigned long long* wstats);
+__global__ void __launch_bounds__(BLOCK, 2) fexp3_queue_kernel(size_t n, const uint8_t* in576, uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit, unsigned long long* wstats);
+__global__ void __launch_bounds__(BLOCK, 2) pair3_queue_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit, unsigned long long* stamps, unsigned long long* wstats);
 __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_queue_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, size_t b2_stride, uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, const int32_t* skip_if, int spin_limit);
 __global__ void __launch_bounds__(BLOCK, 2) g2_lines_table_kernel(const uint8_t* q192, int32_t* buf, int need_g2);
 __global__ void __launch_bounds__(BLOCK, 2) gate_and_kernel(int32_t* gate, const int32_t* a, const int32_t* b);

@@ -241,7 +241,12 @@ void from_bytes(fp12& result, bytes_view& bytes) noexcept { std::memset(&result,
 void to_bytes(bytes_view& result, fp12& value) noexcept { std::memcpy(result.data, raw(value), 576); result.len = 576; }
 void conjugate(fp12& result, fp12& value) noexcept { ck(c12381_gt_op_batch(ctx(), 1, 1, raw(value), nullptr, raw(result))); }
 void multiply(fp12& result, fp12& value) noexcept { ck(c12381_gt_op_batch(ctx(), 0, 1, raw(result), raw(value), raw(result))); }
-void pow(fp12& result, fp12& base, const big& exponent) noexcept {                // was FP12_pow (exponent used as given)
+// was FP12_pow (fp12_BLS12381.cpp:736-774), which uses the exponent AS GIVEN.  The C ABI carries 32-byte exponents: a value below 2^256 is passed as it
+// is; a value of 2^256 or more (a `big` holds up to 406 bits) is reduced mod r by scalar32 first.  Unobservable through the reference's headers: every
+// exponent they form is a Zp_number, normalised below r < 2^255 (zp_number.hpp:656-659, :262-267), and for a base in GT (order r) the reduced
+// exponent gives the same element anyway; it differs from FP12_pow only for an exponent >= 2^256 applied to a base OUTSIDE the order-r subgroup,
+// which no caller of this seam produces.
+void pow(fp12& result, fp12& base, const big& exponent) noexcept {
     uint8_t k[32];
     scalar32(k, exponent);
     ck(c12381_gt_op_batch(ctx(), 2, 1, raw(base), k, raw(result)));

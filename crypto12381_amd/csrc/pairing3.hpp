@@ -1161,6 +1161,14 @@ C12381_HDN void miller3_range(fp4& F, fp2& tc, const fp& px, const fp& py, bool 
         fp_select(sel, t.role == 0, px, py);
         slot_psel_store(F, sel);
     }
+#if defined(C12381_MILLER_UNFUSED)      // A/B (round 5): squaring and doubling step + line as two out-of-line routines, as miller3_range2 runs them
+#pragma unroll 1
+    for (int i = hi; i >= lo; --i) {
+        C12381_FAIR_SHARE(i, F);
+        f12t_sqr_h(F, t);
+        miller3_pair_step(F, tc, px, py, skip, Q, i, t);
+    }
+#else
     const int info = t.role | (t.base << 2) | (skip ? 256 : 0);
     miller3_regs R = m3r_pack(tc, F, info);
 #pragma unroll 1
@@ -1175,6 +1183,7 @@ C12381_HDN void miller3_range(fp4& F, fp2& tc, const fp& px, const fp& py, bool 
         }
     }
     m3r_tc(tc, R);
+#endif
 }
 C12381_HDN void miller3_range2(fp4& F, fp2& tc1, const fp& px1, const fp& py1, bool skip1, const g2p& Q1,
                                fp2& tc2, const fp& px2, const fp& py2, bool skip2, const g2p& Q2, int hi, int lo, const tri& t) {

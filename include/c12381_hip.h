@@ -23,6 +23,14 @@
  *   - "host" entry points take host pointers (the library stages through its own device buffers);
  *     "_dev" entry points take DEVICE pointers (16-byte aligned) and run asynchronously on the
  *     context's stream; call c12381_sync() before reading results.
+ *   - Stream ordering of "_dev" calls.  Every kernel of a context runs on the CONTEXT'S stream (its own, or the
+ *     one given to c12381_set_stream) and only there: inputs must be COMPLETE ON THAT STREAM when the call
+ *     is made, and outputs are ordered only with later work on that stream.  A caller that fills the inputs
+ *     on another stream (a framework's default stream, a copy stream) records an event there and hands it to
+ *     c12381_wait_event() before the call; a caller that consumes the outputs on another stream calls
+ *     c12381_record_event() after it and waits for that event on its own stream.  Neither blocks the host.
+ *     Without such an edge the library may read half-written inputs: by construction it cannot see a foreign
+ *     stream (c12381_sync() or a device-wide synchronise are the host-blocking alternatives).
  *   - One context per host thread / per GPU; contexts are independent (thread-compatible).
  *   - There is no CPU fallback: without a usable HIP device c12381_create fails.
  */
@@ -58,6 +66,15 @@ int c12381_set_stream(c12381_ctx* ctx, void* hip_stream);
  * status read (every host entry point and every c12381_sync reads and clears the status) raised one:
  * callers of _dev entry points separate logical operations with c12381_sync() */
 int c12381_sync(c12381_ctx* ctx);
+/* Device-side ordering against other streams for the "_dev" entry points (see "Stream ordering" above); `hip_event` is a hipEvent_t
+ * passed as void*, created and destroyed by the caller.
+ *   c12381_wait_event:   all work the context launches AFTER this call waits for the event (hipStreamWaitEvent on the context's
+ *                        stream): record the event on the stream that produced the inputs, then call this, then the _dev entry point.
+ *   c12381_record_event: records the event on the context's stream behind everything launched so far (including the library's
+ *                        side-stream work, which is joined first): make the consuming stream wait for it.
+ * No counterpart in the reference (its seam is synchronous host code, include/crypto12381/miracl_core_interface.hpp:186-204). */
+int c12381_wait_event(c12381_ctx* ctx, void* hip_event);
+int c12381_record_event(c12381_ctx* ctx, void* hip_event);
 /* Per-kernel timing with HIP events on the context's stream (used by bench.py for the roofline
  * figure).  enable != 0 starts a fresh recording; kind: 0 = G1 scalar-mul kernel, 1 = G1 finish
  * (inversion + encode) kernel, 2 = G2 scalar-mul kernel, 3 = pairing kernel, 4 = pairing-equality kernel, 5 = MSM bucket kernel,

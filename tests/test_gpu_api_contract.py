@@ -105,6 +105,51 @@ def test_device_pointer_entry_points_report_through_sync(ctx):
     assert res[:49] == b"\xff" * 49 and res[49:] == cat(g["mul49"])[49:]
 
 
+def test_stream_ordering_through_events():
+    """include/c12381_hip.h "Stream ordering": inputs filled on ANOTHER stream behind a long-running kernel, outputs consumed on a third one —
+    c12381_wait_event / c12381_record_event are the only edges (no host-side wait anywhere between the fill and the read-back).  The input
+    buffers hold a different valid batch beforehand, so a library that did not wait would return that batch's (wrong) results, not an error."""
+    import torch
+    from crypto12381_amd import Context
+    dev = torch.device("cuda", 0)
+    g = golden("g1")
+    pts, sc = cat(g["points"]), cat(g["scalars"])
+    n = len(sc) // 32
+    c = Context(0)                                                                 # its own stream, unknown to torch
+    try:
+        stale_p = c.g1_mul(pts, scalars(77, n), 96)                                # another valid batch
+        stale_s = scalars(78, n)
+        want, stale_want = cat(g["mul96"]), c.g1_mul(stale_p, stale_s, 96)
+        assert want != stale_want
+        src_p = torch.frombuffer(bytearray(pts), dtype=torch.uint8).pin_memory()
+        src_s = torch.frombuffer(bytearray(sc), dtype=torch.uint8).pin_memory()
+        dp = torch.frombuffer(bytearray(stale_p), dtype=torch.uint8).to(dev)
+        ds = torch.frombuffer(bytearray(stale_s), dtype=torch.uint8).to(dev)
+        out = torch.zeros(96 * n, dtype=torch.uint8, device=dev)
+        host = torch.zeros(96 * n, dtype=torch.uint8).pin_memory()
+        torch.cuda.synchronize(dev)
+        prod, cons = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        ready, done = torch.cuda.Event(), torch.cuda.Event()
+        with torch.cuda.stream(prod):
+            torch.cuda._sleep(400_000_000)                                         # ~0.2 s of spinning in front of the fill
+            dp.copy_(src_p, non_blocking=True)
+            ds.copy_(src_s, non_blocking=True)
+            ready.record(prod)
+        c.wait_event(ready.cuda_event)
+        c.g1_mul_dev(n, dp.data_ptr(), ds.data_ptr(), out.data_ptr(), 96)
+        done.record(cons)                                                          # creates the handle; re-recorded on the library's stream below
+        c.record_event(done.cuda_event)
+        with torch.cuda.stream(cons):
+            cons.wait_event(done)
+            host.copy_(out, non_blocking=True)
+        cons.synchronize()                                                         # the first host-side wait
+        assert bytes(host.numpy()) == want
+        assert c.sync() == 0
+        assert c.lib.c12381_wait_event(c.h, None) == E_ARG and c.lib.c12381_record_event(c.h, None) == E_ARG
+    finally:
+        c.close()
+
+
 def test_contexts_are_independent(ctx):
     from crypto12381_amd import Context
     g = golden("g1")

@@ -6,7 +6,8 @@ hits all of them alike.
 
     python tools/ab_bench.py [--legs g1,g2,pair,miller,fexp,msm,bbs] [--reps 3] [--rounds 2] default crypto12381_amd/lib/exp/libX.so ...
 
-`default` = the product library.  Prints one table; exit status 1 if any digest differs from the first variant's."""
+`default` = the product library.  Prints one table; exit status 1 if any digest differs from the first variant's or any child failed
+(crash, time-out, no result line): the run stops at the first such child."""
 import argparse
 import hashlib
 import json
@@ -121,17 +122,29 @@ def main():
         child(a.child, legs, a.reps)
         return
     runs = {lib: [] for lib in a.libs}
+    bad = False
+    # A child that crashes, times out or prints no result stops the WHOLE comparison with a non-zero status: a variant that faulted the GPU must
+    # not be followed by further launches on the same box (tools/gpu_pass.sh stops its pass on this status), and a table with a silent hole
+    # in it is not a record.
     for rnd in range(a.rounds):
         for lib in a.libs:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", lib, "--legs", a.legs, "--reps", str(a.reps)], cwd=ROOT,
-                               capture_output=True, text=True, timeout=900)
-            line = [l for l in r.stdout.splitlines() if l.startswith("ABJSON ")]
-            if r.returncode != 0 or not line:
-                print("%s: FAILED rc=%d\n%s" % (lib, r.returncode, (r.stdout + r.stderr)[-1500:]), flush=True)
-                continue
+            cmd = [sys.executable, os.path.abspath(__file__), "--child", lib, "--legs", a.legs, "--reps", str(a.reps)]
+            try:
+                r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+                rc, out, err = r.returncode, r.stdout, r.stderr
+            except subprocess.TimeoutExpired as e:
+                dec = lambda b: b.decode(errors="replace") if isinstance(b, bytes) else (b or "")
+                rc, out, err = -9, dec(e.stdout), dec(e.stderr) + "\n(timed out after 900 s)"
+            line = [l for l in out.splitlines() if l.startswith("ABJSON ")]
+            if rc != 0 or not line:
+                print("%s: FAILED rc=%d in round %d — stopping, no further variant is started\n--- stdout tail\n%s\n--- stderr tail\n%s"
+                      % (lib, rc, rnd, out[-1500:], err[-2500:]), flush=True)
+                bad = True
+                break
             runs[lib].append(json.loads(line[0][7:]))
             print("round %d %-40s %s" % (rnd, os.path.basename(lib), "  ".join("%s %.2f" % (k, v[0]) for k, v in runs[lib][-1].items())), flush=True)
-    bad = False
+        if bad:
+            break
     first = a.libs[0]
     print("\n%-8s" % "leg" + "".join("%28s" % os.path.basename(l)[:26] for l in a.libs))
     for leg in legs + (["miller"] if "fexp" in legs and "miller" not in legs else []):

@@ -13,6 +13,8 @@
 #   clock                                    tools/clock_probe.py
 #   2rank                                    bench.py --gpus 2 started plainly, gloo on the one GPU
 #   soak / psoak:<minutes>                   tools/soak.py / tools/parity_soak.py
+#   wstats[:<n>]                             tools/queue_wave_stats.py (experiments build): where the queue kernels' wavefronts spend a launch
+#   boxg1                                    tools/box_g1_counters.sh: this box's G1 time, wait fractions, gather latency, L2 hit rate, clock
 set -o pipefail
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -38,6 +40,8 @@ for st in "$@"; do
     2rank) C12381_BENCH_BACKEND=gloo timeout -k 10 900 python bench.py --gpus 2 --steps 2 --warmup 1 > $O/bench_2rank_gloo.json 2> $O/bench_2rank_gloo.err; rc=$?; python tools/bench_summary.py $O/bench_2rank_gloo.json;;
     soak)  timeout -k 10 400 python3 tools/soak.py > $O/soak.log 2>&1; rc=$?; tail -2 $O/soak.log;;
     psoak) timeout -k 10 1000 python3 tools/parity_soak.py --minutes ${arg:-2.5} > $O/parity_soak.log 2>&1; rc=$?; tail -1 $O/parity_soak.log;;
+    wstats) C12381_LIB=crypto12381_amd/lib/libc12381_hip_exp.so C12381_PAIR_STAMPS=/tmp/c12381_stamps_$$.bin timeout -k 10 400 python3 tools/queue_wave_stats.py ${arg} 2>&1 | grep -v amdgpu.ids | tee $O/queue_wave_stats.txt; rc=$?;;
+    boxg1) bash tools/box_g1_counters.sh gpurun_out/$TAG/box_g1 2>&1 | tee $O/box_g1.txt; rc=$?;;
     *) echo "unknown stage $name"; rc=2;;
   esac
   echo "== stage $st rc=$rc"
