@@ -58,8 +58,9 @@ def unit_cflags(unit: str):
 # Round 2 reproduced the wrong-values event with a rebuilt variant: whole wavefront groups wrong, plain grid as
 # well as queue, only with -amdgpu-use-amdgpu-trackers=1; the same source without it is exact on every lane.  The option is
 # refused outright — in CFLAGS and in every environment variable through which hipcc / clang accept extra flags — and the
-# compiler the full-batch parity tests were run with is recorded: another one prints a notice
-# (run tests/test_gpu_full_batch.py before trusting a build from it).
+# compiler the full-batch parity tests were run with is recorded: another one STOPS the build (3-4 % of every kernel hang on an LLVM-internal
+# pass gate of exactly this compiler, and the wrong-lanes event was a build-variant effect) unless C12381_ALLOW_UNVALIDATED_COMPILER=1 says
+# that the caller will run tests/test_gpu_full_batch.py on the result.
 FORBIDDEN_FLAGS = ("amdgpu-use-amdgpu-trackers",)
 FLAG_ENV = ("HIPCC_COMPILE_FLAGS_APPEND", "HIPCC_LINK_FLAGS_APPEND", "HIP_CLANG_FLAGS", "CCC_OVERRIDE_OPTIONS", "HIPCC")
 VALIDATED_COMPILER = "AMD clang version 22.0.0git"          # ROCm 7.2.0
@@ -101,7 +102,12 @@ def _hipcc_version():
         except OSError:
             _HIPCC_VERSION = ""
         if _HIPCC_VERSION and VALIDATED_COMPILER not in _HIPCC_VERSION:
-            print("crypto12381_amd.build: compiler differs from the validated one (%s): run the full-batch parity tests" % VALIDATED_COMPILER, flush=True)
+            if os.environ.get("C12381_ALLOW_UNVALIDATED_COMPILER") != "1":
+                raise RuntimeError("crypto12381_amd.build: %s is not the compiler this library was validated with (%s).  Set "
+                                   "C12381_ALLOW_UNVALIDATED_COMPILER=1 to build anyway, then run tests/test_gpu_full_batch.py (every lane of the "
+                                   "full-size batches against the reference) before trusting the result.\n%s" % (HIPCC, VALIDATED_COMPILER, _HIPCC_VERSION))
+            print("crypto12381_amd.build: compiler differs from the validated one (%s) — allowed by C12381_ALLOW_UNVALIDATED_COMPILER: run "
+                  "tests/test_gpu_full_batch.py" % VALIDATED_COMPILER, flush=True)
     return _HIPCC_VERSION or None
 
 
@@ -129,13 +135,35 @@ def _jobs():
 
 def needs_build() -> bool:
     if _hipcc_version() is None:
-        # no compiler here: prebuilt libraries are taken as they are (they were stamped where they were built); missing ones are an error
-        if os.path.exists(LIB) and os.path.exists(LIB_EXP) and os.path.exists(LIB_PROBE):
+        # no compiler here: prebuilt libraries are taken as they are (they were stamped where they were built); a missing product or experiments
+        # library is an error, the bench-only clock probe is optional (bench.py runs without it: roofline.issue then has no clock)
+        missing = [p for p in (LIB, LIB_EXP) if not os.path.exists(p)]
+        if not missing:
+            if not os.path.exists(LIB_PROBE):
+                print("crypto12381_amd.build: no compiler and no prebuilt %s (bench-only clock probe): continuing without it" % LIB_PROBE, flush=True)
             return False
-        raise RuntimeError("crypto12381_amd.build: %s not found and no prebuilt %s — build the library where hipcc is available" % (HIPCC, LIB))
+        raise RuntimeError("crypto12381_amd.build: %s not found and no prebuilt %s — build the library where hipcc is available" % (HIPCC, ", ".join(missing)))
     srcs = _headers() + [os.path.join(CSRC, u) for u in UNITS]
     return (_stale(LIB, srcs) or _stale(LIB_EXP, srcs) or _stale(LIB_PROBE, [PROBE_SRC])
             or not all(_stamp_ok(u, e) and os.path.exists(os.path.join(OBJ, _obj_name(u, e) + ".o")) for u, e in _jobs()))
+
+
+_PASS_GATE_OK = None
+
+
+def _check_pass_gate() -> None:
+    """`-mllvm -opt-disable=<pass>` is a debugging option of LLVM's pass manager, not a stable interface: probe it once on an empty translation unit
+    so that a toolchain without it fails HERE with a clear message, not with 'Unknown command line argument' in the middle of seven compiles.
+    There is no silent fallback to the plain flags: the shipped instruction counts, the issue figures in profiles/ and the every-lane validation
+    all belong to the build WITH the gate (profiles/r04_ab_noreassoc.txt is the digest-equal A/B against the build without it)."""
+    global _PASS_GATE_OK
+    if _PASS_GATE_OK is None:
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-x", "hip", "-c", "-o", os.devnull, "-mllvm", "-opt-disable=reassociate", "--cuda-device-only", "-"],
+                           input="", stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+        _PASS_GATE_OK = r.returncode == 0
+        if not _PASS_GATE_OK:
+            raise RuntimeError("crypto12381_amd.build: %s does not accept `-mllvm -opt-disable=reassociate` (an LLVM pass gate of AMD clang 22, ROCm 7.2): "
+                               "this library is built and validated with it — use that compiler.\n%s" % (HIPCC, r.stderr[-800:]))
 
 
 def _compile(unit: str, exp: bool, force: bool, verbose: bool) -> str:
@@ -162,6 +190,7 @@ def _compile(unit: str, exp: bool, force: bool, verbose: bool) -> str:
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or needs_build():
         _check_flags()
+        _check_pass_gate()
         os.makedirs(OBJ, exist_ok=True)
         jobs = _jobs()
         with ThreadPoolExecutor(max_workers=8) as ex:

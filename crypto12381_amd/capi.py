@@ -57,6 +57,7 @@ def load_library() -> ctypes.CDLL:
         lib.c12381_sync.argtypes = [vp]
         lib.c12381_wait_event.argtypes = [vp, vp]
         lib.c12381_record_event.argtypes = [vp, vp]
+        lib.c12381_trim.argtypes = [vp]
         lib.c12381_profile.argtypes = [vp, ci]
         lib.c12381_profile_read.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
         for name in ("c12381_fp_op_batch", "c12381_fp_op_batch_dev"):
@@ -163,6 +164,10 @@ class Context:
 
     def sync(self) -> int:
         return self._ck(self.lib.c12381_sync(self.h), allow_point=True)
+
+    def trim(self):
+        """free the context's device workspaces (they grow to the largest call served; the next call allocates what it needs)"""
+        self._ck(self.lib.c12381_trim(self.h))
 
     def wait_event(self, hip_event):
         """everything this context launches from now on waits for `hip_event` (a hipEvent_t as an integer, e.g. torch.cuda.Event.cuda_event

@@ -42,14 +42,9 @@ inline const char* tuning_env(const char*) { return nullptr; }
 // Table slabs: 2816 B per lane — 2.95 GB for a full G1 launch of 2^20 points, 2.95 GB for a full G2 launch of 2^19 (two lanes per point);
 // smaller batches allocate for their own size.
 int g_queue_groups_host = 0;                    // experiments builds: C12381_QUEUE_GROUPS (the device copy is set alongside, k_pair3.hip)
-#ifndef C12381_G1_CHUNK_ROUNDS
-#define C12381_G1_CHUNK_ROUNDS 8
-#endif
-#ifndef C12381_G2_CHUNK_ROUNDS
-#define C12381_G2_CHUNK_ROUNDS 8
-#endif
-constexpr size_t G1_CHUNK = (size_t)65536 * C12381_G1_OCC * C12381_G1_CHUNK_ROUNDS;
-constexpr size_t G2_CHUNK = (size_t)32768 * C12381_G2H_OCC * C12381_G2_CHUNK_ROUNDS;
+constexpr size_t CHUNK_ROUNDS = 8;
+constexpr size_t G1_CHUNK = (size_t)65536 * G1_OCC * CHUNK_ROUNDS;
+constexpr size_t G2_CHUNK = (size_t)32768 * G2H_OCC * CHUNK_ROUNDS;
 constexpr int FLAG_WORDS = 4;                    // device status words (read_flag)
 // terms per bucket-method pass (2 * n * windows sort items < 2^31); C12381_MSM_MAX_TERMS lowers it so that tests reach
 // the multi-part path with small inputs
@@ -216,10 +211,7 @@ static int msm_c(size_t n) {
     static const int forced = [] { const char* e = tuning_env("C12381_MSM_C"); const int v = e ? std::atoi(e) : 0; return v >= 4 && v <= 16 ? v : 0; }();
     return forced ? forced : msm_window_bits(n);
 }
-#ifndef C12381_MSM_SORT_STREAMS
-#define C12381_MSM_SORT_STREAMS 2
-#endif
-constexpr int MSM_SORT_STREAMS = C12381_MSM_SORT_STREAMS;      // streams the window segments are sorted on (>= 2: the context's and its side stream)
+constexpr int MSM_SORT_STREAMS = 2;      // streams the window segments are sorted on (>= 2: the context's and its side stream; three or four measure the same, profiles/r04_ab_msm_front2.txt)
 static_assert(MSM_SORT_STREAMS >= 2 && MSM_SORT_STREAMS <= 8, "MSM_SORT_STREAMS");
 // the unsorted value of entry x of a window segment, as the sort's input iterator reads it (msm_entry_value)
 struct msm_value_fn { uint32_t n; __host__ __device__ uint32_t operator()(uint32_t x) const { return msm_entry_value(x, n); } };
@@ -438,6 +430,23 @@ void c12381_destroy(c12381_ctx* c) {
 }
 
 const char* c12381_last_error(const c12381_ctx* c) { return c ? c->err : "null context"; }
+
+// Workspaces grow to the largest call a context has served and stay (a GT power of 2^16 elements leaves 1.4 GB of tables, 2^18 BBS+ verifications
+// a 172 MB state slab, a 2^20 scalar multiplication its 2.95 GB table slab): a long-lived context that has finished with the large batches hands
+// them back here; the next call allocates what it needs again.
+int c12381_trim(c12381_ctx* c) {
+    int rc = bind(c); if (rc) return rc;
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    if (c->side) HIPCK(c, hipStreamSynchronize(c->side));
+    for (hipStream_t st : c->sort_streams) HIPCK(c, hipStreamSynchronize(st));
+    for (int i = 0; i < c12381_ctx::WS_COUNT; ++i) {
+        if (!c->ws[i]) continue;
+        // cached tables whose headers say "valid" live in some of these slots: freeing them only costs a rebuild on the next call that needs them
+        HIPCK(c, hipFree(c->ws[i]));
+        c->ws[i] = nullptr; c->ws_bytes[i] = 0;
+    }
+    return 0;
+}
 
 int c12381_set_stream(c12381_ctx* c, void* hip_stream) {
     int rc = bind(c); if (rc) return rc;
@@ -875,7 +884,7 @@ static const char* pair_stamps_path() {
 }
 static unsigned long long* pair_stamps(c12381_ctx* c, size_t n) {
     if (!pair_stamps_path()) return nullptr;
-    const size_t tasks = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE * 16;      // ten per group (up to 14 with C12381_MILLER_TASKS = 8), one more for its whole-group stamp
+    const size_t tasks = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE * 16;      // ten per group (room for up to 14), one more for its whole-group stamp
     if (c->stamps_tasks < tasks) {
         (void)hipStreamSynchronize(c->stream);              // a kernel of this context may still be writing the old buffer
         if (c->stamps) (void)hipFree(c->stamps);
@@ -1260,23 +1269,23 @@ static int launch_gt_op(c12381_ctx* c, int op, size_t n, const uint8_t* a, const
         if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
         const size_t groups = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE, nwaves = (size_t)blocks * (BLOCK / 64);
         const size_t tables = nwaves + (groups - queue_direct_groups_host(groups, nwaves));
+        // the rule queues at most 2 x the grid: 6144 tables = 1.4 GB, held until c12381_trim / c12381_destroy; a tuning override beyond that is refused
+        if (tables > 3 * PAIR_QUEUE_WAVES) { std::snprintf(c->err, sizeof c->err, "GT power: %zu tables exceed the workspace budget (queued-groups override too large)", tables); return C12381_E_ARG; }
         if ((rc = ensure(c, c12381_ctx::WS_GT_POW, tables * GT_POW_TAB_BYTES_PER_WAVE))) return rc;
         hipLaunchKernelGGL(gt3_pow_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, a, b, out, c->d_flag, (uint4*)c->ws[c12381_ctx::WS_GT_POW], st, fl, ct,
                            pair_spin_limit());
     } else if (op == 2) {
-        // the power: launches of at most GT_POW_WAVES wavefronts, each with its table of x^0 .. x^15 behind it (224 KB per wavefront; the
-        // same workspace serves every launch: they are ordered on the stream)
-        constexpr size_t GT_POW_WAVES = 4096;
-        const size_t waves = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE, per = waves < GT_POW_WAVES ? waves : GT_POW_WAVES;
-        int rc;
-        if ((rc = ensure(c, c12381_ctx::WS_GT_POW, per * GT_POW_TAB_BYTES_PER_WAVE))) return rc;
-        for (size_t w0 = 0; w0 < waves; w0 += per) {
-            const size_t i0 = w0 * TRI_PER_WAVE, m = n - i0 < per * TRI_PER_WAVE ? n - i0 : per * TRI_PER_WAVE;
-            hipLaunchKernelGGL(gt3_op_kernel, dim3(grid_tri(m)), dim3(BLOCK), 0, c->stream, op, m, a + 576 * i0, b + 32 * i0, out + 576 * i0,
-                               (uint4*)c->ws[c12381_ctx::WS_GT_POW]);
-            HIPCK(c, hipGetLastError());
+        // the power in one plain launch: at most PAIR_QUEUE_WAVES wavefronts get here (longer batches took the queue above), each with its table
+        // of x^0 .. x^15 behind it (224 KB per wavefront).  Only an experiments run with the queue forced off can be longer: it runs the
+        // reference's digit sequence without tables.
+        const size_t waves = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE;
+        uint4* tab = nullptr;
+        if (waves <= PAIR_QUEUE_WAVES) {
+            int rc;
+            if ((rc = ensure(c, c12381_ctx::WS_GT_POW, waves * GT_POW_TAB_BYTES_PER_WAVE))) return rc;
+            tab = (uint4*)c->ws[c12381_ctx::WS_GT_POW];
         }
-        return 0;
+        hipLaunchKernelGGL(gt3_op_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, op, n, a, b, out, tab);
     } else hipLaunchKernelGGL(gt3_op_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, op, n, a, b, out, (uint4*)nullptr);
     HIPCK(c, hipGetLastError());
     return 0;

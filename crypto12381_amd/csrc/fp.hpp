@@ -31,18 +31,6 @@
 #define C12381_CONST constexpr
 #endif
 
-// C12381_FAIR_TURN(i), once per iteration of a kernel's main loop (experiment, off: profiles/r04_ab_fair_share.txt): the wavefront in an odd hardware
-// slot of its SIMD alternates its issue priority, so that the two wavefronts of a SIMD advance together instead of oldest first.
-#ifndef C12381_FAIR_GRID
-#define C12381_FAIR_GRID 0
-#endif
-#if defined(__HIP_DEVICE_COMPILE__) && C12381_FAIR_GRID
-#define C12381_FAIR_TURN(i) do { if (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1u) { \
-        if (__builtin_amdgcn_readfirstlane((int)(i)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } } while (0)
-#else
-#define C12381_FAIR_TURN(i) do { } while (0)
-#endif
-
 // A normalised limb (x & LMASK) is known to be non-negative, and LLVM then canonicalises its sign extension to a ZERO
 // extension; once such a value crosses a basic-block boundary (every accumulator of a loop does) instruction
 // selection no longer sees that bit 31 is clear, cannot use v_mad_i64_i32 for sext(a) * zext(b) and emits TWO
@@ -59,19 +47,11 @@ namespace c12381 { __device__ __forceinline__ int32_t limb_opaque(int32_t v) { a
 // limb products and the non-negative m * p products into two chains.  The build switches that pass off (-mllvm -opt-disable=reassociate,
 // crypto12381_amd/build.py): the source order below — carry first, then the products — survives to instruction selection, fp_mul is 463
 // instructions (hand count 460) and needs 44 registers instead of 84.
-// What did NOT work: C12381_ACC_FENCE=1 (round 3, kept as an A/B switch, OFF: profiles/r03_ab_acc_fence_g2_inline.txt) puts an empty asm on the
-// accumulator after every multiply-add — same chain, but the hazard recognizer pads every edge from an inline asm that defines a VGPR to the
-// instruction that reads it with one s_nop (345 s_nop for 208 joins saved in the bucket kernel; pairing kernel 18.1 -> 24.4 ms); round 4 tried
-// every step as its own one-instruction asm statement: exactly the hand-written stream and one s_nop after EVERY instruction (asm -> asm edges
-// are padded too).  A whole multiplier in one asm statement is out of reach in HIP C++ (42 register operands against the limit of 30).
-#ifndef C12381_ACC_FENCE
-#define C12381_ACC_FENCE 0
-#endif
-#if defined(__HIP_DEVICE_COMPILE__) && C12381_ACC_FENCE
-#define C12381_FENCE(acc) asm("" : "+v"(acc))
-#else
-#define C12381_FENCE(acc)
-#endif
+// What did NOT work: an empty asm on the accumulator after every multiply-add (round 3, profiles/r03_ab_acc_fence_g2_inline.txt) — same chain, but the
+// hazard recognizer pads every edge from an inline asm that defines a VGPR to the instruction that reads it with one s_nop (345 s_nop for 208
+// joins saved in the bucket kernel; pairing kernel 18.1 -> 24.4 ms); every step as its own one-instruction asm statement (round 4): exactly the
+// hand-written stream and one s_nop after EVERY instruction (asm -> asm edges are padded too).  A whole multiplier in one asm statement is out
+// of reach in HIP C++ (42 register operands against the limit of 30).
 
 #include "consts.hpp"
 
@@ -236,19 +216,19 @@ C12381_HD void fp_mul(fp& r, const fp& a, const fp& b) {
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
 #pragma unroll
-        for (int i = 0; i <= k; ++i) { acc += (int64_t)a.l[i] * b.l[k - i]; C12381_FENCE(acc); }
+        for (int i = 0; i <= k; ++i) { acc += (int64_t)a.l[i] * b.l[k - i]; }
 #pragma unroll
-        for (int i = 0; i < k; ++i) { acc += (int64_t)m[i] * FP_P[k - i]; C12381_FENCE(acc); }
+        for (int i = 0; i < k; ++i) { acc += (int64_t)m[i] * FP_P[k - i]; }
         m[k] = (int32_t)(((uint32_t)acc * FP_N0) & LMASK);
-        acc += (int64_t)m[k] * FP_P[0]; C12381_FENCE(acc);
+        acc += (int64_t)m[k] * FP_P[0];
         acc >>= LB;
     }
 #pragma unroll
     for (int k = NL; k < 2 * NL - 1; ++k) {
 #pragma unroll
-        for (int i = k - NL + 1; i < NL; ++i) { acc += (int64_t)a.l[i] * b.l[k - i]; C12381_FENCE(acc); }
+        for (int i = k - NL + 1; i < NL; ++i) { acc += (int64_t)a.l[i] * b.l[k - i]; }
 #pragma unroll
-        for (int i = k - NL + 1; i < NL; ++i) { acc += (int64_t)m[i] * FP_P[k - i]; C12381_FENCE(acc); }
+        for (int i = k - NL + 1; i < NL; ++i) { acc += (int64_t)m[i] * FP_P[k - i]; }
         out[k - NL] = C12381_LIMB((int32_t)((uint32_t)acc & LMASK));
         acc >>= LB;
     }
@@ -273,21 +253,21 @@ C12381_HD void fp_sqr(fp& r, const fp& a) {
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
 #pragma unroll
-        for (int i = 0; 2 * i < k; ++i) { acc += (int64_t)a2[i] * a.l[k - i]; C12381_FENCE(acc); }
-        if ((k & 1) == 0) { acc += (int64_t)a.l[k / 2] * a.l[k / 2]; C12381_FENCE(acc); }
+        for (int i = 0; 2 * i < k; ++i) { acc += (int64_t)a2[i] * a.l[k - i]; }
+        if ((k & 1) == 0) { acc += (int64_t)a.l[k / 2] * a.l[k / 2]; }
 #pragma unroll
-        for (int i = 0; i < k; ++i) { acc += (int64_t)m[i] * FP_P[k - i]; C12381_FENCE(acc); }
+        for (int i = 0; i < k; ++i) { acc += (int64_t)m[i] * FP_P[k - i]; }
         m[k] = (int32_t)(((uint32_t)acc * FP_N0) & LMASK);
-        acc += (int64_t)m[k] * FP_P[0]; C12381_FENCE(acc);
+        acc += (int64_t)m[k] * FP_P[0];
         acc >>= LB;
     }
 #pragma unroll
     for (int k = NL; k < 2 * NL - 1; ++k) {
 #pragma unroll
-        for (int i = k - NL + 1; 2 * i < k; ++i) { acc += (int64_t)a2[i] * a.l[k - i]; C12381_FENCE(acc); }
-        if ((k & 1) == 0) { acc += (int64_t)a.l[k / 2] * a.l[k / 2]; C12381_FENCE(acc); }
+        for (int i = k - NL + 1; 2 * i < k; ++i) { acc += (int64_t)a2[i] * a.l[k - i]; }
+        if ((k & 1) == 0) { acc += (int64_t)a.l[k / 2] * a.l[k / 2]; }
 #pragma unroll
-        for (int i = k - NL + 1; i < NL; ++i) { acc += (int64_t)m[i] * FP_P[k - i]; C12381_FENCE(acc); }
+        for (int i = k - NL + 1; i < NL; ++i) { acc += (int64_t)m[i] * FP_P[k - i]; }
         out[k - NL] = C12381_LIMB((int32_t)((uint32_t)acc & LMASK));
         acc >>= LB;
     }
@@ -312,7 +292,7 @@ C12381_HD void fp_col_acc(int64_t& acc, const fp& a, const fp& b, int k) {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
         const int j = k - i;
-        if (j >= 0 && j < NL) { acc += (int64_t)a.l[i] * b.l[j]; C12381_FENCE(acc); }
+        if (j >= 0 && j < NL) { acc += (int64_t)a.l[i] * b.l[j]; }
     }
 }
 // acc += column k of s * a^2 given a2 = 2 s a and ad = s a  (s = +1 or -1): cross terms once, diagonal term
@@ -321,9 +301,9 @@ C12381_HD void fp_col_sqr_acc(int64_t& acc, const fp& a, const fp& a2, const fp&
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
         const int j = k - i;
-        if (j > i && j < NL) { acc += (int64_t)a2.l[i] * a.l[j]; C12381_FENCE(acc); }
+        if (j > i && j < NL) { acc += (int64_t)a2.l[i] * a.l[j]; }
     }
-    if ((k & 1) == 0 && k / 2 < NL) { acc += (int64_t)ad.l[k / 2] * a.l[k / 2]; C12381_FENCE(acc); }
+    if ((k & 1) == 0 && k / 2 < NL) { acc += (int64_t)ad.l[k / 2] * a.l[k / 2]; }
 }
 // limb-wise -a, 2a, -2a: operands of the column scans only (never normalised, never stored)
 C12381_HD void fp_raw_neg(fp& r, const fp& a) {
@@ -351,16 +331,16 @@ C12381_HD void fp_reduce_cols(fp& r, ColFn col) {
     for (int k = 0; k < NL; ++k) {
         col(k, acc);
 #pragma unroll
-        for (int i = 0; i < k; ++i) { acc += (int64_t)m[i] * FP_P[k - i]; C12381_FENCE(acc); }
+        for (int i = 0; i < k; ++i) { acc += (int64_t)m[i] * FP_P[k - i]; }
         m[k] = (int32_t)(((uint32_t)acc * FP_N0) & LMASK);
-        acc += (int64_t)m[k] * FP_P[0]; C12381_FENCE(acc);
+        acc += (int64_t)m[k] * FP_P[0];
         acc >>= LB;
     }
 #pragma unroll
     for (int k = NL; k < 2 * NL - 1; ++k) {
         col(k, acc);
 #pragma unroll
-        for (int i = k - NL + 1; i < NL; ++i) { acc += (int64_t)m[i] * FP_P[k - i]; C12381_FENCE(acc); }
+        for (int i = k - NL + 1; i < NL; ++i) { acc += (int64_t)m[i] * FP_P[k - i]; }
         out[k - NL] = C12381_LIMB((int32_t)((uint32_t)acc & LMASK));
         acc >>= LB;
     }
@@ -384,16 +364,16 @@ C12381_HD void fp_reduce_cols_static(fp& r, ColFn col) {
         constexpr int k = decltype(kc)::value;
         col(k, acc);
 #pragma unroll
-        for (int i = 0; i < k; ++i) { acc += (int64_t)m[i] * FP_P[k - i]; C12381_FENCE(acc); }
+        for (int i = 0; i < k; ++i) { acc += (int64_t)m[i] * FP_P[k - i]; }
         m[k] = (int32_t)(((uint32_t)acc * FP_N0) & LMASK);
-        acc += (int64_t)m[k] * FP_P[0]; C12381_FENCE(acc);
+        acc += (int64_t)m[k] * FP_P[0];
         acc >>= LB;
     });
     fp_static_for(std::make_integer_sequence<int, NL - 1>{}, [&](auto kc) {
         constexpr int k = NL + decltype(kc)::value;
         col(k, acc);
 #pragma unroll
-        for (int i = k - NL + 1; i < NL; ++i) { acc += (int64_t)m[i] * FP_P[k - i]; C12381_FENCE(acc); }
+        for (int i = k - NL + 1; i < NL; ++i) { acc += (int64_t)m[i] * FP_P[k - i]; }
         out[k - NL] = C12381_LIMB((int32_t)((uint32_t)acc & LMASK));
         acc >>= LB;
     });
@@ -434,9 +414,9 @@ C12381_HD void fp_reduce_cols_inj(fp& r, ColFn col, InjFn inj) {
     for (int k = 0; k < NL; ++k) {
         col(k, acc);
 #pragma unroll
-        for (int i = 0; i < k; ++i) { acc += (int64_t)m[i] * FP_P[k - i]; C12381_FENCE(acc); }
+        for (int i = 0; i < k; ++i) { acc += (int64_t)m[i] * FP_P[k - i]; }
         m[k] = (int32_t)(((uint32_t)acc * FP_N0) & LMASK);
-        acc += (int64_t)m[k] * FP_P[0]; C12381_FENCE(acc);
+        acc += (int64_t)m[k] * FP_P[0];
         acc >>= LB;
     }
 #pragma unroll
@@ -444,7 +424,7 @@ C12381_HD void fp_reduce_cols_inj(fp& r, ColFn col, InjFn inj) {
         col(k, acc);
         inj(k - NL, acc);
 #pragma unroll
-        for (int i = k - NL + 1; i < NL; ++i) { acc += (int64_t)m[i] * FP_P[k - i]; C12381_FENCE(acc); }
+        for (int i = k - NL + 1; i < NL; ++i) { acc += (int64_t)m[i] * FP_P[k - i]; }
         out[k - NL] = C12381_LIMB((int32_t)((uint32_t)acc & LMASK));
         acc >>= LB;
     }
@@ -461,7 +441,7 @@ C12381_HD void fp_mul_inj(fp& r, const fp& a, const fp& b, InjFn inj, double inj
     fp t;
     fp_reduce_cols_inj(t, [&](int k, int64_t& acc) {
 #pragma unroll
-        for (int i = 0; i < NL; ++i) { const int j = k - i; if (j >= 0 && j < NL) { acc += (int64_t)a.l[i] * b.l[j]; C12381_FENCE(acc); } }
+        for (int i = 0; i < NL; ++i) { const int j = k - i; if (j >= 0 && j < NL) { acc += (int64_t)a.l[i] * b.l[j]; } }
     }, inj);
     (void)inj_vb; (void)inj_lb;
     C12381_BOUNDS({ check_actual(a, "fp_mul_inj"); check_actual(b, "fp_mul_inj"); set_inj_bounds(t, a.lb * b.lb, a.vb * b.vb, inj_vb, inj_lb, "fp_mul_inj"); })
@@ -475,8 +455,8 @@ C12381_HD void fp_sqr_inj(fp& r, const fp& a, InjFn inj, double inj_vb, double i
     fp_raw_dbl(a2, a);
     fp_reduce_cols_inj(t, [&](int k, int64_t& acc) {
 #pragma unroll
-        for (int i = 0; i < NL; ++i) { const int j = k - i; if (j > i && j < NL) { acc += (int64_t)a2.l[i] * a.l[j]; C12381_FENCE(acc); } }
-        if ((k & 1) == 0 && k / 2 < NL) { acc += (int64_t)a.l[k / 2] * a.l[k / 2]; C12381_FENCE(acc); }
+        for (int i = 0; i < NL; ++i) { const int j = k - i; if (j > i && j < NL) { acc += (int64_t)a2.l[i] * a.l[j]; } }
+        if ((k & 1) == 0 && k / 2 < NL) { acc += (int64_t)a.l[k / 2] * a.l[k / 2]; }
     }, inj);
     (void)inj_vb; (void)inj_lb;
     C12381_BOUNDS({ check_actual(a, "fp_sqr_inj"); set_inj_bounds(t, a.lb * a.lb, a.vb * a.vb, inj_vb, inj_lb, "fp_sqr_inj"); })
@@ -664,7 +644,7 @@ C12381_HDN void fp_pow_fixed(fp& r, const fp& a, const uint32_t (&e)[12]) {
     r = acc;
 }
 // Fermat inversion a^(p-2); 0 -> 0 like the reference (FP_inv fp_BLS12381.cpp:817): 380 squarings + 96 products,
-// 153 K multiply-adds.  Kept as the independent check of fp_inv (tests/host_sim) and selectable with C12381_FERMAT_INV.
+// 153 K multiply-adds.  Kept as the independent check of fp_inv (tests/host_sim).
 C12381_HD void fp_inv_fermat(fp& r, const fp& a) { fp_pow_fixed(r, a, EXP_P_MINUS_2); }
 
 // ------------------------------------------------------------------ inversion by divsteps
@@ -798,11 +778,7 @@ C12381_HDN void fp_inv_divsteps(fp& r, const fp& a) {
     fp_mul(r, x, r2);                                         // (a / R)^-1 * R^2 / R = a^-1 R
 }
 C12381_HD void fp_inv(fp& r, const fp& a) {
-#if defined(C12381_FERMAT_INV)
-    fp_inv_fermat(r, a);
-#else
     fp_inv_divsteps(r, a);
-#endif
 }
 // candidate square root a^((p+1)/4) (p = 3 mod 4); caller verifies r^2 == a
 C12381_HD void fp_sqrt_candidate(fp& r, const fp& a) { fp_pow_fixed(r, a, EXP_P_PLUS_1_DIV_4); }

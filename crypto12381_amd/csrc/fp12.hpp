@@ -183,39 +183,6 @@ C12381_HDN void fp12_sqr(fp12& w, const fp12& x) {
 //   wb = 3 s xc^2 + 2 conj(xb),  wc = 3 xb^2 - 2 conj(xc)   need xb and xc
 // `reduce` re-bounds the results (fp_weak_reduce) in the same pass.  Outputs may alias inputs.
 // A/B switch (pairing3.hpp says why it is off)
-#ifndef C12381_INJ_SQR
-#define C12381_INJ_SQR 0
-#endif
-#if C12381_INJ_SQR
-// Fp4 squaring x = u + v s:  w.a = u^2 + xi v^2 = (u + v)(u + xi v) - (1 + xi) u v,  w.b = 2 u v  (FP4_sqr :243-271).  The term
-// -(2 + i) t3, t3 = u v, is injected into the reductions of the second product (fp2_mul_inj): w.a leaves them normalised — no lazy
-// sums, no carry round.  _raw: w.b = 2 t3 left as limbs below 2^29 for callers that add or select before they normalise anyway.
-C12381_HD void fp4_sqr_core_wa(fp2& wa, fp2& t3, const fp4& x) {
-    const int32_t c1 = fp_opaque_const(1), cm1 = fp_opaque_const(-1), cm2 = fp_opaque_const(-2);
-    fp2 t1, t2, xv;
-    fp2_mul(t3, x.a, x.b);
-    fp2_add(t1, x.a, x.b);
-    fp2_mul_ip(xv, x.b);
-    fp2_add(xv, x.a, xv);
-    fp2_norm1(t2, xv);
-    // (2 + i)(a + b i) = (2a - b) + (a + 2b) i
-    fp2_mul_inj(wa, t1, t2, [&](int i, int64_t& acc) { fp_inj(acc, t3.a, i, cm2); fp_inj(acc, t3.b, i, c1); },
-                [&](int i, int64_t& acc) { fp_inj(acc, t3.a, i, cm1); fp_inj(acc, t3.b, i, cm2); },
-                C12381_INJB(2 * t3.a.vb + t3.b.vb, 2 * t3.a.lb + t3.b.lb), C12381_INJB(t3.a.vb + 2 * t3.b.vb, t3.a.lb + 2 * t3.b.lb));
-}
-C12381_HD void fp4_sqr_core_raw(fp4& w, const fp4& x) {
-    fp2 t3, wa;
-    fp4_sqr_core_wa(wa, t3, x);
-    w.a = wa;
-    fp2_dbl(w.b, t3);
-}
-C12381_HD void fp4_sqr_core(fp4& w, const fp4& x) {            // fp4_sqr body, inlined into the callers below
-    fp2 t3, wa;
-    fp4_sqr_core_wa(wa, t3, x);
-    w.a = wa;
-    fp2_norm1_dbl(w.b, t3);
-}
-#else
 // fp4_sqr body without the final carry round: limbs up to 2^30 (w.a) / 2^29 (w.b) — for callers that add or select
 // before they normalise anyway (the unitary squaring)
 C12381_HD void fp4_sqr_core_raw(fp4& w, const fp4& x) {
@@ -237,7 +204,6 @@ C12381_HD void fp4_sqr_core(fp4& w, const fp4& x) {            // fp4_sqr body, 
     fp2_norm1(w.a, r.a);
     fp2_norm1(w.b, r.b);
 }
-#endif
 C12381_HDN void fp12_usqr_a(fp4& wa, const fp4& xa, bool reduce) {
     fp4 A, t, u;
     fp4_sqr_core(A, xa);

@@ -23,13 +23,9 @@ C12381_HD void g1_norm1(g1p& r, const g1p& p) { fp_norm1(r.x, p.x); fp_norm1(r.y
 // P = 2P.  6M + 2S with 7 reductions (Y3 is a lazily reduced sum of two products).
 // Operand limb bound: <= 2^29.
 // Round 4: u = Y^2 - 9b Z^2 leaves the reduction of Y^2 with -3 (3b Z^2) injected (fp_reduce_cols_inj) — normalised, no lazy
-// sum and no carry round; Y^2 itself is u + 3 (3b Z^2), used lazily (-DC12381_INJ_G1=0: the lazy form, A/B).
-#ifndef C12381_INJ_G1
-#define C12381_INJ_G1 1
-#endif
+// sum and no carry round; Y^2 itself is u + 3 (3b Z^2), used lazily (the lazy form of both formulas: profiles/r04_ab_injection_switches.txt).
 C12381_HD void g1_dbl(g1p& p) {
     fp t0, t1, t2, z8, u, y3, x3, z3;
-#if C12381_INJ_G1
     const int32_t cm3 = fp_opaque_const(-3);
     fp_mul(t1, p.y, p.z);
     fp_sqr(t2, p.z);
@@ -39,18 +35,6 @@ C12381_HD void g1_dbl(g1p& p) {
     fp_mul_small(z8, t0, 8);                             // 8 Y^2
     fp_add(y3, t0, t2);
     fp_mul(z3, t1, z8);
-#else
-    fp_sqr(t0, p.y);
-    fp_mul(t1, p.y, p.z);
-    fp_sqr(t2, p.z);
-    fp_mul_small(z8, t0, 8);                             // 8 Y^2
-    fp_mul_small(t2, t2, 12);                            // 3b Z^2
-    fp_add(y3, t0, t2);
-    fp_mul(z3, t1, z8);
-    fp_dbl(u, t2); fp_add(u, u, t2);                     // 9b Z^2
-    fp_sub(u, t0, u);
-    fp_norm1(u, u);
-#endif
     fp_mul2<false>(y3, u, y3, t2, z8);                   // (Y^2 - 9bZ^2)(Y^2 + 3bZ^2) + 3bZ^2 * 8Y^2
     fp_mul(t1, p.x, p.y);
     fp_mul(x3, u, t1);
@@ -65,7 +49,6 @@ C12381_HD void g1_add(g1p& p, const g1p& q) {
     fp_mul(t0, p.x, q.x);
     fp_mul(t1, p.y, q.y);
     fp_mul(t2, p.z, q.z);
-#if C12381_INJ_G1
     {   // the Karatsuba corrections -t0 - t1, -t1 - t2 ride in the reductions: t3, t4 normalised without a lazy sum or a carry round
         const int32_t cm1 = fp_opaque_const(-1);
         fp sa, sb;
@@ -74,12 +57,6 @@ C12381_HD void g1_add(g1p& p, const g1p& q) {
         fp_add(sa, p.y, p.z); fp_add(sb, q.y, q.z);
         fp_mul_inj(t4, sa, sb, [&](int i, int64_t& acc) { fp_inj(acc, t1, i, cm1); fp_inj(acc, t2, i, cm1); }, C12381_BV(t1.vb + t2.vb), C12381_BV(t1.lb + t2.lb));
     }
-#else
-    fp_add(t3, p.x, p.y); fp_add(t4, q.x, q.y); fp_mul(t3, t3, t4);
-    fp_add(t4, t0, t1); fp_sub(t3, t3, t4); fp_norm1(t3, t3);
-    fp_add(t4, p.y, p.z); fp_add(x3, q.y, q.z); fp_mul(t4, t4, x3);
-    fp_add(x3, t1, t2); fp_sub(t4, t4, x3);
-#endif
     fp_add(x3, p.x, p.z); fp_add(y3, q.x, q.z); fp_mul(x3, x3, y3);
     fp_add(y3, t0, t2); fp_sub(y3, x3, y3);
     fp_mul_small(t0, t0, 3);
@@ -218,10 +195,7 @@ C12381_HD void soa_load_g1(g1p& p, const int32_t* base, size_t stride, size_t id
 // entry touches 176 consecutive bytes of HBM instead of 42 scattered dwords (the limb-major layout of the
 // first version moved ~16x the algorithmic bytes: profiles/r01_pmc_summary_before_table_fix.txt).
 // Per scalar multiplication: 8 + 125 doublings and 7 + 52 additions (4-bit windows: 4 + 128 and 3 + 66).
-#ifndef C12381_G1_WIN
-#define C12381_G1_WIN 5                                 // 4 or 5; A/B on MI355X: 5 is 3.5 % faster
-#endif
-constexpr int G1_WIN = C12381_G1_WIN;
+constexpr int G1_WIN = 5;                               // 4 or 5; A/B on MI355X (profiles/r02_ab_g1_window5.txt): 5 is 3.5 % faster
 static_assert(G1_WIN == 4 || G1_WIN == 5, "window width");
 constexpr int G1_TAB = 1 << (G1_WIN - 1);              // entries 1..8 (1..16)
 constexpr int G1_WINDOWS = G1_WIN == 4 ? 33 : 26;      // 4: 32 biased nibbles + the carry nibble; 5: 26 biased fields cover 130 bits
@@ -410,32 +384,22 @@ C12381_HD void g1_scalar_mul(g1p& acc, const fp& px, const fp& py, bool p_is_inf
         acc = n;
     }
     g1_add_digit(acc, lane_tab, glv_digit(kb1, G1_WINDOWS - 1), true);
-    // C12381_G1_PREFETCH (round 4): the record of an addition is requested one operation ahead — the first digit's before the window's
-    // doublings (44 registers across them), with 2 also the second digit's before the first addition — instead of at the head of the
-    // addition that needs it, where the whole latency of the gather (a 176-byte record somewhere in a slab of gigabytes) was exposed
-    // twice per window (ISA: 11 loads, then vmcnt waits within 20 instructions).  0 = the round-3 order.
-#ifndef C12381_G1_PREFETCH
-#define C12381_G1_PREFETCH 2
-#endif
+    // (round 4, profiles/r04_ab_g1_prefetch.txt) the record of an addition is requested one operation ahead — the first digit's before the window's
+    // doublings (44 registers across them), the second digit's before the first addition — instead of at the head of the addition that needs
+    // it, where the whole latency of the gather (a 176-byte record somewhere in a slab of gigabytes) was exposed twice per window.
 #pragma unroll 1
     for (int w = G1_WINDOWS - 2; w >= 0; --w) {
-        C12381_FAIR_TURN(w);
-#if C12381_G1_PREFETCH && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
         const int d0 = glv_digit(kb0, w), d1 = glv_digit(kb1, w);
         g1p q0, q1, e;
         tab_load_g1(q0, g1_digit_entry(lane_tab, d0));
         __builtin_amdgcn_sched_barrier(0);               // the loads stay in front of the doublings
         g1_dbl(acc); g1_dbl(acc); g1_dbl(acc); g1_dbl(acc);
         if (G1_WIN == 5) g1_dbl(acc);
-#if C12381_G1_PREFETCH >= 2
         tab_load_g1(q1, g1_digit_entry(lane_tab, d1));
         __builtin_amdgcn_sched_barrier(0);
-#endif
         g1_digit_fix(e, q0, d0, false);
         g1_add(acc, e);
-#if C12381_G1_PREFETCH < 2
-        tab_load_g1(q1, g1_digit_entry(lane_tab, d1));
-#endif
         g1_digit_fix(e, q1, d1, true);
         g1_add(acc, e);
 #else

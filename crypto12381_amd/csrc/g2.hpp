@@ -82,10 +82,6 @@ template <class F> C12381_HDN void g2_add(g2pt<F>& p, const g2pt<F>& q) { g2_add
 // window loop (like g1_scalar_mul) instead of out-of-line routines that take the point through private memory.  Pays where the
 // whole addition fits the register file — the two-lane form (fp2h.hpp specialises this to true).
 template <class F> struct g2_inline_loop { static constexpr bool value = false; };
-#ifndef C12381_G2_PREFETCH
-#define C12381_G2_PREFETCH 0                   // A/B, OFF: requesting the records one operation ahead (as G1 does) costs the two-lane loop 51 more spill
-                                               // instructions and 2 % (15.15 vs 14.85 ms per 2^18, profiles/r04_ab_g1_prefetch.txt); 0 = loaded at the head of the addition
-#endif
 
 // ------------------------------------------------------------------ SoA access
 C12381_HD void soa_store_fp2(int32_t* base, size_t stride, size_t idx, const fp2& a) {
@@ -108,10 +104,7 @@ C12381_HD void soa_load_g2(g2p& p, const int32_t* base, size_t stride, size_t id
 }
 
 // ------------------------------------------------------------------ per-lane window table (one 2688-byte record)
-#ifndef C12381_G2_WIN
-#define C12381_G2_WIN 5                                  // 4 or 5 (signed windows over the four 64-bit GS digits); A/B on MI355X: DESIGN.md 5c
-#endif
-constexpr int G2_WIN = C12381_G2_WIN;
+constexpr int G2_WIN = 5;                                // 4 or 5 (signed windows over the four 64-bit GS digits); A/B on MI355X: profiles/r03_ab_g2_window5.txt
 static_assert(G2_WIN == 4 || G2_WIN == 5, "window width");
 constexpr int G2_TAB = 1 << (G2_WIN - 1);               // entries 1..8 (1..16)
 constexpr int G2_WINDOWS = G2_WIN == 4 ? 17 : 13;       // 4: 16 biased nibbles + the carry nibble; 5: 13 biased fields cover 65 bits
@@ -360,30 +353,6 @@ template <class F> C12381_HDN void g2_scalar_mul(g2pt<F>& acc, const F& qx, cons
     g2_set_inf(run);
 #pragma unroll 1
     for (int w = G2_WINDOWS - 1; w >= 0; --w) {
-        C12381_FAIR_TURN(w);
-#if defined(__HIP_DEVICE_COMPILE__) && C12381_G2_PREFETCH
-        // round 4 (as g1_scalar_mul): in the register-resident two-lane form the record of an addition is requested one operation ahead —
-        // before the window's doublings / before the previous addition — instead of at the head of the addition that needs it
-        if (g2_inline_loop<F>::value && w != G2_WINDOWS - 1) {
-            const int d0 = gs_digit(ub[0], w), d1 = gs_digit(ub[1], w), d2 = gs_digit(ub[2], w), d3 = gs_digit(ub[3], w);
-            g2pt<F> qa, qb, e;
-            g2_digit_load(qa, lane_tab, d0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll 1
-            for (int i = 0; i < G2_WIN; ++i) { F a, b, c; g2_dbl_core(run, a, b, c); }
-            g2_digit_load(qb, lane_tab, d1);
-            __builtin_amdgcn_sched_barrier(0);
-            g2_digit_fix<0>(e, qa, d0); g2_add_core(run, e);
-            g2_digit_load(qa, lane_tab, d2);
-            __builtin_amdgcn_sched_barrier(0);
-            g2_digit_fix<1>(e, qb, d1); g2_add_core(run, e);
-            g2_digit_load(qb, lane_tab, d3);
-            __builtin_amdgcn_sched_barrier(0);
-            g2_digit_fix<2>(e, qa, d2); g2_add_core(run, e);
-            g2_digit_fix<3>(e, qb, d3); g2_add_core(run, e);
-            continue;
-        }
-#endif
         if (w != G2_WINDOWS - 1) {
             if (g2_inline_loop<F>::value) {
 #pragma unroll 1

@@ -9,10 +9,7 @@
 namespace c12381 {
 
 using g2hp = g2pt<fp2h>;
-#ifndef C12381_G2H_INLINE
-#define C12381_G2H_INLINE 1            // A/B: 0 = out-of-line g2_add / g2_dbl_n with the running point in private memory
-#endif
-template <> struct g2_inline_loop<fp2h> { static constexpr bool value = C12381_G2H_INLINE != 0; };
+template <> struct g2_inline_loop<fp2h> { static constexpr bool value = true; };   // (out of line, the running point in private memory: profiles/r03_ab_acc_fence_g2_inline.txt)
 constexpr int G2H_TAB_DWORDS = G2_TAB * G1_ENT_DWORDS;          // per lane: 16 entries x 44 dwords (4-bit windows: 8)
 
 C12381_HD constexpr int g2_ent_dwords(const g2hp&) { return G1_ENT_DWORDS; }

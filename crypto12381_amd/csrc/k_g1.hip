@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(BLOCK, 2) fp_mulchain_kernel(size_t n, int ite
 
 // proj layout: coordinate-major, limb-major SoA: proj[(c*NL + limb) * stride + element]
 // pt_stride = 96 for per-lane points, 0 to broadcast one point to every lane (fixed-base columns of BBS+)
-__global__ void __launch_bounds__(BLOCK, C12381_G1_OCC) g1_mul_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab,
+__global__ void __launch_bounds__(BLOCK, G1_OCC) g1_mul_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab,
                                                        int32_t* proj, size_t proj_stride, size_t proj_off, int* bad_flag, const int32_t* skip_if,
                                                        int small_term) {
     if (skip_if && skip_if[HDR_VALID] != 0) return;          // this column is served by a valid fixed-base table (k_fixed.hip)
@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(BLOCK, 2) msm_sizes_kernel(size_t nbk, const u
         for (uint32_t s = 0; s < ns; ++s) seg[base + s] = make_uint2((uint32_t)b, s);
     }
 }
-__global__ void __launch_bounds__(BLOCK, C12381_MSM_OCC) msm_bucket_kernel(size_t nbk, const uint32_t* lo, const uint32_t* hi, const uint32_t* vals,
+__global__ void __launch_bounds__(BLOCK, MSM_OCC) msm_bucket_kernel(size_t nbk, const uint32_t* lo, const uint32_t* hi, const uint32_t* vals,
                                                            const int32_t* pts2, int32_t* bk, const uint32_t* order, uint32_t cap, uint32_t early_max) {
     const size_t slot = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (slot >= nbk) return;

@@ -10,7 +10,7 @@ using namespace c12381;
 
 namespace c12381 {
 
-__global__ void __launch_bounds__(BLOCK, C12381_G2H_OCC) g2_mul2_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab,
+__global__ void __launch_bounds__(BLOCK, G2H_OCC) g2_mul2_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab,
                                                         int* bad_flag, const int32_t* skip_if, int32_t* proj, size_t proj_stride, size_t proj_off, int in_g2) {
     if (skip_if && skip_if[HDR_VALID] != 0) return;          // served by a valid fixed-base table (k_fixed.hip)
     const size_t lane = (size_t)blockIdx.x * BLOCK + threadIdx.x;

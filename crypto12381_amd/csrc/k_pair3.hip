@@ -23,32 +23,12 @@ __device__ __forceinline__ size_t queue_direct_groups(size_t ngroups, size_t nwa
     return ngroups - queued;
 }
 // Miller-loop tasks per group in the queue kernels (the 64 iterations in equal parts)
-#ifndef C12381_MILLER_TASKS
-#define C12381_MILLER_TASKS 4
-#endif
-static_assert(64 % C12381_MILLER_TASKS == 0, "C12381_MILLER_TASKS divides 64");
-constexpr int MILLER_ITERS_PER_TASK = 64 / C12381_MILLER_TASKS;
-// Issue priority of the two kinds of work (s_setprio) — an experiment, OFF (profiles/r04_ab_queue_priority.txt).  A SIMD serves the older of its two
-// wavefronts first, so a wavefront that has finished its whole groups and moved on to queue tasks keeps the younger one's whole group waiting.
-// 1: whole groups at a raised priority, tasks at the default ("longest job first") — 2^16 pairings 16.9 -> 33.2 ms: a task wavefront that cannot
-// issue at all holds its group's chain up, and the wavefronts that claimed the following phases spin behind it.  2: everything raised, 3: the
-// tasks raised — both within 0.5 % of no priorities at all (what the age order already does).
-#ifndef C12381_QUEUE_PRIO
-#define C12381_QUEUE_PRIO 0
-#endif
-#if C12381_QUEUE_PRIO == 1
-#define C12381_QUEUE_PRIO_WHOLE() __builtin_amdgcn_s_setprio(2)
-#define C12381_QUEUE_PRIO_TASKS() __builtin_amdgcn_s_setprio(0)
-#elif C12381_QUEUE_PRIO == 2      // experiment: everything at the raised priority
-#define C12381_QUEUE_PRIO_WHOLE() __builtin_amdgcn_s_setprio(2)
-#define C12381_QUEUE_PRIO_TASKS() __builtin_amdgcn_s_setprio(2)
-#elif C12381_QUEUE_PRIO == 3      // experiment: the tasks first
-#define C12381_QUEUE_PRIO_WHOLE() __builtin_amdgcn_s_setprio(0)
-#define C12381_QUEUE_PRIO_TASKS() __builtin_amdgcn_s_setprio(2)
-#else
-#define C12381_QUEUE_PRIO_WHOLE() ((void)0)
-#define C12381_QUEUE_PRIO_TASKS() ((void)0)
-#endif
+constexpr int MILLER_TASKS_PER_GROUP = 4;       // 2 and 8 measured: 2 loses 4 %, 8 is within the spread of 4 (profiles/r04_ab_queue_priority.txt, r05_ab_miller_variants.txt)
+static_assert(64 % MILLER_TASKS_PER_GROUP == 0, "the Miller-loop tasks divide the 64 iterations");
+constexpr int MILLER_ITERS_PER_TASK = 64 / MILLER_TASKS_PER_GROUP;
+// (Issue priorities for the two kinds of work — s_setprio around the whole groups / the tasks — were measured and are not in the tree: whole groups
+// above tasks doubles the launch, a task holder that cannot issue stalls everyone behind its hand-over; the other two orders change nothing, the
+// SIMD's age order already does that.  profiles/r04_ab_queue_priority.txt)
 namespace c12381 {
 int set_queue_groups_override(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(g_queue_groups_override), &v, sizeof(int)) == hipSuccess ? 0 : -1; }
 }
@@ -279,7 +259,7 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
     t.role = lane == 63u ? 0 : (int)(lane - 3u * trip);
     t.base = lane == 63u ? 63 : (int)(3u * trip);
     const size_t ngroups = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE;
-    constexpr unsigned int MILLER_TASKS = C12381_MILLER_TASKS, TASKS = MILLER_TASKS + 6;
+    constexpr unsigned int MILLER_TASKS = MILLER_TASKS_PER_GROUP, TASKS = MILLER_TASKS + 6;
     constexpr int ROWS = ST_Y1 + ST_ROWS_F;
     // Hybrid schedule.  Wavefronts first claim WHOLE groups (counter[1]: no hand-over, no wait on a slower partner, the state stays
     // in registers and in the LDS slot) until only the last third of the groups (queue_direct_groups) is left; those go through the queue in tenth-length
@@ -290,7 +270,6 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
     const size_t nwaves = (size_t)gridDim.x * (BLOCK / 64);
     const size_t ndirect = queue_direct_groups(ngroups, nwaves);
     const unsigned long long ts_entry = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-    C12381_QUEUE_PRIO_WHOLE();
     for (;;) {
         const unsigned int gc = atomicAdd(counter + 1, lane == 0 ? 1u : 0u);
         const size_t g = (size_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)gc);
@@ -306,7 +285,6 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
             o[3] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
         }
     }
-    C12381_QUEUE_PRIO_TASKS();
     const size_t nq = ngroups - ndirect;                       // queued groups: ndirect .. ngroups - 1
     const size_t ntasks = nq * TASKS;
     for (;;) {
@@ -452,11 +430,10 @@ __device__ __forceinline__ void split3_queue_body(size_t n, const uint8_t* in1, 
     t.role = lane == 63u ? 0 : (int)(lane - 3u * trip);
     t.base = lane == 63u ? 63 : (int)(3u * trip);
     const size_t ngroups = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE;
-    constexpr unsigned int TASKS = MILLER ? (unsigned)C12381_MILLER_TASKS : 6u;
+    constexpr unsigned int TASKS = MILLER ? (unsigned)MILLER_TASKS_PER_GROUP : 6u;
     constexpr int ROWS = ST_Y1 + ST_ROWS_F;
     const size_t nwaves = (size_t)gridDim.x * (BLOCK / 64);
     const size_t ndirect = queue_direct_groups(ngroups, nwaves);
-    C12381_QUEUE_PRIO_WHOLE();
     for (;;) {                                                 // whole groups first
         const unsigned int gc = atomicAdd(counter + 1, lane == 0 ? 1u : 0u);
         const size_t g = (size_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)gc);
@@ -482,7 +459,6 @@ __device__ __forceinline__ void split3_queue_body(size_t n, const uint8_t* in1, 
         }
         ws.whole_done();
     }
-    C12381_QUEUE_PRIO_TASKS();
     const size_t nq = ngroups - ndirect;
     const size_t ntasks = nq * TASKS;
     for (;;) {
@@ -608,12 +584,11 @@ __device__ __forceinline__ void pair3_fixed_queue_body(size_t n, const uint8_t* 
     t.role = lane == 63u ? 0 : (int)(lane - 3u * trip);
     t.base = lane == 63u ? 63 : (int)(3u * trip);
     const size_t ngroups = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE;
-    constexpr unsigned int MILLER_TASKS = C12381_MILLER_TASKS, TASKS = MILLER_TASKS + 6;
+    constexpr unsigned int MILLER_TASKS = MILLER_TASKS_PER_GROUP, TASKS = MILLER_TASKS + 6;
     constexpr int ROWS = ST_Y1 + ST_ROWS_F;
     // whole groups first, the last third of the groups through the queue (see pair3_queue_body)
     const size_t nwaves = (size_t)gridDim.x * (BLOCK / 64);
     const size_t ndirect = queue_direct_groups(ngroups, nwaves);
-    C12381_QUEUE_PRIO_WHOLE();
     for (;;) {
         const unsigned int gc = atomicAdd(counter + 1, lane == 0 ? 1u : 0u);
         const size_t g = (size_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)gc);
@@ -647,7 +622,6 @@ __device__ __forceinline__ void pair3_fixed_queue_body(size_t n, const uint8_t* 
             else gt_store_coeff(out + 576 * e, F, t.role);
         }
     }
-    C12381_QUEUE_PRIO_TASKS();
     const size_t nq = ngroups - ndirect;
     const size_t ntasks = nq * TASKS;
     for (;;) {

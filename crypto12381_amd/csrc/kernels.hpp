@@ -26,21 +26,12 @@ constexpr int HDR_DWORDS = 64;                   // table data starts here
 int set_queue_groups_override(int v);             // k_pair3.hip: tuning switch (C12381_QUEUE_GROUPS)
 constexpr int GATE_OTHER = 49;                   // (gate + GATE_OTHER)[HDR_VALID] = the complement of gate[HDR_VALID]
 
-// Waves per SIMD of the three scalar-multiplication kernels (register budget 512 / occupancy: 256, 168 or 128 VGPRs).  A/B on MI355X
-// (tools/build_variant.sh <name> -DC12381_G1_OCC=3 ...): a 64-bit multiply-add issues every ~5.5 cycles from two
-// resident wavefronts and every ~4.6 from eight (profiles/r03_valu_rates.txt), so a third wavefront pays if its spills stay small.
-#ifndef C12381_G1_OCC
-#define C12381_G1_OCC 2
-#endif
-#ifndef C12381_MSM_OCC
-#define C12381_MSM_OCC 2
-#endif
-#ifndef C12381_G2H_OCC
-#define C12381_G2H_OCC 2
-#endif
+// Waves per SIMD of the three scalar-multiplication kernels (register budget 512 / occupancy: 256, 168 or 128 VGPRs).  Three per SIMD were
+// measured twice and lose: the spills cost more than the third wavefront fills (profiles/r03_ab_occupancy.txt, r04_ab_occupancy3.txt).
+constexpr int G1_OCC = 2, MSM_OCC = 2, G2H_OCC = 2;
 __global__ void __launch_bounds__(BLOCK, 2) fp_op_kernel(int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out);
 __global__ void __launch_bounds__(BLOCK, 2) fp_mulchain_kernel(size_t n, int iters, const uint8_t* a, const uint8_t* b, uint8_t* out);
-__global__ void __launch_bounds__(BLOCK, C12381_G1_OCC) g1_mul_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab, int32_t* proj, size_t proj_stride, size_t proj_off, int* bad_flag, const int32_t* skip_if, int small_term);
+__global__ void __launch_bounds__(BLOCK, G1_OCC) g1_mul_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab, int32_t* proj, size_t proj_stride, size_t proj_off, int* bad_flag, const int32_t* skip_if, int small_term);
 __global__ void __launch_bounds__(BLOCK, 2) g1_rsub_kernel(size_t n, int32_t* acc, size_t acc_stride, const int32_t* other, size_t other_stride, size_t other_off, const int32_t* run_if);
 __global__ void __launch_bounds__(BLOCK, 2) g1_add_kernel(size_t n, const uint8_t* a, const uint8_t* b, int32_t* proj, size_t proj_stride, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) g1_finish_kernel(size_t n, const int32_t* proj, size_t stride, int32_t* pref, uint8_t* out, int fmt, size_t T);
@@ -53,7 +44,7 @@ __global__ void __launch_bounds__(BLOCK, 2) msm_ranges_kernel(size_t E, const ui
 __global__ void __launch_bounds__(BLOCK, 2) msm_prep16_kernel(size_t n, const uint8_t* pts, int in_fmt, const uint8_t* scalars, int c, int W, int32_t* pts2, uint16_t* keys, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) msm_ranges16_kernel(size_t n, const uint16_t* keys, int c, int W, uint32_t* lo, uint32_t* hi);
 constexpr int MSM_RANGES_PER_THREAD = 8;           // entries per thread of msm_ranges16_kernel (the host sizes its grid with it)
-__global__ void __launch_bounds__(BLOCK, C12381_MSM_OCC) msm_bucket_kernel(size_t nbk, const uint32_t* lo, const uint32_t* hi, const uint32_t* vals, const int32_t* pts2, int32_t* bk, const uint32_t* order, uint32_t cap, uint32_t early_max);
+__global__ void __launch_bounds__(BLOCK, MSM_OCC) msm_bucket_kernel(size_t nbk, const uint32_t* lo, const uint32_t* hi, const uint32_t* vals, const int32_t* pts2, int32_t* bk, const uint32_t* order, uint32_t cap, uint32_t early_max);
 __global__ void __launch_bounds__(BLOCK, 2) msm_sizes_kernel(size_t nbk, const uint32_t* lo, const uint32_t* hi, uint32_t* key, uint32_t* ident, uint32_t cap, uint32_t* cnt, uint2* seg, uint4* big, uint32_t early_max);
 __global__ void __launch_bounds__(BLOCK, 2) msm_overflow_kernel(const uint32_t* cnt, const uint2* seg, const uint32_t* lo, const uint32_t* hi, const uint32_t* vals, const int32_t* pts2, int32_t* part, uint32_t cap);
 __global__ void __launch_bounds__(BLOCK, 2) msm_overflow_combine_kernel(const uint32_t* cnt, const uint4* big, const int32_t* part, int32_t* bk);
@@ -65,7 +56,7 @@ __global__ void __launch_bounds__(64, 1) msm_small_term_kernel(const int32_t* sb
 __global__ void __launch_bounds__(64, 1) msm_small_early_kernel(const uint32_t* lo, const uint32_t* hi, uint32_t small_bucket, uint32_t early_max, const uint32_t* vals, const int32_t* pts2, int32_t* term_out, uint32_t* done);
 constexpr uint32_t MSM_SMALL_EARLY_MAX = 4096;     // longest small-scalar bucket msm_small_early_kernel takes (64 additions per lane)
 __global__ void __launch_bounds__(BLOCK, 2) g2_mul_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab, size_t tab_stride, uint8_t* out, int fmt, int* bad_flag, const int32_t* skip_if, int32_t* proj, size_t proj_stride, size_t proj_off, int in_g2);
-__global__ void __launch_bounds__(BLOCK, C12381_G2H_OCC) g2_mul2_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab, int* bad_flag, const int32_t* skip_if, int32_t* proj, size_t proj_stride, size_t proj_off, int in_g2);
+__global__ void __launch_bounds__(BLOCK, G2H_OCC) g2_mul2_kernel(size_t n, const uint8_t* pts, size_t pt_stride, const uint8_t* scalars, int32_t* tab, int* bad_flag, const int32_t* skip_if, int32_t* proj, size_t proj_stride, size_t proj_off, int in_g2);
 __global__ void __launch_bounds__(BLOCK, 2) g2_finish_kernel(size_t n, const int32_t* proj, size_t stride, int32_t* pref, uint8_t* out, int fmt, size_t T);
 __global__ void __launch_bounds__(BLOCK, 2) g2_lift_kernel(size_t n, const uint8_t* pts, int32_t* proj, size_t stride, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) g2_reduce_kernel(size_t n, const int32_t* in, size_t in_stride, size_t m, int32_t* outp, size_t out_stride);

@@ -25,15 +25,9 @@ namespace c12381 {
 constexpr int MSM_PT_DWORDS = 2 * NL;          // affine (x, y) in Montgomery form, normalised limbs: 112 B, seven 16-byte words
 // stride of the records in the MSM's point array: 128 B, one cache line per gathered point.  Packed 112-byte records straddle two
 // lines more often than not — the bucket kernel's gathers then fetched 16.6 GB per 2^22-term product for 7.5 GB of records
-// (profiles/r03_pmc_summary.json).  -DC12381_MSM_PT_STRIDE=28 restores the packed layout (A/B).
-#ifndef C12381_MSM_PT_STRIDE
-#define C12381_MSM_PT_STRIDE 32
-#endif
-constexpr int MSM_PT_STRIDE = C12381_MSM_PT_STRIDE;
-#ifndef C12381_MSM_CHUNK
-#define C12381_MSM_CHUNK 8
-#endif
-constexpr int MSM_CHUNK = C12381_MSM_CHUNK;    // buckets per lane in the window reduction (8: measured 1.1 % faster than 16 at 2^22 terms, profiles/r04_ab_msm_front.txt; -DC12381_MSM_CHUNK=16 for the A/B)
+// (profiles/r03_pmc_summary.json; the A/B against the packed stride of 28: profiles/r03_ab_msm_record_stride_g2_local_point.txt).
+constexpr int MSM_PT_STRIDE = 32;
+constexpr int MSM_CHUNK = 8;                   // buckets per lane in the window reduction (8: measured 1.1 % faster than 16 at 2^22 terms, profiles/r04_ab_msm_front.txt)
 // entries a bucket lane sums at most: twice the mean run + 32 (uniform scalars: mean + 11 sigma or more, so nothing is
 // cut); the rest of a longer run is cut into overflow segments of half that length, one lane each (k_g1.hip).  A lane
 // with a long run finishes alone at single-wavefront latency (~9 us per addition), hence a cap relative to the mean.
@@ -54,7 +48,6 @@ C12381_HD void g1_add_affine(g1p& p, const fp& qx, const fp& qy) {
     fp t0, t1, t2, t3, t4, y3, z3;
     fp_mul(t0, p.x, qx);
     fp_mul(t1, p.y, qy);
-#if C12381_INJ_G1
     {   // round 4: the linear terms ride in the reductions (fp_mul_inj): t3, t4 normalised without lazy sums or carry rounds
         const int32_t c1 = fp_opaque_const(1), cm1 = fp_opaque_const(-1);
         fp sa, sb;
@@ -63,12 +56,6 @@ C12381_HD void g1_add_affine(g1p& p, const fp& qx, const fp& qy) {
         fp_mul_inj(t4, qy, p.z, [&](int i, int64_t& acc) { fp_inj(acc, p.y, i, c1); }, C12381_BV(p.y.vb), C12381_BV(p.y.lb));                                         // Y2 Z1 + Y1
         fp_mul_inj(y3, qx, p.z, [&](int i, int64_t& acc) { fp_inj(acc, p.x, i, c1); }, C12381_BV(p.x.vb), C12381_BV(p.x.lb));                                         // X2 Z1 + X1
     }
-#else
-    fp_add(t3, qx, qy); fp_add(t4, p.x, p.y); fp_mul(t3, t3, t4);
-    fp_add(t4, t0, t1); fp_sub(t3, t3, t4); fp_norm1(t3, t3);                 // X1 Y2 + X2 Y1
-    fp_mul(t4, qy, p.z); fp_add(t4, t4, p.y); fp_norm1(t4, t4);               // Y2 Z1 + Y1
-    fp_mul(y3, qx, p.z); fp_add(y3, y3, p.x);                                 // X2 Z1 + X1
-#endif
     fp_mul_small(t0, t0, 3);
     fp_mul_small(t2, p.z, 12);                                                // b3 Z1
     fp_add(z3, t1, t2); fp_sub(t1, t1, t2);
@@ -88,7 +75,7 @@ C12381_HD void msm_store_pt(int32_t* dst, const fp& x, const fp& y) {
 }
 C12381_HD void msm_load_pt(fp& x, fp& y, const int32_t* src) {
     int32_t w[MSM_PT_DWORDS];
-#if defined(__HIP_DEVICE_COMPILE__) && (!defined(C12381_EXPLICIT_AS) || C12381_EXPLICIT_AS)
+#if defined(__HIP_DEVICE_COMPILE__)
     // the records live in global memory (point array of the MSM, line tables of a fixed G2 argument): said explicitly, because an
     // out-of-line routine sees a generic pointer and would use flat loads, whose every wait is a full vmcnt(0) + lgkmcnt(0) drain
     const __attribute__((address_space(1))) q4* s = (const __attribute__((address_space(1))) q4*)(const void*)src;
@@ -186,7 +173,6 @@ C12381_HD void msm_bucket_one(g1p& acc, size_t lo, size_t hi, const uint32_t* va
     uint32_t idx_next = lo + 1 < hi ? vals_sorted[lo + 1] : 0u;
 #pragma unroll 1
     for (size_t j = lo; j < hi; ++j) {
-        C12381_FAIR_TURN(j >> 2);
         const fp x = xn, y = yn;
         if (j + 1 < hi) {
             msm_load_pt(xn, yn, pts2 + (size_t)idx_next * MSM_PT_STRIDE);

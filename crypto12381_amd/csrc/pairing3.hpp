@@ -81,10 +81,7 @@ C12381_HD int wave_uniform(int v) { return v; }
 // one's priority evens the pair out: 2048 wavefronts of pairings 11.87 -> 11.35 ms.  NOT in the work-queue kernels: there the older wavefront's
 // head start is what the queued tasks fill, and a task holder that is held back stalls the wavefronts waiting for its hand-over (2^16
 // pairings 17.5 -> 20.3 ms with the alternation on; profiles/r04_ab_fair_share.txt).
-#ifndef C12381_FAIR
-#define C12381_FAIR 1
-#endif
-#if defined(__HIP_DEVICE_COMPILE__) && C12381_FAIR
+#if defined(__HIP_DEVICE_COMPILE__)
 // (the conditions as scalars: on per-lane values the two branches become two exec-masked regions and BOTH s_setprio execute)
 #define C12381_FAIR_SHARE(i, slot) do { if ((__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1u) && __builtin_amdgcn_readfirstlane(slot_fair(slot)) != 0) { \
         if (__builtin_amdgcn_readfirstlane((int)(i)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } } while (0)
@@ -215,42 +212,11 @@ C12381_HD fp4& m3r_slot(const miller3_regs& r) { return *r.F; }
 #endif
 
 // ------------------------------------------------------------------ inlined Fp4 cores (operands stay in registers)
-// A/B switches of the round-4 injection forms (tools/build_variant.sh -DC12381_INJ_x=0|1).  Defaults by measurement, one session, every
-// digest equal (profiles/r04_ab_injection_switches.txt): the injected forms of the Fp4 product / squaring and of the generic line
-// product issue 1-3 % fewer instructions but 2-4 % MORE multiply-adds, and the Miller loop came out 1.2 % slower with the line form on
-// (8.88 vs 8.99 ms; its fused iteration spilled 130 instead of 91 dwords), the pairing 1.4 % slower with all three on — so they are OFF;
-// the line product against a normalised table entry (f12t_mul_line1_core) loses its weak reduction and is ON (BBS+ -0.7 %), like the
-// cyclotomic squaring (f12t_usqr3_h: fexp -3.7 %, pairing -3.4 %) and the G1 formulas (g1.hpp: G1 -0.6 %, MSM -0.8 %).
-#ifndef C12381_INJ_MUL
-#define C12381_INJ_MUL 0
-#endif
-#ifndef C12381_INJ_LINE
-#define C12381_INJ_LINE 0
-#endif
-#ifndef C12381_INJ_LINE1
-#define C12381_INJ_LINE1 1
-#endif
-#if C12381_INJ_MUL
-// w = x y = (x.a y.a + xi t2) + ((x.a + x.b)(y.a + y.b) - x.a y.a - t2) s,  t2 = x.b y.b  (FP4_mul :274-304).  t2 is reduced first and
-// injected: w.a = x.a y.a + xi t2 directly, and since x.a y.a = w.a - xi t2 the middle term is (x.a + x.b)(y.a + y.b) - w.a + (xi - 1) t2
-// with xi - 1 = i — both coordinates leave their reductions normalised (no lazy sums, no carry round: -168 instructions, +112 of them
-// multiply-adds by +-1).
-C12381_HD void fp4_mul_core(fp4& w, const fp4& x, const fp4& y) {
-    const int32_t c1 = fp_opaque_const(1), cm1 = fp_opaque_const(-1);
-    fp2 t2, sx, sy, wa, wb;
-    fp2_mul(t2, x.b, y.b);
-    fp2_mul_inj(wa, x.a, y.a, [&](int i, int64_t& acc) { fp_inj(acc, t2.a, i, c1); fp_inj(acc, t2.b, i, cm1); },
-                [&](int i, int64_t& acc) { fp_inj(acc, t2.a, i, c1); fp_inj(acc, t2.b, i, c1); },
-                C12381_INJB(t2.a.vb + t2.b.vb, t2.a.lb + t2.b.lb), C12381_INJB(t2.a.vb + t2.b.vb, t2.a.lb + t2.b.lb));
-    fp2_add(sx, x.a, x.b);
-    fp2_add(sy, y.a, y.b);
-    fp2_mul_inj(wb, sx, sy, [&](int i, int64_t& acc) { fp_inj(acc, wa.a, i, cm1); fp_inj(acc, t2.b, i, cm1); },
-                [&](int i, int64_t& acc) { fp_inj(acc, wa.b, i, cm1); fp_inj(acc, t2.a, i, c1); },
-                // value: -w.a + i t2 = -(t1' + xi t2) + i t2 = -t1' - t2 exactly (t1' = the reduced x.a y.a inside w.a): the bound of the old lazy form
-                C12381_INJB(wa.a.vb - t2.b.vb, wa.a.lb + t2.b.lb), C12381_INJB(wa.b.vb - t2.a.vb, wa.b.lb + t2.a.lb));
-    w.a = wa; w.b = wb;
-}
-#else
+// Reductions that absorb their linear terms (fp_reduce_cols_inj, round 4) are used where they measured faster, one session, every digest equal
+// (profiles/r04_ab_injection_switches.txt): the line product against a normalised table entry (f12t_mul_line1_core, BBS+ -0.7 %), the cyclotomic
+// squaring (f12t_usqr3_h: fexp -3.7 %, pairing -3.4 %) and the G1 formulas (g1.hpp: G1 -0.6 %, MSM -0.8 %).  The injected forms of the Fp4
+// product / squaring and of the generic line product issued 1-3 % fewer instructions but 2-4 % MORE multiply-adds and spilled more in the fused
+// Miller iteration (Miller loop +1.2 %, pairing +1.4 % with all three): measured, not kept in the tree.
 C12381_HD void fp4_mul_core(fp4& w, const fp4& x, const fp4& y) {
     fp2 t1, t2, t3, t4;
     fp2_mul(t1, x.a, y.a);
@@ -265,7 +231,6 @@ C12381_HD void fp4_mul_core(fp4& w, const fp4& x, const fp4& y) {
     fp2_norm1(w.b, t4);
     fp2_norm1(w.a, t3);
 }
-#endif
 // the same without the final carry round (limbs up to 3 * 2^28): for a product that only enters a difference which is
 // carried afterwards (the Karatsuba middle term)
 C12381_HD void fp4_mul_core_raw(fp4& w, const fp4& x, const fp4& y) {
@@ -324,10 +289,7 @@ C12381_HDN void f12t_mul(fp4& w, const fp4& x, const fp4& y, const tri& t) {
 // trips to HBM per product (measured: 64.7 K cycles per call against 37.7 K of issue, profiles/r02_pair_routines_2waves.txt).
 // y is ALWAYS an object in the caller's private memory (a local of the exponentiation routines / the kernels): said explicitly — through the
 // generic reference the two reads of y are flat loads, whose every wait drains vmcnt AND lgkmcnt (the routine's LDS traffic with it)
-#ifndef C12381_EXPLICIT_AS
-#define C12381_EXPLICIT_AS 1                  // A/B: 0 = generic pointers (flat loads) as in round 3
-#endif
-#if defined(__HIP_DEVICE_COMPILE__) && C12381_EXPLICIT_AS
+#if defined(__HIP_DEVICE_COMPILE__)
 C12381_HD void fp4_load_private(fp4& r, const fp4* p) {
     typedef __attribute__((address_space(5))) const c12381_v4i priv_v4i;
     priv_v4i* q = (priv_v4i*)(const void*)p;
@@ -346,11 +308,7 @@ C12381_HDN void f12t_mul_h(fp4& H, const fp4& y, const tri& t) {
             fp4 x, yv, xn, yn;
             slot_load(x, H);
             fp4_load_private(yv, &y);
-#if C12381_SLOT_NEIGHBOUR
             slot_load_role(xn, H, tri_next(t), t);
-#else
-            tri_fetch_fp4(xn, x, tri_next(t), t);
-#endif
             tri_fetch_fp4(yn, yv, tri_next(t), t);
             fp4_addn(sx, x, xn); fp4_addn(sy, yv, yn);
         }
@@ -379,11 +337,9 @@ C12381_HDN void f12t_mul_h(fp4& H, const fp4& y, const tri& t) {
     slot_store(H, w);
 }
 // w = x^2 (FP12_sqr :190-238 as six squarings: z_r = x_r^2, (x_r + x_{r+1})^2).
-// C12381_SLOT_NEIGHBOUR (A/B, round 4): where the value whose neighbour coefficient is needed sits in the LDS slots, the neighbour's is
-// read straight from ITS slot (slot_load_role: 14 ds_read_b128) instead of being shuffled out of registers (56 ds_bpermute_b32)
-#ifndef C12381_SLOT_NEIGHBOUR
-#define C12381_SLOT_NEIGHBOUR 1
-#endif
+// Where the value whose neighbour coefficient is needed sits in the LDS slots, the neighbour's is read straight from ITS slot
+// (slot_load_role: 14 ds_read_b128) instead of being shuffled out of registers (56 ds_bpermute_b32) — measured as neutral, kept for the shorter
+// stream (profiles/r04_ab_slot_neighbour.txt).
 template <bool FROM_SLOT>
 C12381_HD void f12t_sqr_body_t(fp4& w, const fp4& x, const fp4& H, const tri& t) {
     fp4 xn, z, zc, zn, e, sx;
@@ -397,7 +353,7 @@ C12381_HD void f12t_sqr_body_t(fp4& w, const fp4& x, const fp4& H, const tri& t)
 }
 C12381_HD void f12t_sqr_body(fp4& w, const fp4& x, const tri& t) { f12t_sqr_body_t<false>(w, x, x, t); }
 C12381_HDN void f12t_sqr(fp4& w, const fp4& x, const tri& t) { fp4 xv = x, r; f12t_sqr_body(r, xv, t); w = r; }      // w may alias x
-C12381_HDN void f12t_sqr_h(fp4& H, const tri& t) { fp4 x, r; slot_load(x, H); f12t_sqr_body_t<C12381_SLOT_NEIGHBOUR != 0>(r, x, H, t); slot_store(H, r); }
+C12381_HDN void f12t_sqr_h(fp4& H, const tri& t) { fp4 x, r; slot_load(x, H); f12t_sqr_body_t<true>(r, x, H, t); slot_store(H, r); }
 // Granger-Scott unitary squaring (FP12_usqr :147-186): one Fp4 squaring per lane.
 //   w_a = 3 xa^2 - 2 conj(xa),  w_b = 3 s xc^2 + 2 conj(xb),  w_c = 3 xb^2 - 2 conj(xc)
 C12381_HD void f12t_usqr_tail(fp4& w, const fp4& q, const fp4& x, bool reduce, const tri& t) {
@@ -593,45 +549,6 @@ C12381_HDN void f12t_inv(fp4& w, const fp4& x, const tri& t) {
     fp4_inv(f3i, f3);
     fp4_mul_core(w, f, f3i);
 }
-#if C12381_INJ_LINE
-// f *= line(l0, l1, l2)  (sparse M-type line, see fp12_mul_line).  One dense-by-sparse product per lane:
-//   x <- x (l0 + l1 s) + (q' xi, q'' xi | q'' xi, q') with q0 = x.a l2, q1 = x.b l2 of the NEXT role — roles a, b add ((1+i) qn0, (1+i) qn1),
-//   role c adds ((1+i) qn1, qn0).
-// Everything that is added to the two coordinates of the Fp4 product is INJECTED into their reductions (fp2_mul_inj): the Karatsuba
-// corrections of the product itself (see fp4_mul_core) and the neighbour's terms with their (1 + i) — the result is normalised as it
-// leaves the reductions: no lazy sums, no carry round.  Role-dependent signs / zeros are multiplier registers.
-C12381_HD void f12t_mul_line_core(fp4& x, const fp2& l0, const fp2& l1, const fp2& l2, const tri& t) {
-    const int32_t c1 = fp_opaque_const(1), cm1 = fp_opaque_const(-1);
-    const bool r2 = t.role == 2;
-    fp2 q0, q1, qn0, qn1;
-    fp2_mul(q0, x.a, l2);
-    fp2_mul(q1, x.b, l2);
-    fp2 t2, sx, sy, wa, wb;
-    fp2_mul(t2, x.b, l1);
-    tri_fetch_fp2(qn0, q0, tri_next(t), t);
-    tri_fetch_fp2(qn1, q1, tri_next(t), t);
-    fp2 pick, other;
-    fp2_select(pick, r2, qn1, qn0);                        // enters .a times (1 + i)
-    fp2_select(other, r2, qn0, qn1);                       // enters .b times (1 + i) on roles a, b; as it is on role c
-    const int32_t o_cross = lane_opaque(r2 ? 0 : 1), o_ncross = lane_opaque(r2 ? 0 : -1);
-    // .a = x.a l0 + xi t2 + xi pick:   xi (a + b i) = (a - b) + (a + b) i
-    fp2_mul_inj(wa, x.a, l0, [&](int i, int64_t& acc) { fp_inj(acc, t2.a, i, c1); fp_inj(acc, t2.b, i, cm1); fp_inj(acc, pick.a, i, c1); fp_inj(acc, pick.b, i, cm1); },
-                [&](int i, int64_t& acc) { fp_inj(acc, t2.a, i, c1); fp_inj(acc, t2.b, i, c1); fp_inj(acc, pick.a, i, c1); fp_inj(acc, pick.b, i, c1); },
-                C12381_INJB(t2.a.vb + t2.b.vb + pick.a.vb + pick.b.vb, t2.a.lb + t2.b.lb + pick.a.lb + pick.b.lb),
-                C12381_INJB(t2.a.vb + t2.b.vb + pick.a.vb + pick.b.vb, t2.a.lb + t2.b.lb + pick.a.lb + pick.b.lb));
-    fp2_add(sx, x.a, x.b);
-    fp2_add(sy, l0, l1);
-    // .b = sx sy - x.a l0 - t2 + (other | xi other);   x.a l0 = wa - xi t2 - xi pick  =>  sx sy - wa + i t2 + xi pick + (other | xi other)
-    fp2_mul_inj(wb, sx, sy, [&](int i, int64_t& acc) { fp_inj(acc, wa.a, i, cm1); fp_inj(acc, t2.b, i, cm1); fp_inj(acc, pick.a, i, c1); fp_inj(acc, pick.b, i, cm1);
-                                                       fp_inj(acc, other.a, i, c1); fp_inj(acc, other.b, i, o_ncross); },
-                [&](int i, int64_t& acc) { fp_inj(acc, wa.b, i, cm1); fp_inj(acc, t2.a, i, c1); fp_inj(acc, pick.a, i, c1); fp_inj(acc, pick.b, i, c1);
-                                           fp_inj(acc, other.b, i, c1); fp_inj(acc, other.a, i, o_cross); },
-                // value: -wa + i t2 + xi pick = -(x.a l0 reduced) - t2 exactly; then the neighbour's term
-                C12381_INJB(wa.a.vb - t2.b.vb - pick.a.vb - pick.b.vb + other.a.vb + other.b.vb, wa.a.lb + t2.b.lb + pick.a.lb + pick.b.lb + other.a.lb + other.b.lb),
-                C12381_INJB(wa.b.vb - t2.a.vb - pick.a.vb - pick.b.vb + other.a.vb + other.b.vb, wa.b.lb + t2.a.lb + pick.a.lb + pick.b.lb + other.a.lb + other.b.lb));
-    x.a = wa; x.b = wb;
-}
-#else
 // f *= line(l0, l1, l2)  (sparse M-type line, see fp12_mul_line).  One dense-by-sparse product per lane.
 C12381_HD void f12t_mul_line_core(fp4& x, const fp2& l0, const fp2& l1, const fp2& l2, const tri& t) {
     fp4 la; la.a = l0; la.b = l1;
@@ -652,8 +569,6 @@ C12381_HD void f12t_mul_line_core(fp4& x, const fp2& l0, const fp2& l1, const fp
     fp2_add(p.b, p.b, ib);
     fp4_norm1(x, p);
 }
-#endif
-#if C12381_INJ_LINE1
 // the same for a line whose s-coefficient is 1 (l1 = 1: the lines of a fixed G2 argument are stored divided by it, see
 // miller_lines_precompute): x (l0 + s) = (xa l0 + (1+i) xb) + (xa + xb l0) s — two Fp2 products instead of Karatsuba's three.
 // x passes through UNMULTIPLIED ((1+i) xb in .a, xa in .b): its value bound would double per line, so each reduction also takes the
@@ -690,31 +605,6 @@ C12381_HD void f12t_mul_line1_core(fp4& x, const fp2& l0, const fp2& l2, const t
                 C12381_INJB(0.502, x.a.a.lb + other.a.lb + other.b.lb + 64.0 * 268435456.0), C12381_INJB(0.502, x.a.b.lb + other.a.lb + other.b.lb + 64.0 * 268435456.0));
     x.a = wa; x.b = wb;
 }
-#else
-// the same for a line whose s-coefficient is 1 (l1 = 1: the lines of a fixed G2 argument are stored divided by it, see
-// miller_lines_precompute): x (l0 + s) = (xa l0 + (1+i) xb) + (xa + xb l0) s — two Fp2 products instead of Karatsuba's three
-C12381_HD void f12t_mul_line1_core(fp4& x, const fp2& l0, const fp2& l2, const tri& t) {
-    fp4 p;
-    fp2 q0, q1, qn0, qn1, ia, ib, t1, t2, ix;
-    fp2_mul(q0, x.a, l2);
-    fp2_mul(q1, x.b, l2);
-    fp2_mul(t1, x.a, l0);
-    fp2_mul(t2, x.b, l0);
-    fp2_mul_ip(ix, x.b);
-    fp2_add(p.a, t1, ix);
-    fp2_add(p.b, x.a, t2);
-    tri_fetch_fp2(qn0, q0, tri_next(t), t);
-    tri_fetch_fp2(qn1, q1, tri_next(t), t);
-    fp2 pick;
-    fp2_select(pick, t.role == 2, qn1, qn0);
-    fp2_mul_ip(ia, pick);
-    fp2_mul_ip(ib, qn1);
-    fp2_select(ib, t.role == 2, qn0, ib);
-    fp2_add(p.a, p.a, ia);
-    fp2_add(p.b, p.b, ib);
-    fp4_weak_reduce(x, p);                                 // x passes through unmultiplied (xa, (1+i) xb): without a reduction its value bound would double per line
-}
-#endif
 C12381_HDN void f12t_mul_line(fp4& x, const fp2& l0, const fp2& l1, const fp2& l2, const tri& t) { f12t_mul_line_core(x, l0, l1, l2, t); }
 C12381_HDN void f12t_mul_line_h(fp4& H, const fp2& l0, const fp2& l1, const fp2& l2, const tri& t) {
     fp4 x;
@@ -989,11 +879,7 @@ C12381_HD void miller3_iter_body(fp2& tc, fp4& F, int info) {
         {
             fp4 x, xn, sx;
             slot_load(x, F);
-#if C12381_SLOT_NEIGHBOUR
             slot_load_role(xn, F, tri_next(t), t);
-#else
-            tri_fetch_fp4(xn, x, tri_next(t), t);
-#endif
             fp4_add(sx, x, xn);                            // limbs < 2^29 + slack: within the operand bound of the Fp2 products
             C12381_PHASE();
             fp4_sqr_core_raw(zc, sx);                           // un-normalised: zc only enters e, which gets its own carry round
@@ -1161,14 +1047,6 @@ C12381_HDN void miller3_range(fp4& F, fp2& tc, const fp& px, const fp& py, bool 
         fp_select(sel, t.role == 0, px, py);
         slot_psel_store(F, sel);
     }
-#if defined(C12381_MILLER_UNFUSED)      // A/B (round 5): squaring and doubling step + line as two out-of-line routines, as miller3_range2 runs them
-#pragma unroll 1
-    for (int i = hi; i >= lo; --i) {
-        C12381_FAIR_SHARE(i, F);
-        f12t_sqr_h(F, t);
-        miller3_pair_step(F, tc, px, py, skip, Q, i, t);
-    }
-#else
     const int info = t.role | (t.base << 2) | (skip ? 256 : 0);
     miller3_regs R = m3r_pack(tc, F, info);
 #pragma unroll 1
@@ -1183,7 +1061,6 @@ C12381_HDN void miller3_range(fp4& F, fp2& tc, const fp& px, const fp& py, bool 
         }
     }
     m3r_tc(tc, R);
-#endif
 }
 C12381_HDN void miller3_range2(fp4& F, fp2& tc1, const fp& px1, const fp& py1, bool skip1, const g2p& Q1,
                                fp2& tc2, const fp& px2, const fp& py2, bool skip2, const g2p& Q2, int hi, int lo, const tri& t) {

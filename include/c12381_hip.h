@@ -75,6 +75,11 @@ int c12381_sync(c12381_ctx* ctx);
  * No counterpart in the reference (its seam is synchronous host code, include/crypto12381/miracl_core_interface.hpp:186-204). */
 int c12381_wait_event(c12381_ctx* ctx, void* hip_event);
 int c12381_record_event(c12381_ctx* ctx, void* hip_event);
+/* Device workspaces grow to the largest call a context has served and are kept for the next one (a 2^20 G1 batch: 2.95 GB of window tables;
+ * a GT power of 2^16 elements: 1.4 GB of power tables; 2^18 BBS+ verifications: a 172 MB state slab).  c12381_trim waits for the context's
+ * streams and frees all of them; cached fixed-base / line tables are rebuilt by the next call that needs them.  (The reference's seam never
+ * allocates: src/miracl_core_interface.cpp works on caller-owned PODs.) */
+int c12381_trim(c12381_ctx* ctx);
 /* Per-kernel timing with HIP events on the context's stream (used by bench.py for the roofline
  * figure).  enable != 0 starts a fresh recording; kind: 0 = G1 scalar-mul kernel, 1 = G1 finish
  * (inversion + encode) kernel, 2 = G2 scalar-mul kernel, 3 = pairing kernel, 4 = pairing-equality kernel, 5 = MSM bucket kernel,

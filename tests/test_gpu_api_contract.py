@@ -150,6 +150,32 @@ def test_stream_ordering_through_events():
         c.close()
 
 
+def test_trim_releases_the_workspaces_and_the_next_call_rebuilds_them():
+    """c12381_trim (include/c12381_hip.h): workspaces and cached tables go, results stay the same afterwards"""
+    import torch
+    from crypto12381_amd import Context
+    g, gp = golden("g1"), golden("pairing")
+    pts, sc = cat(g["points"]), cat(g["scalars"])
+    c = Context(0)
+    try:
+        gen = bytes.fromhex(g["generator"])
+        fixed = c.g1_mul_fixed(gen, sc, 49)                                       # builds a cached fixed-base table
+        assert c.g1_mul(pts, sc, 49) == cat(g["mul49"])
+        k = len(gp["gt_pow_exp"])
+        pw = c.gt_op("pow", cat(gp["gt"])[:576 * k], cat(gp["gt_pow_exp"]))
+        assert pw == cat(gp["gt_pow"])
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info(0)[0]
+        c.trim()
+        assert torch.cuda.mem_get_info(0)[0] >= free_before                      # nothing is held back
+        assert c.g1_mul_fixed(gen, sc, 49) == fixed
+        assert c.g1_mul(pts, sc, 49) == cat(g["mul49"])
+        assert c.gt_op("pow", cat(gp["gt"])[:576 * k], cat(gp["gt_pow_exp"])) == pw
+        assert c.g1_msm(pts, sc, 49).hex() == g["msm49"]
+    finally:
+        c.close()
+
+
 def test_contexts_are_independent(ctx):
     from crypto12381_amd import Context
     g = golden("g1")

@@ -178,8 +178,9 @@ def test_gt_ops_and_split_pairing(ctx, oracle_port):
 
 def test_gt_power_routes(ctx, oracle_port):
     """gt3_op_kernel takes the 4-bit windowed ladder for a wavefront (21 elements) whose bases are all in the cyclotomic subgroup and the
-    reference's own digit sequence otherwise: wavefronts of either kind and mixed ones in one batch, zero bases, edge exponents, and a batch
-    longer than one launch of the power (4096 wavefronts = 86 016 elements) — every element against the oracle."""
+    reference's own digit sequence otherwise: wavefronts of either kind and mixed ones in one batch, zero bases, edge exponents — every element
+    against the oracle; then the same mixture as a batch of 4097 groups, which takes gt3_pow_queue_kernel (more than one machine round:
+    whole groups on the grid's wavefronts, the rest as five queued tasks per group), both ladders in queued and in whole groups."""
     g = golden("pairing")
     gt = cat(g["gt"])
     ng = len(gt) // 576
@@ -197,7 +198,7 @@ def test_gt_power_routes(ctx, oracle_port):
     e = b"".join(int(v).to_bytes(32, "big") for v in exps)
     want = oracle_port.gt_op("pow", a, e)
     assert ctx.gt_op("pow", a, e) == want
-    big = 4096 * 21 + 100                                  # the second launch starts at element 86 016
+    big = 4096 * 21 + 100                                  # 4097 groups: 2048 of them whole, the others through the queue
     reps = big // 63 + 1
     got = ctx.gt_op("pow", (a * reps)[:576 * big], (e * reps)[:32 * big])
     assert got == (want * reps)[:576 * big]

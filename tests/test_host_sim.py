@@ -267,29 +267,6 @@ def test_sim_pairing_three_lanes(sim):
     assert list(ok.raw[:m]) == g["eq2"]
 
 
-def test_sim_injection_forms_other_than_the_defaults():
-    """The round-4 'injected reduction' forms that are switched OFF by measurement (Fp4 product / squaring, generic line product:
-    pairing3.hpp, fp12.hpp) and the lazy forms of the ones that are ON (line against a normalised table entry, G1 formulas) stay in the
-    tree as A/B variants (tools/build_variant.sh -DC12381_INJ_x=0|1): both settings of every switch run the three-lane pairing, the
-    two-table product and the bucket MSM under the bounds checker against the golden vectors."""
-    g = golden("pairing")
-    g1, g2 = cat(g["g1"])[:96 * 6], cat(g["g2"])[:192 * 6]
-    gg = golden("g1")
-    pts, sc = cat(gg["points"]), cat(gg["scalars"])
-    for name, flags in (("all_on", ["-DC12381_INJ_SQR=1", "-DC12381_INJ_MUL=1", "-DC12381_INJ_LINE=1", "-DC12381_INJ_LINE1=1", "-DC12381_INJ_G1=1"]),
-                        ("all_off", ["-DC12381_INJ_SQR=0", "-DC12381_INJ_MUL=0", "-DC12381_INJ_LINE=0", "-DC12381_INJ_LINE1=0", "-DC12381_INJ_G1=0"])):
-        so = os.path.join(SIM_DIR, "libsim_%s.so" % name)
-        srcs = [os.path.join(SIM_DIR, "sim.cpp")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
-        if not os.path.exists(so) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in srcs):
-            subprocess.run(["g++", "-O1", "-std=c++17", "-DC12381_CHECK_BOUNDS", *flags, "-fPIC", "-shared", "-pthread", "-o", so, os.path.join(SIM_DIR, "sim.cpp")],
-                           check=True)
-        lib = ctypes.CDLL(so)
-        out = ctypes.create_string_buffer(576 * 6)
-        assert lib.sim_pair3_batch(sz(6), g1, g2, out) == 0 and out.raw == cat(g["gt"])[:576 * 6], name
-        o49 = ctypes.create_string_buffer(49)
-        assert lib.sim_g1_msm_pippenger(sz(len(pts) // 96), pts, sc, o49, 49, 7) == 0 and o49.raw.hex() == gg["msm49"], name
-
-
 def test_sim_msm_pippenger(sim, oracle_port):
     """Bucket-method MSM of msm.hpp (device routines run sequentially, std::stable_sort instead of hipCUB)."""
     g = golden("g1")

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Build an alternative libc12381_hip.so with extra compile flags into crypto12381_amd/lib/exp/lib<name>.so (A/B runs: C12381_LIB).
-# usage: bash tools/build_variant.sh <name> <extra flags...>      e.g.  bash tools/build_variant.sh occ3 -DC12381_G1_OCC=3
+# usage: bash tools/build_variant.sh <name> <extra flags...>      e.g.  bash tools/build_variant.sh dflt BASEFLAGS=... (the compile-time A/B knobs of
+# rounds 2-4 are gone from the sources with their losing arms: a variant is a working-tree edit built under another name, or other compiler flags)
 # (add -DC12381_EXPERIMENTS for a variant that also reads the C12381_* tuning variables; BASEFLAGS="..." in the environment replaces the
 # product's base flags, e.g. to drop the max-ilp scheduling strategy)
 set -e

@@ -32,10 +32,11 @@ def stats(label, run):
     xcc = (w[:, 7] >> np.uint64(32)).astype(np.int64) & 0xf
     wave_id, simd, cu, sh, se = hwid & 0xf, (hwid >> 4) & 3, (hwid >> 8) & 0xf, (hwid >> 12) & 1, (hwid >> 13) & 7
     simd_key = ((((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd)
-    # s_memtime is a counter of the XCD the wavefront runs on (the eight XCDs are not synchronised): every time is taken relative to the first
-    # entry seen on the same XCD, the span is the longest of the eight
-    for x in np.unique(xcc):
-        m = xcc == x
+    # s_memtime is not one clock for the chip (the stamps of different CUs lie up to tens of ms apart): every time is taken relative to the first
+    # entry seen on the SAME CU (its eight wavefronts start within microseconds of the launch), the span is the longest CU's
+    cu_key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+    for k in np.unique(cu_key):
+        m = cu_key == k
         base = entry[m].min()
         entry[m] -= base; exit_[m] -= base
     t0, t1 = 0.0, exit_.max()
