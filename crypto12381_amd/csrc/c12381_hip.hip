@@ -67,7 +67,7 @@ struct c12381_ctx {
     std::vector<hipEvent_t> sort_events;
     char err[256] = {0};
     enum { WS_TAB, WS_PROJ, WS_PREF, WS_IN0, WS_IN1, WS_OUT, WS_RED0, WS_RED1, WS_BBS_Q, WS_BBS_B, WS_BBS_IN, WS_BBS_WIRE, WS_BBS_WIRE_IN,
-           WS_PAIR_ST, WS_FQ_W, WS_FQ_G, WS_FQ_GATE, WS_FQ_P, WS_FB_G2, WS_FB_G1_0, WS_FB_G1_1, WS_FB_G1_2, WS_FB_G1_3, WS_MSM_PTS, WS_MSM_K0, WS_MSM_K1, WS_MSM_V0, WS_MSM_V1, WS_MSM_TMP, WS_MSM_RNG, WS_MSM_BK, WS_MSM_ORD, WS_MSM_OVF, WS_DEC1, WS_DEC2, WS_GT_POW, WS_COUNT };
+           WS_PAIR_ST, WS_POW_ST, WS_FQ_W, WS_FQ_G, WS_FQ_GATE, WS_FQ_P, WS_FB_G2, WS_FB_G1_0, WS_FB_G1_1, WS_FB_G1_2, WS_FB_G1_3, WS_MSM_PTS, WS_MSM_K0, WS_MSM_K1, WS_MSM_V0, WS_MSM_V1, WS_MSM_TMP, WS_MSM_RNG, WS_MSM_BK, WS_MSM_ORD, WS_MSM_OVF, WS_DEC1, WS_DEC2, WS_GT_POW, WS_COUNT };
     void* ws[WS_COUNT] = {nullptr};
     size_t ws_bytes[WS_COUNT] = {0};
     int* d_flag = nullptr;
@@ -79,9 +79,11 @@ struct c12381_ctx {
     // diagnostic (experiments builds, C12381_PAIR_STAMPS): per-task time stamps of the last queue pairing launch, on this context's device
     unsigned long long* stamps = nullptr;
     size_t stamps_tasks = 0;
-    // ... followed by 8 words per wavefront of the grid (k_pair3.hip queue_wave_stats) for the last queue launch of pairings, Miller loops or
+    // ... followed by 12 words per wavefront of the grid (k_pair3.hip queue_wave_stats) for the last queue launch of pairings, Miller loops or
     // final exponentiations; c12381_sync() writes both regions to the file
     static constexpr size_t STAMP_WAVES = 4096;
+    // launch counter of the work-queue kernels whose state travels in tagged words (k_pair3.hip stw_store): 28 bits, never 0
+    uint32_t queue_epoch = 0;
 };
 
 namespace {
@@ -888,10 +890,10 @@ static unsigned long long* pair_stamps(c12381_ctx* c, size_t n) {
     if (c->stamps_tasks < tasks) {
         (void)hipStreamSynchronize(c->stream);              // a kernel of this context may still be writing the old buffer
         if (c->stamps) (void)hipFree(c->stamps);
-        if (hipMalloc((void**)&c->stamps, tasks * 32 + c12381_ctx::STAMP_WAVES * 64) != hipSuccess) { c->stamps = nullptr; c->stamps_tasks = 0; return nullptr; }
+        if (hipMalloc((void**)&c->stamps, tasks * 32 + c12381_ctx::STAMP_WAVES * 96) != hipSuccess) { c->stamps = nullptr; c->stamps_tasks = 0; return nullptr; }
         c->stamps_tasks = tasks;
     }
-    (void)hipMemsetAsync(c->stamps, 0, c->stamps_tasks * 32 + c12381_ctx::STAMP_WAVES * 64, c->stream);
+    (void)hipMemsetAsync(c->stamps, 0, c->stamps_tasks * 32 + c12381_ctx::STAMP_WAVES * 96, c->stream);
     return c->stamps;
 }
 // the per-wavefront region behind the per-task stamps (null when the diagnostic is off)
@@ -901,7 +903,7 @@ static unsigned long long* pair_wave_stats(c12381_ctx* c, size_t n) {
 }
 static void pair_stamps_dump(c12381_ctx* c) {
     if (!pair_stamps_path() || !c->stamps) return;
-    std::vector<unsigned long long> h(c->stamps_tasks * 4 + c12381_ctx::STAMP_WAVES * 8);
+    std::vector<unsigned long long> h(c->stamps_tasks * 4 + c12381_ctx::STAMP_WAVES * 12);
     if (hipMemcpy(h.data(), c->stamps, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
     if (FILE* f = std::fopen(pair_stamps_path(), "wb")) { std::fwrite(h.data(), 8, h.size(), f); std::fclose(f); }
 }
@@ -919,18 +921,32 @@ static size_t queue_direct_groups_host(size_t ngroups, size_t nwaves) {
     if (g_queue_groups_host > 0) queued = (size_t)g_queue_groups_host < ngroups ? (size_t)g_queue_groups_host : ngroups;
     return ngroups - queued;
 }
-// state slab: [flags: one word per group][task counter][whole-group counter][pad to 256 B][42 x 1 KiB per QUEUED group] — whole
-// groups keep their state in registers and the LDS slot; 2^18 BBS+ verifications: 4096 blocks (172 MB) instead of 12484 (0.5 GB)
-static int pair_queue_setup(c12381_ctx* c, size_t n, uint4*& state, unsigned int*& flags, unsigned int*& counter, unsigned& blocks) {
+// state slab: [flags: one word per group][task counter][whole-group counter][pad to 256 B][one block per QUEUED group] — whole
+// groups keep their state in registers and the LDS slot; 2^18 BBS+ verifications: 4096 blocks (344 MB) instead of 12484 (1.0 GB).
+// tagged (every kernel but the GT power): blocks of PAIR_QUEUE_STATE_BYTES in 8-byte tagged words, `epoch` = this launch's tag base.  The slab
+// then only ever holds tagged words or zeros (zeroed when it is allocated and when the 28-bit epoch wraps), so a word of an earlier launch —
+// at whatever offset that launch's group count put it — can never carry the tag of this one.  The GT power keeps the fenced 16-byte rows in a
+// slab of its own.
+static int pair_queue_setup(c12381_ctx* c, size_t n, uint4*& state, unsigned int*& flags, unsigned int*& counter, unsigned& blocks, unsigned int* epoch = nullptr) {
     const size_t groups = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE;
     const size_t head = round_up((groups + 2) * 4, 256);          // flags | task counter | whole-group counter
     const size_t waves = groups < PAIR_QUEUE_WAVES ? groups : PAIR_QUEUE_WAVES;
     blocks = (unsigned)((waves * 64 + BLOCK - 1) / BLOCK);
     const size_t nwaves = (size_t)blocks * (BLOCK / 64);
     const size_t nq = groups - queue_direct_groups_host(groups, nwaves);
+    const bool tagged = epoch != nullptr;
+    const int slot = tagged ? c12381_ctx::WS_PAIR_ST : c12381_ctx::WS_POW_ST;
+    const size_t bytes = head + nq * (tagged ? PAIR_QUEUE_STATE_BYTES : (size_t)PAIR_QUEUE_STATE_ROWS * 1024);
     int rc;
-    if ((rc = ensure(c, c12381_ctx::WS_PAIR_ST, head + nq * (size_t)PAIR_QUEUE_STATE_ROWS * 1024))) return rc;
-    uint8_t* base = (uint8_t*)c->ws[c12381_ctx::WS_PAIR_ST];
+    bool fresh = c->ws_bytes[slot] < bytes;
+    if ((rc = ensure(c, slot, bytes))) return rc;
+    if (tagged) {
+        c->queue_epoch = (c->queue_epoch + 1u) & 0x0fffffffu;
+        if (c->queue_epoch == 0) { c->queue_epoch = 1; fresh = true; }
+        if (fresh) HIPCK(c, hipMemsetAsync(c->ws[slot], 0, c->ws_bytes[slot], c->stream));
+        *epoch = c->queue_epoch;
+    }
+    uint8_t* base = (uint8_t*)c->ws[slot];
     flags = (unsigned int*)base;
     counter = flags + groups;
     state = (uint4*)(base + head);
@@ -942,10 +958,10 @@ static int launch_pair(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8_t
     if (pair_lanes() == 1) { hipLaunchKernelGGL(pair_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag); HIPCK(c, hipGetLastError()); return 0; }
 #endif
     if (pair_use_queue(n)) {
-        uint4* st; unsigned int *fl, *ct; unsigned blocks; int rc;
-        if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
+        uint4* st; unsigned int *fl, *ct, ep; unsigned blocks; int rc;
+        if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks, &ep))) return rc;
         unsigned long long* const stp = pair_stamps(c, n);
-        hipLaunchKernelGGL(pair3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag, st, fl, ct, pair_spin_limit(), stp, stp ? stp + c->stamps_tasks * 4 : nullptr);
+        hipLaunchKernelGGL(pair3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag, st, fl, ct, pair_spin_limit(), ep, stp, stp ? stp + c->stamps_tasks * 4 : nullptr);
     } else hipLaunchKernelGGL(pair3_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag);
     HIPCK(c, hipGetLastError());
     return 0;
@@ -956,9 +972,9 @@ static int launch_pair_eq(c12381_ctx* c, size_t n, const uint8_t* a1, const uint
     if (pair_lanes() == 1) { hipLaunchKernelGGL(pair_eq_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, a1, a2, b1, b2, b2_stride, ok, c->d_flag); HIPCK(c, hipGetLastError()); return 0; }
 #endif
     if (pair_use_queue(n)) {
-        uint4* st; unsigned int *fl, *ct; unsigned blocks; int rc;
-        if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
-        hipLaunchKernelGGL(pair3_eq_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, a1, a2, b1, b2, b2_stride, ok, c->d_flag, st, fl, ct, skip_if, pair_spin_limit());
+        uint4* st; unsigned int *fl, *ct, ep; unsigned blocks; int rc;
+        if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks, &ep))) return rc;
+        hipLaunchKernelGGL(pair3_eq_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, a1, a2, b1, b2, b2_stride, ok, c->d_flag, st, fl, ct, skip_if, pair_spin_limit(), ep);
     } else hipLaunchKernelGGL(pair3_eq_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, a1, a2, b1, b2, b2_stride, ok, c->d_flag, skip_if);
     HIPCK(c, hipGetLastError());
     return 0;
@@ -968,11 +984,11 @@ int c12381_pair_batch_dev(c12381_ctx* c, size_t n, const uint8_t* g1, const uint
     if (!g1 || !g2 || !gt) return C12381_E_ARG;
     if (n == 0) return 0;
     if (pair_lanes() != 1 && pair_use_queue(n)) {            // workspace and its reset stay outside the timed bracket
-        uint4* st; unsigned int *fl, *ct; unsigned blocks;
-        if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
+        uint4* st; unsigned int *fl, *ct, ep; unsigned blocks;
+        if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks, &ep))) return rc;
         timed tm(c, 3);
         unsigned long long* const stp = pair_stamps(c, n);
-        hipLaunchKernelGGL(pair3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag, st, fl, ct, pair_spin_limit(), stp, stp ? stp + c->stamps_tasks * 4 : nullptr);
+        hipLaunchKernelGGL(pair3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, g1, g2, gt, c->d_flag, st, fl, ct, pair_spin_limit(), ep, stp, stp ? stp + c->stamps_tasks * 4 : nullptr);
         HIPCK(c, hipGetLastError());
         return 0;
     }
@@ -1037,10 +1053,11 @@ int c12381_pair_fixed_g2_batch_dev(c12381_ctx* c, size_t n, const uint8_t* g1, c
     if (n == 0) return 0;
     if ((rc = lines_table(c, c12381_ctx::WS_FQ_P, g2_192, 0))) return rc;
     uint4* st; unsigned int *fl, *ct; unsigned blocks;
-    if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
+    unsigned int ep;
+    if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks, &ep))) return rc;
     timed tm(c, 3);
     hipLaunchKernelGGL(pair3_fixed_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, g1, (const int32_t*)c->ws[c12381_ctx::WS_FQ_P], gt, c->d_flag,
-                       st, fl, ct, pair_spin_limit());
+                       st, fl, ct, pair_spin_limit(), ep);
     HIPCK(c, hipGetLastError());
     return 0;
 }
@@ -1247,9 +1264,9 @@ static int launch_miller(c12381_ctx* c, size_t n, const uint8_t* g1, const uint8
     if (pair_lanes() == 1) { hipLaunchKernelGGL(miller_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, n, g1, g2, out, c->d_flag); HIPCK(c, hipGetLastError()); return 0; }
 #endif
     if (pair_use_queue(n)) {              // more than one machine round of wavefront tasks: quarter-loop tasks from the work queue
-        uint4* st; unsigned int *fl, *ct; unsigned blocks; int rc;
-        if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
-        hipLaunchKernelGGL(miller3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, g1, g2, out, c->d_flag, st, fl, ct, pair_spin_limit(), pair_wave_stats(c, n));
+        uint4* st; unsigned int *fl, *ct, ep; unsigned blocks; int rc;
+        if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks, &ep))) return rc;
+        hipLaunchKernelGGL(miller3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, g1, g2, out, c->d_flag, st, fl, ct, pair_spin_limit(), ep, pair_wave_stats(c, n));
     } else hipLaunchKernelGGL(miller3_kernel, dim3(grid_tri(n)), dim3(BLOCK), 0, c->stream, n, g1, g2, out, c->d_flag);
     HIPCK(c, hipGetLastError());
     return 0;
@@ -1259,9 +1276,9 @@ static int launch_gt_op(c12381_ctx* c, int op, size_t n, const uint8_t* a, const
     if (pair_lanes() == 1) { hipLaunchKernelGGL(gt_op_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, op, n, a, b, out); HIPCK(c, hipGetLastError()); return 0; }
 #endif
     if (op == 3 && pair_use_queue(n)) {   // final exponentiations alone, more than one machine round: its six steps as queue tasks
-        uint4* st; unsigned int *fl, *ct; unsigned blocks; int rc;
-        if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
-        hipLaunchKernelGGL(fexp3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, a, out, c->d_flag, st, fl, ct, pair_spin_limit(), pair_wave_stats(c, n));
+        uint4* st; unsigned int *fl, *ct, ep; unsigned blocks; int rc;
+        if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks, &ep))) return rc;
+        hipLaunchKernelGGL(fexp3_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, a, out, c->d_flag, st, fl, ct, pair_spin_limit(), ep, pair_wave_stats(c, n));
     } else if (op == 2 && pair_use_queue(n)) {
         // the power, more than one machine round: five tasks per queued group (k_pair3.hip gt3_pow_queue_kernel); one table per wavefront of the
         // grid and one per queued group (at most 2048 + 4096 tables of 224 KB)
@@ -1539,11 +1556,11 @@ int c12381_bbs_plus_verify_batch_dev(c12381_ctx* c, size_t n, size_t nmsg, const
     if ((rc = g1_finish(c, n, red, rstride, d_b, 96))) return rc;
     timed tm(c, 4);
     if (fq) {
-        uint4* st; unsigned int *fl, *ct; unsigned blocks;
-        if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks))) return rc;
+        uint4* st; unsigned int *fl, *ct, ep; unsigned blocks;
+        if ((rc = pair_queue_setup(c, n, st, fl, ct, blocks, &ep))) return rc;
         hipLaunchKernelGGL(pair3_prod_fixed_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, n, A_96, d_b,
                            (const int32_t*)c->ws[c12381_ctx::WS_FQ_W] + FB_HEADER_DWORDS, (const int32_t*)c->ws[c12381_ctx::WS_FQ_G] + FB_HEADER_DWORDS, ok,
-                           c->d_flag, st, fl, ct, gate_generic, pair_spin_limit());
+                           c->d_flag, st, fl, ct, gate_generic, pair_spin_limit(), ep);
         HIPCK(c, hipGetLastError());
     }
     return launch_pair_eq(c, n, A_96, d_q, d_b, g2_192, (size_t)0, ok, gate_generic);
@@ -1695,11 +1712,11 @@ int c12381_bbs_plus_verify_aggregate_dev(c12381_ctx* c, size_t n, size_t nmsg, c
     if (nmsg) HIPCK(c, hipMemcpyAsync(pts + 96 * (n + 2), h_96, 96 * nmsg, hipMemcpyDeviceToDevice, c->stream));
     if ((rc = c12381_g1_msm_dev(c, n, A_96, rho_32, p1, 96))) return rc;
     if ((rc = c12381_g1_msm_dev(c, terms, pts, sc, p2, 96))) return rc;
-    uint4* st; unsigned int *fl, *ct; unsigned blocks;
-    if ((rc = pair_queue_setup(c, 1, st, fl, ct, blocks))) return rc;
+    uint4* st; unsigned int *fl, *ct, ep; unsigned blocks;
+    if ((rc = pair_queue_setup(c, 1, st, fl, ct, blocks, &ep))) return rc;
     hipLaunchKernelGGL(pair3_prod_fixed_queue_kernel, dim3(blocks), dim3(BLOCK), 0, c->stream, (size_t)1, (const uint8_t*)p1, (const uint8_t*)p2,
                        (const int32_t*)c->ws[c12381_ctx::WS_FQ_W] + FB_HEADER_DWORDS, (const int32_t*)c->ws[c12381_ctx::WS_FQ_G] + FB_HEADER_DWORDS, all_ok,
-                       c->d_flag, st, fl, ct, (const int32_t*)gate, pair_spin_limit());
+                       c->d_flag, st, fl, ct, (const int32_t*)gate, pair_spin_limit(), ep);
     HIPCK(c, hipGetLastError());
     return 0;
 }

@@ -91,6 +91,47 @@ __device__ __forceinline__ void st_load(T& x, const uint4* rows, unsigned lane) 
     for (int r = 0; r < ROWS; ++r) { const uint4 v = rows[(size_t)r * 64 + lane]; w[4 * r] = (int32_t)v.x; w[4 * r + 1] = (int32_t)v.y; w[4 * r + 2] = (int32_t)v.z; w[4 * r + 3] = (int32_t)v.w; }
 }
 
+// ---- the same state WITHOUT cache maintenance (round 5): every 32-bit word travels in an 8-byte word together with a 32-bit tag — launch epoch and
+// the phase that wrote it — as one relaxed agent-scope atomic store (global_store_dwordx2 sc1: write-through, coherent across the eight XCDs' L2s for
+// that location), and is read by a relaxed agent-scope atomic load (sc1); a reader that sees another tag in ANY word reads again.  Single-copy atomicity
+// of an aligned 8-byte access is all this needs: no release / acquire pair, i.e. none of the buffer_wbl2 sc1 / buffer_inv sc1 the fences of the
+// 16-byte form cost per task — a write-back and an invalidation of the whole XCD's L2 under 256 resident wavefronts whose spills and private
+// operands live there (measured with the fences simply left out — WRONG results, timing only — tasks 5-7 % shorter and the whole groups running
+// beside them 2-3 %: profiles/r05_ab_fence_free_handover.txt).  The price is twice the bytes of a state that is 1 KB per lane and task.
+// Rows of 64 lanes x 8 bytes; one row per 32-bit word of the value.
+constexpr int ST_DW_F = 56, ST_DW_TC = 28;                    // 32-bit words of an Fp4 / Fp2
+constexpr int STW_F = 0, STW_TC1 = ST_DW_F, STW_TC2 = STW_TC1 + ST_DW_TC, STW_Y1 = STW_TC2 + ST_DW_TC, STW_ROWS = STW_Y1 + ST_DW_F;      // 168 rows of 512 bytes
+static_assert((size_t)STW_ROWS * 512 == PAIR_QUEUE_STATE_BYTES, "kernels.hpp: size of a queued group's state block");
+__device__ __forceinline__ uint32_t st_tag(uint32_t epoch, unsigned int writer_phase) { return (epoch << 4) | (writer_phase + 1u); }
+template <class T, int DW>
+__device__ __forceinline__ void stw_store(unsigned long long* rows, unsigned lane, const T& x, uint32_t tag) {
+    static_assert(sizeof(T) == DW * 4, "state word count");
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(&x);
+#pragma unroll
+    for (int r = 0; r < DW; ++r)
+        __hip_atomic_store(&rows[(size_t)r * 64 + lane], ((unsigned long long)tag << 32) | w[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// false: some word still carried another tag after spin_limit re-reads (the writer never finished): the caller poisons the group
+template <class T, int DW>
+__device__ __forceinline__ bool stw_load(T& x, const unsigned long long* rows, unsigned lane, uint32_t tag, int spin_limit, unsigned int* reread = nullptr) {
+    static_assert(sizeof(T) == DW * 4, "state word count");
+    uint32_t* w = reinterpret_cast<uint32_t*>(&x);
+    int spins = 0;
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int r = 0; r < DW; ++r) {
+            const unsigned long long v = __hip_atomic_load(&rows[(size_t)r * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            w[r] = (uint32_t)v;
+            ok = ok && (uint32_t)(v >> 32) == tag;
+        }
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0) return true;           // wave-uniform
+        if (reread) ++*reread;
+        if (spin_limit < 0 || ++spins > spin_limit) return false;
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
+
 // ---- hand-over protocol of the work queue.  flags[g] = number of finished phases of group g, bit 31 = the group is
 // POISONED: a wavefront gave up waiting for its predecessor (bounded spin), so the group's state is not to be trusted.
 // A poisoned task skips its arithmetic and passes the mark on (successors then start at once instead of spinning
@@ -114,6 +155,23 @@ __device__ __forceinline__ void queue_publish(unsigned int* flags, size_t g, uns
     __threadfence();
     if (lane == 0) __hip_atomic_fetch_max(&flags[g], (poisoned ? Q_POISON : 0u) | (p + 1u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
+// The forms for state that travels in tagged words (stw_store / stw_load): the flag only says "worth looking" and carries the poison mark, the data
+// validates itself — relaxed accesses, no cache maintenance.  (s_waitcnt: the flag is not raised before the stores have left the wavefront.)
+__device__ __forceinline__ bool queue_wait_rlx(unsigned int* flags, size_t g, unsigned int p, int spin_limit) {
+    if (p == 0) return false;
+    int spins = 0;
+    for (;;) {
+        const unsigned int v = (unsigned int)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&flags[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (spin_limit < 0 || (v & Q_POISON)) return true;
+        if (v >= p) return false;
+        if (++spins > spin_limit) return true;
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
+__device__ __forceinline__ void queue_publish_rlx(unsigned int* flags, size_t g, unsigned int p, bool poisoned, unsigned lane) {
+    __builtin_amdgcn_s_waitcnt(0);
+    if (lane == 0) __hip_atomic_fetch_max(&flags[g], (poisoned ? Q_POISON : 0u) | (p + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void gt_poison(uint8_t* o576, int role) {
     uint4* q = reinterpret_cast<uint4*>(o576 + (role == 0 ? 384 : (role == 1 ? 192 : 0)));
 #pragma unroll
@@ -122,21 +180,25 @@ __device__ __forceinline__ void gt_poison(uint8_t* o576, int role) {
 
 // Diagnostic (experiments runs, C12381_PAIR_STAMPS): what ONE wavefront of a queue kernel spent its launch on, in shader-clock cycles
 // (s_memtime) — whole groups, queue tasks from start to publish (state loads and stores included), hand-over waits (claim to start) —
-// written once at exit as 8 words per wavefront (tools/queue_wave_stats.py).  Everything is wave-uniform (SGPRs); null pointer = off.
+// written once at exit as 12 words per wavefront (tools/queue_wave_stats.py).  Everything is wave-uniform (SGPRs); null pointer = off.
+// Inside a task: loaded() after the state has arrived (the tag comparison has consumed it), computed() before the state is stored.
 struct queue_wave_stats {
     unsigned long long* out;
-    unsigned long long t_entry = 0, whole = 0, task = 0, wait = 0, t0 = 0;
-    unsigned int n_whole = 0, n_task = 0;
+    unsigned long long t_entry = 0, whole = 0, task = 0, wait = 0, t0 = 0, t1 = 0, load = 0, store = 0;
+    unsigned int n_whole = 0, n_task = 0, reread = 0;
     __device__ __forceinline__ explicit queue_wave_stats(unsigned long long* wstats) : out(wstats) { if (out) t_entry = __builtin_amdgcn_s_memtime(); }
     __device__ __forceinline__ void mark() { if (out) t0 = __builtin_amdgcn_s_memtime(); }
     __device__ __forceinline__ void whole_done() { if (out) { whole += __builtin_amdgcn_s_memtime() - t0; ++n_whole; } }
-    __device__ __forceinline__ void wait_done() { if (out) { const unsigned long long t = __builtin_amdgcn_s_memtime(); wait += t - t0; t0 = t; } }
-    __device__ __forceinline__ void task_done() { if (out) { task += __builtin_amdgcn_s_memtime() - t0; ++n_task; } }
+    __device__ __forceinline__ void wait_done() { if (out) { const unsigned long long t = __builtin_amdgcn_s_memtime(); wait += t - t0; t0 = t; t1 = t; } }
+    __device__ __forceinline__ void loaded() { if (out) { const unsigned long long t = __builtin_amdgcn_s_memtime(); load += t - t1; t1 = t; } }
+    __device__ __forceinline__ void computed() { if (out) t1 = __builtin_amdgcn_s_memtime(); }
+    __device__ __forceinline__ void task_done() { if (out) { const unsigned long long t = __builtin_amdgcn_s_memtime(); task += t - t0; store += t - t1; ++n_task; } }
     __device__ __forceinline__ void finish() {
         if (!out || (threadIdx.x & 63u) != 0) return;
-        unsigned long long* o = out + 8 * (((size_t)blockIdx.x * BLOCK + threadIdx.x) >> 6);
+        unsigned long long* o = out + 12 * (((size_t)blockIdx.x * BLOCK + threadIdx.x) >> 6);
         o[0] = t_entry; o[1] = __builtin_amdgcn_s_memtime(); o[2] = whole; o[3] = n_whole; o[4] = task; o[5] = n_task; o[6] = wait;
         o[7] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);      // HW_ID | XCC_ID
+        o[8] = load; o[9] = store; o[10] = reread;
     }
 };
 
@@ -250,9 +312,10 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_prod_kernel(size_t n, int k, c
 // (queue_wait above: a time-out poisons the group instead of letting it run on stale state).
 template <bool EQ>
 __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, size_t b2_stride,
-                                                 uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit, fp4& H,
-                                                 unsigned long long* stamps = nullptr, unsigned long long* wstats = nullptr) {
+                                                 uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit, uint32_t epoch,
+                                                 fp4& H, unsigned long long* stamps = nullptr, unsigned long long* wstats = nullptr) {
     queue_wave_stats ws(wstats);
+    unsigned long long* const stw = reinterpret_cast<unsigned long long*>(state);
     const unsigned lane = threadIdx.x & 63u;
     const unsigned trip = lane / 3u;
     tri t;
@@ -260,7 +323,6 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
     t.base = lane == 63u ? 63 : (int)(3u * trip);
     const size_t ngroups = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE;
     constexpr unsigned int MILLER_TASKS = MILLER_TASKS_PER_GROUP, TASKS = MILLER_TASKS + 6;
-    constexpr int ROWS = ST_Y1 + ST_ROWS_F;
     // Hybrid schedule.  Wavefronts first claim WHOLE groups (counter[1]: no hand-over, no wait on a slower partner, the state stays
     // in registers and in the LDS slot) until only the last third of the groups (queue_direct_groups) is left; those go through the queue in tenth-length
     // tasks (counter[0]), which is what evens out the end of the launch: whole groups finish up to a group-time apart (the two
@@ -304,16 +366,12 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
         unsigned long long ts_claim = 0, ts_start = 0;
         if (stamps) ts_claim = __builtin_amdgcn_s_memtime();
         ws.mark();
-        const bool poisoned = queue_wait(flags, g, p, spin_limit);
+        bool poisoned = queue_wait_rlx(flags, g, p, spin_limit);
         ws.wait_done();
         if (stamps) ts_start = __builtin_amdgcn_s_memtime();
-        uint4* st = state + (g - ndirect) * (size_t)ROWS * 64;        // only the queued groups own a state block (pair_queue_setup)
-        if (poisoned) {
-            if (p == TASKS - 1 && active) {
-                bad_flag[1] = 1;
-                if (EQ) { if (t.role == 0) out[e] = 0xff; } else gt_poison(out + 576 * e, t.role);
-            }
-        } else if (p < MILLER_TASKS) {
+        unsigned long long* st = stw + (g - ndirect) * (size_t)STW_ROWS * 64;        // only the queued groups own a state block (pair_queue_setup)
+        const uint32_t tag_in = st_tag(epoch, p - 1u), tag_out = st_tag(epoch, p);     // F always comes from the phase before
+        if (!poisoned && p < MILLER_TASKS) {
             fp px, py, px2, py2; fp2 qx, qy, qx2, qy2; bool pinf, qinf, pinf2 = true, qinf2 = true, ok, okb = true;
             pair_inputs(px, py, pinf, qx, qy, qinf, ok, a1 + 96 * i, a2 + 192 * i);
             if (!ok) { pinf = true; qinf = true; }
@@ -336,59 +394,68 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
                 slot_store(H, one);
             } else {
                 fp4 f;
-                st_load<fp4, ST_ROWS_F>(f, st + ST_F * 64, lane);
+                bool got = stw_load<fp4, ST_DW_F>(f, st + STW_F * 64, lane, tag_in, spin_limit);
+                got = stw_load<fp2, ST_DW_TC>(tc, st + STW_TC1 * 64, lane, tag_in, spin_limit) && got;
+                if (EQ) got = stw_load<fp2, ST_DW_TC>(tc2, st + STW_TC2 * 64, lane, tag_in, spin_limit) && got;
+                poisoned = !got;
                 slot_store(H, f);
-                st_load<fp2, ST_ROWS_TC>(tc, st + ST_TC1 * 64, lane);
-                if (EQ) st_load<fp2, ST_ROWS_TC>(tc2, st + ST_TC2 * 64, lane);
             }
-            const int hi = 64 - MILLER_ITERS_PER_TASK * (int)p, lo = hi - (MILLER_ITERS_PER_TASK - 1);
-            if (EQ) miller3_range2(H, tc, px, py, pinf, Q, tc2, px2, py2, pinf2, Q2, hi, lo, t);
-            else miller3_range(H, tc, px, py, pinf, Q, hi, lo, t);
-            if (p == MILLER_TASKS - 1) f12t_conj_h(H, t);
-            {
-                fp4 f;
-                slot_load(f, H);
-                st_store<fp4, ST_ROWS_F>(st + ST_F * 64, lane, f);
+            ws.loaded();
+            if (!poisoned) {
+                const int hi = 64 - MILLER_ITERS_PER_TASK * (int)p, lo = hi - (MILLER_ITERS_PER_TASK - 1);
+                if (EQ) miller3_range2(H, tc, px, py, pinf, Q, tc2, px2, py2, pinf2, Q2, hi, lo, t);
+                else miller3_range(H, tc, px, py, pinf, Q, hi, lo, t);
+                if (p == MILLER_TASKS - 1) f12t_conj_h(H, t);
+                ws.computed();
+                {
+                    fp4 f;
+                    slot_load(f, H);
+                    stw_store<fp4, ST_DW_F>(st + STW_F * 64, lane, f, tag_out);
+                }
+                if (p < MILLER_TASKS - 1) {
+                    stw_store<fp2, ST_DW_TC>(st + STW_TC1 * 64, lane, tc, tag_out);
+                    if (EQ) stw_store<fp2, ST_DW_TC>(st + STW_TC2 * 64, lane, tc2, tag_out);
+                }
             }
-            if (p < MILLER_TASKS - 1) {
-                st_store<fp2, ST_ROWS_TC>(st + ST_TC1 * 64, lane, tc);
-                if (EQ) st_store<fp2, ST_ROWS_TC>(st + ST_TC2 * 64, lane, tc2);
-            }
-        } else {
+        } else if (!poisoned) {
             const int step = (int)(p - MILLER_TASKS);
             fp4 r, y1, aux;                              // aux shares the rows of the (finished) running points
-            st_load<fp4, ST_ROWS_F>(r, st + ST_F * 64, lane);
-            if (step >= 1) st_load<fp4, ST_ROWS_F>(y1, st + ST_Y1 * 64, lane);
-            if (step == 5) st_load<fp4, ST_ROWS_F>(aux, st + ST_TC1 * 64, lane);
-            f12t_final_exp_step(step, r, y1, aux, H, t);
-            if (step < 5) {
-                st_store<fp4, ST_ROWS_F>(st + ST_F * 64, lane, r);
-                if (step == 0) st_store<fp4, ST_ROWS_F>(st + ST_Y1 * 64, lane, y1);
-                if (step == 4) st_store<fp4, ST_ROWS_F>(st + ST_TC1 * 64, lane, aux);
-            } else {
-                // validity of this lane's inputs (cheap next to the arithmetic; keeps the state slab free of flags)
-                fp px, py; fp2 qx, qy; bool pinf, qinf, ok, okb = true;
-                pair_inputs(px, py, pinf, qx, qy, qinf, ok, a1 + 96 * i, a2 + 192 * i);
-                if (EQ) pair_inputs(px, py, pinf, qx, qy, qinf, okb, b1 + 96 * i, b2 + b2_stride * i);
-                const bool valid = ok && okb;
-                if (EQ) {
-                    const bool one = f12t_is_one(r, t);
-                    if (active && t.role == 0) {
-                        if (!valid) *bad_flag = 1;
-                        out[e] = valid ? (one ? 1 : 0) : 0xff;
-                    }
-                } else if (active) {
-                    if (!valid) {
-                        *bad_flag = 1;
-                        uint4* q = reinterpret_cast<uint4*>(out + 576 * e + (t.role == 0 ? 384 : (t.role == 1 ? 192 : 0)));
-                        for (int j = 0; j < 12; ++j) q[j] = make_uint4(~0u, ~0u, ~0u, ~0u);
-                    } else {
-                        gt_store_coeff(out + 576 * e, r, t.role);
+            bool got = stw_load<fp4, ST_DW_F>(r, st + STW_F * 64, lane, tag_in, spin_limit);
+            if (step >= 1) got = stw_load<fp4, ST_DW_F>(y1, st + STW_Y1 * 64, lane, st_tag(epoch, MILLER_TASKS), spin_limit) && got;       // written by step 0
+            if (step == 5) got = stw_load<fp4, ST_DW_F>(aux, st + STW_TC1 * 64, lane, st_tag(epoch, MILLER_TASKS + 4u), spin_limit) && got;  // written by step 4
+            poisoned = !got;
+            ws.loaded();
+            if (!poisoned) {
+                f12t_final_exp_step(step, r, y1, aux, H, t);
+                ws.computed();
+                if (step < 5) {
+                    stw_store<fp4, ST_DW_F>(st + STW_F * 64, lane, r, tag_out);
+                    if (step == 0) stw_store<fp4, ST_DW_F>(st + STW_Y1 * 64, lane, y1, tag_out);
+                    if (step == 4) stw_store<fp4, ST_DW_F>(st + STW_TC1 * 64, lane, aux, tag_out);
+                } else {
+                    // validity of this lane's inputs (cheap next to the arithmetic; keeps the state slab free of flags)
+                    fp px, py; fp2 qx, qy; bool pinf, qinf, ok, okb = true;
+                    pair_inputs(px, py, pinf, qx, qy, qinf, ok, a1 + 96 * i, a2 + 192 * i);
+                    if (EQ) pair_inputs(px, py, pinf, qx, qy, qinf, okb, b1 + 96 * i, b2 + b2_stride * i);
+                    const bool valid = ok && okb;
+                    if (EQ) {
+                        const bool one = f12t_is_one(r, t);
+                        if (active && t.role == 0) {
+                            if (!valid) *bad_flag = 1;
+                            out[e] = valid ? (one ? 1 : 0) : 0xff;
+                        }
+                    } else if (active) {
+                        if (!valid) { *bad_flag = 1; gt_poison(out + 576 * e, t.role); }
+                        else gt_store_coeff(out + 576 * e, r, t.role);
                     }
                 }
             }
         }
-        queue_publish(flags, g, p, poisoned, lane);
+        if (poisoned && p == TASKS - 1 && active) {        // the group's state was never completed: 0xff outputs, C12381_E_INTERNAL
+            bad_flag[1] = 1;
+            if (EQ) { if (t.role == 0) out[e] = 0xff; } else gt_poison(out + 576 * e, t.role);
+        }
+        queue_publish_rlx(flags, g, p, poisoned, lane);
         ws.task_done();
         if (stamps && lane == 0) {
             unsigned long long* o = stamps + 4 * (size_t)task;
@@ -400,18 +467,18 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
 }
 
 __global__ void __launch_bounds__(BLOCK, 2) pair3_queue_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag, uint4* state,
-                                                            unsigned int* flags, unsigned int* counter, int spin_limit, unsigned long long* stamps, unsigned long long* wstats) {
+                                                            unsigned int* flags, unsigned int* counter, int spin_limit, unsigned int epoch, unsigned long long* stamps, unsigned long long* wstats) {
     __shared__ fp4_slot slots[BLOCK];
     slot_fair_set(slots[threadIdx.x].v, 0);
-    pair3_queue_body<false>(n, g1, g2, nullptr, nullptr, 0, gt, bad_flag, state, flags, counter, spin_limit, slots[threadIdx.x].v, stamps, wstats);
+    pair3_queue_body<false>(n, g1, g2, nullptr, nullptr, 0, gt, bad_flag, state, flags, counter, spin_limit, epoch, slots[threadIdx.x].v, stamps, wstats);
 }
 __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_queue_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2,
                                                                size_t b2_stride, uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags,
-                                                               unsigned int* counter, const int32_t* skip_if, int spin_limit) {
+                                                               unsigned int* counter, const int32_t* skip_if, int spin_limit, unsigned int epoch) {
     if (skip_if && skip_if[HDR_VALID] != 0) return;
     __shared__ fp4_slot slots[BLOCK];
     slot_fair_set(slots[threadIdx.x].v, 0);
-    pair3_queue_body<true>(n, a1, a2, b1, b2, b2_stride, out, bad_flag, state, flags, counter, spin_limit, slots[threadIdx.x].v);
+    pair3_queue_body<true>(n, a1, a2, b1, b2, b2_stride, out, bad_flag, state, flags, counter, spin_limit, epoch, slots[threadIdx.x].v);
 }
 
 // ------------------------------------------------------------------ the split forms through the same queue
@@ -421,9 +488,10 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_queue_kernel(size_t n, cons
 // schedule and hand-over protocol as pair3_queue_body; a separate body, so that the pairing kernels' code is untouched.
 template <bool MILLER>
 __device__ __forceinline__ void split3_queue_body(size_t n, const uint8_t* in1, const uint8_t* in2, uint8_t* out, int* bad_flag, uint4* state,
-                                                  unsigned int* flags, unsigned int* counter, int spin_limit, fp4& H,
+                                                  unsigned int* flags, unsigned int* counter, int spin_limit, uint32_t epoch, fp4& H,
                                                   unsigned long long* wstats) {
     queue_wave_stats ws(wstats);
+    unsigned long long* const stw = reinterpret_cast<unsigned long long*>(state);
     const unsigned lane = threadIdx.x & 63u;
     const unsigned trip = lane / 3u;
     tri t;
@@ -431,7 +499,6 @@ __device__ __forceinline__ void split3_queue_body(size_t n, const uint8_t* in1, 
     t.base = lane == 63u ? 63 : (int)(3u * trip);
     const size_t ngroups = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE;
     constexpr unsigned int TASKS = MILLER ? (unsigned)MILLER_TASKS_PER_GROUP : 6u;
-    constexpr int ROWS = ST_Y1 + ST_ROWS_F;
     const size_t nwaves = (size_t)gridDim.x * (BLOCK / 64);
     const size_t ndirect = queue_direct_groups(ngroups, nwaves);
     for (;;) {                                                 // whole groups first
@@ -471,12 +538,11 @@ __device__ __forceinline__ void split3_queue_body(size_t n, const uint8_t* in1, 
         const bool active = lane < 63u && e < n;
         const size_t i = e < n ? e : n - 1;
         ws.mark();
-        const bool poisoned = queue_wait(flags, g, p, spin_limit);
+        bool poisoned = queue_wait_rlx(flags, g, p, spin_limit);
         ws.wait_done();
-        uint4* st = state + (g - ndirect) * (size_t)ROWS * 64;
-        if (poisoned) {
-            if (p == TASKS - 1 && active) { bad_flag[1] = 1; gt_poison(out + 576 * e, t.role); }
-        } else if (MILLER) {
+        unsigned long long* st = stw + (g - ndirect) * (size_t)STW_ROWS * 64;
+        const uint32_t tag_in = st_tag(epoch, p - 1u), tag_out = st_tag(epoch, p);
+        if (!poisoned && MILLER) {
             fp px, py; fp2 qx, qy; bool pinf, qinf, ok;
             pair_inputs(px, py, pinf, qx, qy, qinf, ok, in1 + 96 * i, in2 + 192 * i);
             if (!ok) { pinf = true; qinf = true; }
@@ -490,54 +556,66 @@ __device__ __forceinline__ void split3_queue_body(size_t n, const uint8_t* in1, 
                 slot_store(H, one);
             } else {
                 fp4 f;
-                st_load<fp4, ST_ROWS_F>(f, st + ST_F * 64, lane);
+                bool got = stw_load<fp4, ST_DW_F>(f, st + STW_F * 64, lane, tag_in, spin_limit);
+                got = stw_load<fp2, ST_DW_TC>(tc, st + STW_TC1 * 64, lane, tag_in, spin_limit) && got;
+                poisoned = !got;
                 slot_store(H, f);
-                st_load<fp2, ST_ROWS_TC>(tc, st + ST_TC1 * 64, lane);
             }
-            const int hi = 64 - MILLER_ITERS_PER_TASK * (int)p, lo = hi - (MILLER_ITERS_PER_TASK - 1);
-            miller3_range(H, tc, px, py, pinf, Q, hi, lo, t);
-            if (p == TASKS - 1) {
-                f12t_conj_h(H, t);
-                if (active) {
-                    if (!ok) { *bad_flag = 1; gt_poison(out + 576 * e, t.role); }
-                    else { fp4 F; slot_load(F, H); gt_store_coeff(out + 576 * e, F, t.role); }
+            ws.loaded();
+            if (!poisoned) {
+                const int hi = 64 - MILLER_ITERS_PER_TASK * (int)p, lo = hi - (MILLER_ITERS_PER_TASK - 1);
+                miller3_range(H, tc, px, py, pinf, Q, hi, lo, t);
+                ws.computed();
+                if (p == TASKS - 1) {
+                    f12t_conj_h(H, t);
+                    if (active) {
+                        if (!ok) { *bad_flag = 1; gt_poison(out + 576 * e, t.role); }
+                        else { fp4 F; slot_load(F, H); gt_store_coeff(out + 576 * e, F, t.role); }
+                    }
+                } else {
+                    fp4 f;
+                    slot_load(f, H);
+                    stw_store<fp4, ST_DW_F>(st + STW_F * 64, lane, f, tag_out);
+                    stw_store<fp2, ST_DW_TC>(st + STW_TC1 * 64, lane, tc, tag_out);
                 }
-            } else {
-                fp4 f;
-                slot_load(f, H);
-                st_store<fp4, ST_ROWS_F>(st + ST_F * 64, lane, f);
-                st_store<fp2, ST_ROWS_TC>(st + ST_TC1 * 64, lane, tc);
             }
-        } else {
+        } else if (!poisoned) {
             const int step = (int)p;
             fp4 r, y1, aux;
+            bool got = true;
             if (step == 0) gt_load_coeff(r, in1 + 576 * i, t.role);
-            else st_load<fp4, ST_ROWS_F>(r, st + ST_F * 64, lane);
-            if (step >= 1) st_load<fp4, ST_ROWS_F>(y1, st + ST_Y1 * 64, lane);
-            if (step == 5) st_load<fp4, ST_ROWS_F>(aux, st + ST_TC1 * 64, lane);
-            f12t_final_exp_step(step, r, y1, aux, H, t);
-            if (step < 5) {
-                st_store<fp4, ST_ROWS_F>(st + ST_F * 64, lane, r);
-                if (step == 0) st_store<fp4, ST_ROWS_F>(st + ST_Y1 * 64, lane, y1);
-                if (step == 4) st_store<fp4, ST_ROWS_F>(st + ST_TC1 * 64, lane, aux);
-            } else if (active) gt_store_coeff(out + 576 * e, r, t.role);
+            else got = stw_load<fp4, ST_DW_F>(r, st + STW_F * 64, lane, tag_in, spin_limit, &ws.reread);
+            if (step >= 1) got = stw_load<fp4, ST_DW_F>(y1, st + STW_Y1 * 64, lane, st_tag(epoch, 0u), spin_limit) && got;      // written by step 0
+            if (step == 5) got = stw_load<fp4, ST_DW_F>(aux, st + STW_TC1 * 64, lane, st_tag(epoch, 4u), spin_limit) && got;    // written by step 4
+            poisoned = !got;
+            ws.loaded();
+            if (!poisoned) {
+                f12t_final_exp_step(step, r, y1, aux, H, t);
+                ws.computed();
+                if (step < 5) {
+                    stw_store<fp4, ST_DW_F>(st + STW_F * 64, lane, r, tag_out);
+                    if (step == 0) stw_store<fp4, ST_DW_F>(st + STW_Y1 * 64, lane, y1, tag_out);
+                    if (step == 4) stw_store<fp4, ST_DW_F>(st + STW_TC1 * 64, lane, aux, tag_out);
+                } else if (active) gt_store_coeff(out + 576 * e, r, t.role);
+            }
         }
-        queue_publish(flags, g, p, poisoned, lane);
+        if (poisoned && p == TASKS - 1 && active) { bad_flag[1] = 1; gt_poison(out + 576 * e, t.role); }
+        queue_publish_rlx(flags, g, p, poisoned, lane);
         ws.task_done();
     }
     ws.finish();
 }
 __global__ void __launch_bounds__(BLOCK, 2) miller3_queue_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* out, int* bad_flag, uint4* state,
-                                                              unsigned int* flags, unsigned int* counter, int spin_limit, unsigned long long* wstats) {
+                                                              unsigned int* flags, unsigned int* counter, int spin_limit, unsigned int epoch, unsigned long long* wstats) {
     __shared__ fp4_slot slots[BLOCK];
     slot_fair_set(slots[threadIdx.x].v, 0);
-    split3_queue_body<true>(n, g1, g2, out, bad_flag, state, flags, counter, spin_limit, slots[threadIdx.x].v, wstats);
+    split3_queue_body<true>(n, g1, g2, out, bad_flag, state, flags, counter, spin_limit, epoch, slots[threadIdx.x].v, wstats);
 }
 __global__ void __launch_bounds__(BLOCK, 2) fexp3_queue_kernel(size_t n, const uint8_t* in576, uint8_t* out, int* bad_flag, uint4* state,
-                                                            unsigned int* flags, unsigned int* counter, int spin_limit, unsigned long long* wstats) {
+                                                            unsigned int* flags, unsigned int* counter, int spin_limit, unsigned int epoch, unsigned long long* wstats) {
     __shared__ fp4_slot slots[BLOCK];
     slot_fair_set(slots[threadIdx.x].v, 0);
-    split3_queue_body<false>(n, in576, nullptr, out, bad_flag, state, flags, counter, spin_limit, slots[threadIdx.x].v, wstats);
+    split3_queue_body<false>(n, in576, nullptr, out, bad_flag, state, flags, counter, spin_limit, epoch, slots[threadIdx.x].v, wstats);
 }
 
 // ------------------------------------------------------------------ both G2 arguments fixed for the batch
@@ -577,7 +655,8 @@ __global__ void __launch_bounds__(BLOCK, 2) gate_and_kernel(int32_t* gate, const
 template <bool TWO>
 __device__ __forceinline__ void pair3_fixed_queue_body(size_t n, const uint8_t* a96, const uint8_t* c96, const int32_t* tabw, const int32_t* tabg,
                                                        uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter,
-                                                       int spin_limit, bool table_ok, fp4& H) {
+                                                       int spin_limit, uint32_t epoch, bool table_ok, fp4& H) {
+    unsigned long long* const stw = reinterpret_cast<unsigned long long*>(state);
     const unsigned lane = threadIdx.x & 63u;
     const unsigned trip = lane / 3u;
     tri t;
@@ -585,7 +664,6 @@ __device__ __forceinline__ void pair3_fixed_queue_body(size_t n, const uint8_t* 
     t.base = lane == 63u ? 63 : (int)(3u * trip);
     const size_t ngroups = (n + TRI_PER_WAVE - 1) / TRI_PER_WAVE;
     constexpr unsigned int MILLER_TASKS = MILLER_TASKS_PER_GROUP, TASKS = MILLER_TASKS + 6;
-    constexpr int ROWS = ST_Y1 + ST_ROWS_F;
     // whole groups first, the last third of the groups through the queue (see pair3_queue_body)
     const size_t nwaves = (size_t)gridDim.x * (BLOCK / 64);
     const size_t ndirect = queue_direct_groups(ngroups, nwaves);
@@ -633,8 +711,9 @@ __device__ __forceinline__ void pair3_fixed_queue_body(size_t n, const uint8_t* 
         const size_t e = g * TRI_PER_WAVE + (lane == 63u ? TRI_PER_WAVE - 1 : trip);
         const bool active = lane < 63u && e < n;
         const size_t i = e < n ? e : n - 1;
-        const bool poisoned = queue_wait(flags, g, p, spin_limit);
-        uint4* st = state + (g - ndirect) * (size_t)ROWS * 64;        // only the queued groups own a state block (pair_queue_setup)
+        bool poisoned = queue_wait_rlx(flags, g, p, spin_limit);
+        unsigned long long* st = stw + (g - ndirect) * (size_t)STW_ROWS * 64;        // only the queued groups own a state block (pair_queue_setup)
+        const uint32_t tag_in = st_tag(epoch, p - 1u), tag_out = st_tag(epoch, p);
         fp ax, ay, cx, cy; bool ainf, cinf = true, oka, okc = true;
         if (!poisoned && (p < MILLER_TASKS || p == TASKS - 1)) {
             g1_parse96(ax, ay, ainf, oka, a96 + 96 * i);
@@ -644,71 +723,69 @@ __device__ __forceinline__ void pair3_fixed_queue_body(size_t n, const uint8_t* 
                 if (!okc) cinf = true;
             }
         }
-        if (poisoned) {
-            if (p == TASKS - 1 && active) {
-                bad_flag[1] = 1;
-                if (TWO) { if (t.role == 0) out[e] = 0xff; } else gt_poison(out + 576 * e, t.role);
-            }
-        } else if (p < MILLER_TASKS) {
+        if (!poisoned && p < MILLER_TASKS) {
             {
                 fp4 f;
-                if (p == 0) f12t_one(f, t); else st_load<fp4, ST_ROWS_F>(f, st + ST_F * 64, lane);
+                if (p == 0) f12t_one(f, t); else poisoned = !stw_load<fp4, ST_DW_F>(f, st + STW_F * 64, lane, tag_in, spin_limit);
                 slot_store(H, f);
             }
-            const int hi = 64 - MILLER_ITERS_PER_TASK * (int)p, lo = hi - (MILLER_ITERS_PER_TASK - 1);
-            if (TWO) miller3_range2_fixed(H, ax, ay, ainf, tabw, cx, cy, cinf, tabg, hi, lo, t);
-            else miller3_range_fixed(H, ax, ay, ainf, tabw, hi, lo, t);
-            if (p == MILLER_TASKS - 1) f12t_conj_h(H, t);
-            {
+            if (!poisoned) {
+                const int hi = 64 - MILLER_ITERS_PER_TASK * (int)p, lo = hi - (MILLER_ITERS_PER_TASK - 1);
+                if (TWO) miller3_range2_fixed(H, ax, ay, ainf, tabw, cx, cy, cinf, tabg, hi, lo, t);
+                else miller3_range_fixed(H, ax, ay, ainf, tabw, hi, lo, t);
+                if (p == MILLER_TASKS - 1) f12t_conj_h(H, t);
                 fp4 f;
                 slot_load(f, H);
-                st_store<fp4, ST_ROWS_F>(st + ST_F * 64, lane, f);
+                stw_store<fp4, ST_DW_F>(st + STW_F * 64, lane, f, tag_out);
             }
-        } else {
+        } else if (!poisoned) {
             const int step = (int)(p - MILLER_TASKS);
             fp4 r, y1, aux;
-            st_load<fp4, ST_ROWS_F>(r, st + ST_F * 64, lane);
-            if (step >= 1) st_load<fp4, ST_ROWS_F>(y1, st + ST_Y1 * 64, lane);
-            if (step == 5) st_load<fp4, ST_ROWS_F>(aux, st + ST_TC1 * 64, lane);
-            f12t_final_exp_step(step, r, y1, aux, H, t);
-            if (step < 5) {
-                st_store<fp4, ST_ROWS_F>(st + ST_F * 64, lane, r);
-                if (step == 0) st_store<fp4, ST_ROWS_F>(st + ST_Y1 * 64, lane, y1);
-                if (step == 4) st_store<fp4, ST_ROWS_F>(st + ST_TC1 * 64, lane, aux);
-            } else if (TWO) {
-                const bool one = f12t_is_one(r, t);
-                const bool valid = oka && okc;
-                if (active && t.role == 0) {
-                    if (!valid) *bad_flag = 1;
-                    out[e] = valid ? (one ? 1 : 0) : 0xff;
-                }
-            } else if (active) {
-                if (!(oka && table_ok)) {
-                    *bad_flag = 1;
-                    uint4* q = reinterpret_cast<uint4*>(out + 576 * e + (t.role == 0 ? 384 : (t.role == 1 ? 192 : 0)));
-                    for (int j = 0; j < 12; ++j) q[j] = make_uint4(~0u, ~0u, ~0u, ~0u);
-                } else {
-                    gt_store_coeff(out + 576 * e, r, t.role);
+            bool got = stw_load<fp4, ST_DW_F>(r, st + STW_F * 64, lane, tag_in, spin_limit);
+            if (step >= 1) got = stw_load<fp4, ST_DW_F>(y1, st + STW_Y1 * 64, lane, st_tag(epoch, MILLER_TASKS), spin_limit) && got;       // written by step 0
+            if (step == 5) got = stw_load<fp4, ST_DW_F>(aux, st + STW_TC1 * 64, lane, st_tag(epoch, MILLER_TASKS + 4u), spin_limit) && got;  // written by step 4
+            poisoned = !got;
+            if (!poisoned) {
+                f12t_final_exp_step(step, r, y1, aux, H, t);
+                if (step < 5) {
+                    stw_store<fp4, ST_DW_F>(st + STW_F * 64, lane, r, tag_out);
+                    if (step == 0) stw_store<fp4, ST_DW_F>(st + STW_Y1 * 64, lane, y1, tag_out);
+                    if (step == 4) stw_store<fp4, ST_DW_F>(st + STW_TC1 * 64, lane, aux, tag_out);
+                } else if (TWO) {
+                    const bool one = f12t_is_one(r, t);
+                    const bool valid = oka && okc;
+                    if (active && t.role == 0) {
+                        if (!valid) *bad_flag = 1;
+                        out[e] = valid ? (one ? 1 : 0) : 0xff;
+                    }
+                } else if (active) {
+                    if (!(oka && table_ok)) { *bad_flag = 1; gt_poison(out + 576 * e, t.role); }
+                    else gt_store_coeff(out + 576 * e, r, t.role);
                 }
             }
         }
-        queue_publish(flags, g, p, poisoned, lane);
+        if (poisoned && p == TASKS - 1 && active) {        // the group's state was never completed: 0xff outputs, C12381_E_INTERNAL
+            bad_flag[1] = 1;
+            if (TWO) { if (t.role == 0) out[e] = 0xff; } else gt_poison(out + 576 * e, t.role);
+        }
+        queue_publish_rlx(flags, g, p, poisoned, lane);
     }
 }
 __global__ void __launch_bounds__(BLOCK, 2) pair3_prod_fixed_queue_kernel(size_t n, const uint8_t* a96, const uint8_t* c96, const int32_t* tabw,
                                                                        const int32_t* tabg, uint8_t* out, int* bad_flag, uint4* state,
-                                                                       unsigned int* flags, unsigned int* counter, const int32_t* run_if, int spin_limit) {
+                                                                       unsigned int* flags, unsigned int* counter, const int32_t* run_if, int spin_limit,
+                                                                       unsigned int epoch) {
     if (run_if[HDR_VALID] == 0) return;
     __shared__ fp4_slot slots[BLOCK];
     slot_fair_set(slots[threadIdx.x].v, 0);
-    pair3_fixed_queue_body<true>(n, a96, c96, tabw, tabg, out, bad_flag, state, flags, counter, spin_limit, true, slots[threadIdx.x].v);
+    pair3_fixed_queue_body<true>(n, a96, c96, tabw, tabg, out, bad_flag, state, flags, counter, spin_limit, epoch, true, slots[threadIdx.x].v);
 }
 // gt[i] = e(P_i, Q) for ONE Q given by its coefficient table (header at `buf`, lines behind it)
 __global__ void __launch_bounds__(BLOCK, 2) pair3_fixed_queue_kernel(size_t n, const uint8_t* g1_96, const int32_t* buf, uint8_t* gt, int* bad_flag,
-                                                                  uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit) {
+                                                                  uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit, unsigned int epoch) {
     __shared__ fp4_slot slots[BLOCK];
     slot_fair_set(slots[threadIdx.x].v, 0);
-    pair3_fixed_queue_body<false>(n, g1_96, nullptr, buf + HDR_DWORDS, nullptr, gt, bad_flag, state, flags, counter, spin_limit, buf[HDR_VALID] != 0, slots[threadIdx.x].v);
+    pair3_fixed_queue_body<false>(n, g1_96, nullptr, buf + HDR_DWORDS, nullptr, gt, bad_flag, state, flags, counter, spin_limit, epoch, buf[HDR_VALID] != 0, slots[threadIdx.x].v);
 }
 
 // ------------------------------------------------------------------ split pairing and GT arithmetic on triples

@@ -75,20 +75,21 @@ __global__ void __launch_bounds__(BLOCK, 2) gt_is_unity_kernel(size_t n, const u
 __global__ void __launch_bounds__(BLOCK, 2) pair3_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) pair3_prod_kernel(size_t n, int k, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag, int miller_only);
 __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, size_t b2_stride, uint8_t* out, int* bad_flag, const int32_t* skip_if);
-__global__ void __launch_bounds__(BLOCK, 2) miller3_queue_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit, unsigned long long* wstats);
-__global__ void __launch_bounds__(BLOCK, 2) fexp3_queue_kernel(size_t n, const uint8_t* in576, uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit, unsigned long long* wstats);
-__global__ void __launch_bounds__(BLOCK, 2) pair3_queue_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit, unsigned long long* stamps, unsigned long long* wstats);
-__global__ void __launch_bounds__(BLOCK, 2) pair3_eq_queue_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, size_t b2_stride, uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, const int32_t* skip_if, int spin_limit);
+__global__ void __launch_bounds__(BLOCK, 2) miller3_queue_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit, unsigned int epoch, unsigned long long* wstats);
+__global__ void __launch_bounds__(BLOCK, 2) fexp3_queue_kernel(size_t n, const uint8_t* in576, uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit, unsigned int epoch, unsigned long long* wstats);
+__global__ void __launch_bounds__(BLOCK, 2) pair3_queue_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit, unsigned int epoch, unsigned long long* stamps, unsigned long long* wstats);
+__global__ void __launch_bounds__(BLOCK, 2) pair3_eq_queue_kernel(size_t n, const uint8_t* a1, const uint8_t* a2, const uint8_t* b1, const uint8_t* b2, size_t b2_stride, uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, const int32_t* skip_if, int spin_limit, unsigned int epoch);
 __global__ void __launch_bounds__(BLOCK, 2) g2_lines_table_kernel(const uint8_t* q192, int32_t* buf, int need_g2);
 __global__ void __launch_bounds__(BLOCK, 2) gate_and_kernel(int32_t* gate, const int32_t* a, const int32_t* b);
-__global__ void __launch_bounds__(BLOCK, 2) pair3_prod_fixed_queue_kernel(size_t n, const uint8_t* a96, const uint8_t* c96, const int32_t* tabw, const int32_t* tabg, uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, const int32_t* run_if, int spin_limit);
-__global__ void __launch_bounds__(BLOCK, 2) pair3_fixed_queue_kernel(size_t n, const uint8_t* g1_96, const int32_t* buf, uint8_t* gt, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit);
+__global__ void __launch_bounds__(BLOCK, 2) pair3_prod_fixed_queue_kernel(size_t n, const uint8_t* a96, const uint8_t* c96, const int32_t* tabw, const int32_t* tabg, uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, const int32_t* run_if, int spin_limit, unsigned int epoch);
+__global__ void __launch_bounds__(BLOCK, 2) pair3_fixed_queue_kernel(size_t n, const uint8_t* g1_96, const int32_t* buf, uint8_t* gt, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit, unsigned int epoch);
 __global__ void __launch_bounds__(BLOCK, 2) miller3_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* out, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) gt3_op_kernel(int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out, uint4* pow_tab);
 __global__ void __launch_bounds__(BLOCK, 2) gt3_pow_queue_kernel(size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out, int* bad_flag, uint4* pow_tab, uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit);
 constexpr size_t GT_POW_TAB_BYTES_PER_WAVE = (size_t)16 * 14 * 64 * 16;   // 16 entries x 14 rows (one Fp4 per lane) x 64 lanes x 16 bytes
 __global__ void __launch_bounds__(BLOCK, 2) gt3_is_unity_kernel(size_t n, const uint8_t* a, uint8_t* out);
-constexpr int PAIR_QUEUE_STATE_ROWS = 42;        // 16-byte rows x 64 lanes per group of 21 pairings (F, tc1, tc2, y1)
+constexpr int PAIR_QUEUE_STATE_ROWS = 42;        // 16-byte rows x 64 lanes per group of 21 pairings (F, tc1, tc2, y1): the fenced form (GT power queue)
+constexpr size_t PAIR_QUEUE_STATE_BYTES = (size_t)168 * 64 * 8;   // a queued group's block: 168 32-bit words per lane, each in an 8-byte tagged word (k_pair3.hip stw_store)
 __global__ void __launch_bounds__(BLOCK, 2) g1_from_hash_kernel(size_t n, const uint8_t* in, int mode, int32_t* proj, size_t proj_stride, int* bad_flag);
 __global__ void __launch_bounds__(BLOCK, 2) zp_op_kernel(int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out);
 __global__ void __launch_bounds__(BLOCK, 2) zp_fold_cols_kernel(size_t n, const uint8_t* a, size_t a_col_stride, const uint8_t* r32, const uint8_t* m32, int first, size_t T, uint8_t* out);

@@ -25,9 +25,10 @@ def stats(label, run):
     run(); run()                                   # the second launch's stamps are the ones read (warm caches, workspace in place)
     c.sync()
     a = np.fromfile(path, dtype=np.uint64)
-    w = a[-STAMP_WAVES * 8:].reshape(-1, 8)
+    w = a[-STAMP_WAVES * 12:].reshape(-1, 12)
     w = w[w[:, 1] > 0]
     entry, exit_, whole, nwhole, task, ntask, wait = (w[:, k].astype(np.float64) for k in range(7))
+    load, store, reread = w[:, 8].astype(np.float64), w[:, 9].astype(np.float64), w[:, 10].astype(np.float64)
     hwid = (w[:, 7] & np.uint64(0xffffffff)).astype(np.int64)
     xcc = (w[:, 7] >> np.uint64(32)).astype(np.int64) & 0xf
     wave_id, simd, cu, sh, se = hwid & 0xf, (hwid >> 4) & 3, (hwid >> 8) & 0xf, (hwid >> 12) & 1, (hwid >> 13) & 7
@@ -60,6 +61,9 @@ def stats(label, run):
         np.median((whole / np.maximum(nwhole, 1))[older & (nwhole > 0)]) / 1e6 if (older & (nwhole > 0)).any() else 0,
         np.median((whole / np.maximum(nwhole, 1))[~older & (nwhole > 0)]) / 1e6 if (~older & (nwhole > 0)).any() else 0,
         (task[older].sum() / max(ntask[older].sum(), 1)) / 1e6, (task[~older].sum() / max(ntask[~older].sum(), 1)) / 1e6))
+    nt = max(ntask.sum(), 1)
+    print("   inside a task (mean K cycles): state arrives %.1f, arithmetic %.1f, state leaves + publish %.1f" % (
+        load.sum() / nt / 1e3, (task.sum() - load.sum() - store.sum()) / nt / 1e3, store.sum() / nt / 1e3) + (";  re-reads of the first value: %d in %d tasks" % (reread.sum(), nt) if reread.sum() else ""))
     ex = np.sort(exit_ - t0)
     print("   exits (M cycles after the first entry): p5 %.2f  p25 %.2f  p50 %.2f  p75 %.2f  p95 %.2f  last %.2f" % tuple(np.percentile(ex, [5, 25, 50, 75, 95, 100]) / 1e6))
     # SIMD-level: cycles in which 0 / 1 / 2 of the SIMD's wavefronts were inside the kernel and not in a hand-over wait cannot be told from totals;
