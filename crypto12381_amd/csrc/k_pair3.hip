@@ -92,38 +92,50 @@ __device__ __forceinline__ void st_load(T& x, const uint4* rows, unsigned lane) 
 }
 
 // ---- the same state WITHOUT cache maintenance (round 5): every 32-bit word travels in an 8-byte word together with a 32-bit tag — launch epoch and
-// the phase that wrote it — as one relaxed agent-scope atomic store (global_store_dwordx2 sc1: write-through, coherent across the eight XCDs' L2s for
-// that location), and is read by a relaxed agent-scope atomic load (sc1); a reader that sees another tag in ANY word reads again.  Single-copy atomicity
-// of an aligned 8-byte access is all this needs: no release / acquire pair, i.e. none of the buffer_wbl2 sc1 / buffer_inv sc1 the fences of the
-// 16-byte form cost per task — a write-back and an invalidation of the whole XCD's L2 under 256 resident wavefronts whose spills and private
-// operands live there (measured with the fences simply left out — WRONG results, timing only — tasks 5-7 % shorter and the whole groups running
-// beside them 2-3 %: profiles/r05_ab_fence_free_handover.txt).  The price is twice the bytes of a state that is 1 KB per lane and task.
-// Rows of 64 lanes x 8 bytes; one row per 32-bit word of the value.
+// the phase that wrote it; a reader that sees another tag in ANY word reads again.  The accesses are agent-scope coherent (sc1: write-through /
+// read past this XCD's L2 — the eight XCDs' L2s are not coherent with each other for ordinary accesses: with an L1 invalidation alone the results
+// were wrong, profiles/r05_ab_fence_free_handover.txt), and a word validates itself, so no release / acquire pair is needed: none of the
+// buffer_wbl2 sc1 / buffer_inv sc1 the fences of the 16-byte form cost per task — a write-back and an invalidation of the whole XCD's L2 under
+// 256 resident wavefronts whose spills and private operands live there (tasks 5-7 % longer, the whole groups running beside them 2-3 %).
+// Two tagged words per lane and instruction: buffer_load / buffer_store_dwordx4 with sc1 (as relaxed agent-scope ATOMIC 8-byte accesses —
+// global_load / store_dwordx2 sc1 — the same traffic took ~600 cycles of issue per instruction, 65-105 K cycles per task to arrive and 20-48 K to
+// leave: they are not coalesced).  An aligned 8-byte half of a lane's 16-byte access is never torn (one lane's 16 bytes move in one transaction),
+// and tearing BETWEEN the halves is harmless, each carries its own tag.  Rows of 64 lanes x 16 bytes; one row per pair of 32-bit words.
 constexpr int ST_DW_F = 56, ST_DW_TC = 28;                    // 32-bit words of an Fp4 / Fp2
-constexpr int STW_F = 0, STW_TC1 = ST_DW_F, STW_TC2 = STW_TC1 + ST_DW_TC, STW_Y1 = STW_TC2 + ST_DW_TC, STW_ROWS = STW_Y1 + ST_DW_F;      // 168 rows of 512 bytes
-static_assert((size_t)STW_ROWS * 512 == PAIR_QUEUE_STATE_BYTES, "kernels.hpp: size of a queued group's state block");
+constexpr int STW_F = 0, STW_TC1 = ST_DW_F / 2, STW_TC2 = STW_TC1 + ST_DW_TC / 2, STW_Y1 = STW_TC2 + ST_DW_TC / 2, STW_ROWS = STW_Y1 + ST_DW_F / 2;      // 84 rows of 1 KB
+static_assert((size_t)STW_ROWS * 1024 == PAIR_QUEUE_STATE_BYTES, "kernels.hpp: size of a queued group's state block");
+constexpr int STW_AUX = 16 | (int)0x80000000u;                // cache policy of the buffer instructions: sc1, volatile (never merged or hoisted)
+typedef int32_t stw_v4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t st_tag(uint32_t epoch, unsigned int writer_phase) { return (epoch << 4) | (writer_phase + 1u); }
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t stw_rsrc(const void* rows) {          // rows: wave-uniform
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(rows), 0, 0x7fffffff, 0x00020000);
+}
 template <class T, int DW>
-__device__ __forceinline__ void stw_store(unsigned long long* rows, unsigned lane, const T& x, uint32_t tag) {
-    static_assert(sizeof(T) == DW * 4, "state word count");
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(&x);
+__device__ __forceinline__ void stw_store(void* rows, unsigned lane, const T& x, uint32_t tag) {
+    static_assert(sizeof(T) == DW * 4 && DW % 2 == 0, "state word count");
+    const int32_t* w = reinterpret_cast<const int32_t*>(&x);
+    const __amdgpu_buffer_rsrc_t rs = stw_rsrc(rows);
 #pragma unroll
-    for (int r = 0; r < DW; ++r)
-        __hip_atomic_store(&rows[(size_t)r * 64 + lane], ((unsigned long long)tag << 32) | w[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int r = 0; r < DW / 2; ++r) {
+        stw_v4 v;
+        v.x = w[2 * r]; v.y = (int32_t)tag; v.z = w[2 * r + 1]; v.w = (int32_t)tag;
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)((r * 64 + lane) * 16), 0, STW_AUX);
+    }
 }
 // false: some word still carried another tag after spin_limit re-reads (the writer never finished): the caller poisons the group
 template <class T, int DW>
-__device__ __forceinline__ bool stw_load(T& x, const unsigned long long* rows, unsigned lane, uint32_t tag, int spin_limit, unsigned int* reread = nullptr) {
-    static_assert(sizeof(T) == DW * 4, "state word count");
-    uint32_t* w = reinterpret_cast<uint32_t*>(&x);
+__device__ __forceinline__ bool stw_load(T& x, const void* rows, unsigned lane, uint32_t tag, int spin_limit, unsigned int* reread = nullptr) {
+    static_assert(sizeof(T) == DW * 4 && DW % 2 == 0, "state word count");
+    int32_t* w = reinterpret_cast<int32_t*>(&x);
+    const __amdgpu_buffer_rsrc_t rs = stw_rsrc(rows);
     int spins = 0;
     for (;;) {
         bool ok = true;
 #pragma unroll
-        for (int r = 0; r < DW; ++r) {
-            const unsigned long long v = __hip_atomic_load(&rows[(size_t)r * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            w[r] = (uint32_t)v;
-            ok = ok && (uint32_t)(v >> 32) == tag;
+        for (int r = 0; r < DW / 2; ++r) {
+            const stw_v4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((r * 64 + lane) * 16), 0, STW_AUX);
+            w[2 * r] = v.x; w[2 * r + 1] = v.z;
+            ok = ok && (uint32_t)v.y == tag && (uint32_t)v.w == tag;
         }
         if (__builtin_amdgcn_ballot_w64(!ok) == 0) return true;           // wave-uniform
         if (reread) ++*reread;
@@ -156,7 +168,8 @@ __device__ __forceinline__ void queue_publish(unsigned int* flags, size_t g, uns
     if (lane == 0) __hip_atomic_fetch_max(&flags[g], (poisoned ? Q_POISON : 0u) | (p + 1u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 // The forms for state that travels in tagged words (stw_store / stw_load): the flag only says "worth looking" and carries the poison mark, the data
-// validates itself — relaxed accesses, no cache maintenance.  (s_waitcnt: the flag is not raised before the stores have left the wavefront.)
+// validates itself — relaxed accesses, no cache maintenance, and the publisher does not wait for its stores either (21-48 K cycles per task while
+// they drained): a reader that arrives before the last word re-reads.
 __device__ __forceinline__ bool queue_wait_rlx(unsigned int* flags, size_t g, unsigned int p, int spin_limit) {
     if (p == 0) return false;
     int spins = 0;
@@ -169,7 +182,6 @@ __device__ __forceinline__ bool queue_wait_rlx(unsigned int* flags, size_t g, un
     }
 }
 __device__ __forceinline__ void queue_publish_rlx(unsigned int* flags, size_t g, unsigned int p, bool poisoned, unsigned lane) {
-    __builtin_amdgcn_s_waitcnt(0);
     if (lane == 0) __hip_atomic_fetch_max(&flags[g], (poisoned ? Q_POISON : 0u) | (p + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void gt_poison(uint8_t* o576, int role) {
@@ -315,7 +327,7 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
                                                  uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter, int spin_limit, uint32_t epoch,
                                                  fp4& H, unsigned long long* stamps = nullptr, unsigned long long* wstats = nullptr) {
     queue_wave_stats ws(wstats);
-    unsigned long long* const stw = reinterpret_cast<unsigned long long*>(state);
+    uint8_t* const stw = reinterpret_cast<uint8_t*>(state);
     const unsigned lane = threadIdx.x & 63u;
     const unsigned trip = lane / 3u;
     tri t;
@@ -369,7 +381,7 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
         bool poisoned = queue_wait_rlx(flags, g, p, spin_limit);
         ws.wait_done();
         if (stamps) ts_start = __builtin_amdgcn_s_memtime();
-        unsigned long long* st = stw + (g - ndirect) * (size_t)STW_ROWS * 64;        // only the queued groups own a state block (pair_queue_setup)
+        uint8_t* st = wave_uniform(stw + (g - ndirect) * PAIR_QUEUE_STATE_BYTES);        // only the queued groups own a state block (pair_queue_setup)
         const uint32_t tag_in = st_tag(epoch, p - 1u), tag_out = st_tag(epoch, p);     // F always comes from the phase before
         if (!poisoned && p < MILLER_TASKS) {
             fp px, py, px2, py2; fp2 qx, qy, qx2, qy2; bool pinf, qinf, pinf2 = true, qinf2 = true, ok, okb = true;
@@ -394,9 +406,9 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
                 slot_store(H, one);
             } else {
                 fp4 f;
-                bool got = stw_load<fp4, ST_DW_F>(f, st + STW_F * 64, lane, tag_in, spin_limit);
-                got = stw_load<fp2, ST_DW_TC>(tc, st + STW_TC1 * 64, lane, tag_in, spin_limit) && got;
-                if (EQ) got = stw_load<fp2, ST_DW_TC>(tc2, st + STW_TC2 * 64, lane, tag_in, spin_limit) && got;
+                bool got = stw_load<fp4, ST_DW_F>(f, st + STW_F * 1024, lane, tag_in, spin_limit);
+                got = stw_load<fp2, ST_DW_TC>(tc, st + STW_TC1 * 1024, lane, tag_in, spin_limit) && got;
+                if (EQ) got = stw_load<fp2, ST_DW_TC>(tc2, st + STW_TC2 * 1024, lane, tag_in, spin_limit) && got;
                 poisoned = !got;
                 slot_store(H, f);
             }
@@ -410,28 +422,28 @@ __device__ __forceinline__ void pair3_queue_body(size_t n, const uint8_t* a1, co
                 {
                     fp4 f;
                     slot_load(f, H);
-                    stw_store<fp4, ST_DW_F>(st + STW_F * 64, lane, f, tag_out);
+                    stw_store<fp4, ST_DW_F>(st + STW_F * 1024, lane, f, tag_out);
                 }
                 if (p < MILLER_TASKS - 1) {
-                    stw_store<fp2, ST_DW_TC>(st + STW_TC1 * 64, lane, tc, tag_out);
-                    if (EQ) stw_store<fp2, ST_DW_TC>(st + STW_TC2 * 64, lane, tc2, tag_out);
+                    stw_store<fp2, ST_DW_TC>(st + STW_TC1 * 1024, lane, tc, tag_out);
+                    if (EQ) stw_store<fp2, ST_DW_TC>(st + STW_TC2 * 1024, lane, tc2, tag_out);
                 }
             }
         } else if (!poisoned) {
             const int step = (int)(p - MILLER_TASKS);
             fp4 r, y1, aux;                              // aux shares the rows of the (finished) running points
-            bool got = stw_load<fp4, ST_DW_F>(r, st + STW_F * 64, lane, tag_in, spin_limit);
-            if (step >= 1) got = stw_load<fp4, ST_DW_F>(y1, st + STW_Y1 * 64, lane, st_tag(epoch, MILLER_TASKS), spin_limit) && got;       // written by step 0
-            if (step == 5) got = stw_load<fp4, ST_DW_F>(aux, st + STW_TC1 * 64, lane, st_tag(epoch, MILLER_TASKS + 4u), spin_limit) && got;  // written by step 4
+            bool got = stw_load<fp4, ST_DW_F>(r, st + STW_F * 1024, lane, tag_in, spin_limit);
+            if (step >= 1) got = stw_load<fp4, ST_DW_F>(y1, st + STW_Y1 * 1024, lane, st_tag(epoch, MILLER_TASKS), spin_limit) && got;       // written by step 0
+            if (step == 5) got = stw_load<fp4, ST_DW_F>(aux, st + STW_TC1 * 1024, lane, st_tag(epoch, MILLER_TASKS + 4u), spin_limit) && got;  // written by step 4
             poisoned = !got;
             ws.loaded();
             if (!poisoned) {
                 f12t_final_exp_step(step, r, y1, aux, H, t);
                 ws.computed();
                 if (step < 5) {
-                    stw_store<fp4, ST_DW_F>(st + STW_F * 64, lane, r, tag_out);
-                    if (step == 0) stw_store<fp4, ST_DW_F>(st + STW_Y1 * 64, lane, y1, tag_out);
-                    if (step == 4) stw_store<fp4, ST_DW_F>(st + STW_TC1 * 64, lane, aux, tag_out);
+                    stw_store<fp4, ST_DW_F>(st + STW_F * 1024, lane, r, tag_out);
+                    if (step == 0) stw_store<fp4, ST_DW_F>(st + STW_Y1 * 1024, lane, y1, tag_out);
+                    if (step == 4) stw_store<fp4, ST_DW_F>(st + STW_TC1 * 1024, lane, aux, tag_out);
                 } else {
                     // validity of this lane's inputs (cheap next to the arithmetic; keeps the state slab free of flags)
                     fp px, py; fp2 qx, qy; bool pinf, qinf, ok, okb = true;
@@ -491,7 +503,7 @@ __device__ __forceinline__ void split3_queue_body(size_t n, const uint8_t* in1, 
                                                   unsigned int* flags, unsigned int* counter, int spin_limit, uint32_t epoch, fp4& H,
                                                   unsigned long long* wstats) {
     queue_wave_stats ws(wstats);
-    unsigned long long* const stw = reinterpret_cast<unsigned long long*>(state);
+    uint8_t* const stw = reinterpret_cast<uint8_t*>(state);
     const unsigned lane = threadIdx.x & 63u;
     const unsigned trip = lane / 3u;
     tri t;
@@ -540,7 +552,7 @@ __device__ __forceinline__ void split3_queue_body(size_t n, const uint8_t* in1, 
         ws.mark();
         bool poisoned = queue_wait_rlx(flags, g, p, spin_limit);
         ws.wait_done();
-        unsigned long long* st = stw + (g - ndirect) * (size_t)STW_ROWS * 64;
+        uint8_t* st = wave_uniform(stw + (g - ndirect) * PAIR_QUEUE_STATE_BYTES);
         const uint32_t tag_in = st_tag(epoch, p - 1u), tag_out = st_tag(epoch, p);
         if (!poisoned && MILLER) {
             fp px, py; fp2 qx, qy; bool pinf, qinf, ok;
@@ -556,8 +568,8 @@ __device__ __forceinline__ void split3_queue_body(size_t n, const uint8_t* in1, 
                 slot_store(H, one);
             } else {
                 fp4 f;
-                bool got = stw_load<fp4, ST_DW_F>(f, st + STW_F * 64, lane, tag_in, spin_limit);
-                got = stw_load<fp2, ST_DW_TC>(tc, st + STW_TC1 * 64, lane, tag_in, spin_limit) && got;
+                bool got = stw_load<fp4, ST_DW_F>(f, st + STW_F * 1024, lane, tag_in, spin_limit);
+                got = stw_load<fp2, ST_DW_TC>(tc, st + STW_TC1 * 1024, lane, tag_in, spin_limit) && got;
                 poisoned = !got;
                 slot_store(H, f);
             }
@@ -575,8 +587,8 @@ __device__ __forceinline__ void split3_queue_body(size_t n, const uint8_t* in1, 
                 } else {
                     fp4 f;
                     slot_load(f, H);
-                    stw_store<fp4, ST_DW_F>(st + STW_F * 64, lane, f, tag_out);
-                    stw_store<fp2, ST_DW_TC>(st + STW_TC1 * 64, lane, tc, tag_out);
+                    stw_store<fp4, ST_DW_F>(st + STW_F * 1024, lane, f, tag_out);
+                    stw_store<fp2, ST_DW_TC>(st + STW_TC1 * 1024, lane, tc, tag_out);
                 }
             }
         } else if (!poisoned) {
@@ -584,18 +596,18 @@ __device__ __forceinline__ void split3_queue_body(size_t n, const uint8_t* in1, 
             fp4 r, y1, aux;
             bool got = true;
             if (step == 0) gt_load_coeff(r, in1 + 576 * i, t.role);
-            else got = stw_load<fp4, ST_DW_F>(r, st + STW_F * 64, lane, tag_in, spin_limit, &ws.reread);
-            if (step >= 1) got = stw_load<fp4, ST_DW_F>(y1, st + STW_Y1 * 64, lane, st_tag(epoch, 0u), spin_limit) && got;      // written by step 0
-            if (step == 5) got = stw_load<fp4, ST_DW_F>(aux, st + STW_TC1 * 64, lane, st_tag(epoch, 4u), spin_limit) && got;    // written by step 4
+            else got = stw_load<fp4, ST_DW_F>(r, st + STW_F * 1024, lane, tag_in, spin_limit, &ws.reread);
+            if (step >= 1) got = stw_load<fp4, ST_DW_F>(y1, st + STW_Y1 * 1024, lane, st_tag(epoch, 0u), spin_limit) && got;      // written by step 0
+            if (step == 5) got = stw_load<fp4, ST_DW_F>(aux, st + STW_TC1 * 1024, lane, st_tag(epoch, 4u), spin_limit) && got;    // written by step 4
             poisoned = !got;
             ws.loaded();
             if (!poisoned) {
                 f12t_final_exp_step(step, r, y1, aux, H, t);
                 ws.computed();
                 if (step < 5) {
-                    stw_store<fp4, ST_DW_F>(st + STW_F * 64, lane, r, tag_out);
-                    if (step == 0) stw_store<fp4, ST_DW_F>(st + STW_Y1 * 64, lane, y1, tag_out);
-                    if (step == 4) stw_store<fp4, ST_DW_F>(st + STW_TC1 * 64, lane, aux, tag_out);
+                    stw_store<fp4, ST_DW_F>(st + STW_F * 1024, lane, r, tag_out);
+                    if (step == 0) stw_store<fp4, ST_DW_F>(st + STW_Y1 * 1024, lane, y1, tag_out);
+                    if (step == 4) stw_store<fp4, ST_DW_F>(st + STW_TC1 * 1024, lane, aux, tag_out);
                 } else if (active) gt_store_coeff(out + 576 * e, r, t.role);
             }
         }
@@ -656,7 +668,7 @@ template <bool TWO>
 __device__ __forceinline__ void pair3_fixed_queue_body(size_t n, const uint8_t* a96, const uint8_t* c96, const int32_t* tabw, const int32_t* tabg,
                                                        uint8_t* out, int* bad_flag, uint4* state, unsigned int* flags, unsigned int* counter,
                                                        int spin_limit, uint32_t epoch, bool table_ok, fp4& H) {
-    unsigned long long* const stw = reinterpret_cast<unsigned long long*>(state);
+    uint8_t* const stw = reinterpret_cast<uint8_t*>(state);
     const unsigned lane = threadIdx.x & 63u;
     const unsigned trip = lane / 3u;
     tri t;
@@ -712,7 +724,7 @@ __device__ __forceinline__ void pair3_fixed_queue_body(size_t n, const uint8_t* 
         const bool active = lane < 63u && e < n;
         const size_t i = e < n ? e : n - 1;
         bool poisoned = queue_wait_rlx(flags, g, p, spin_limit);
-        unsigned long long* st = stw + (g - ndirect) * (size_t)STW_ROWS * 64;        // only the queued groups own a state block (pair_queue_setup)
+        uint8_t* st = wave_uniform(stw + (g - ndirect) * PAIR_QUEUE_STATE_BYTES);        // only the queued groups own a state block (pair_queue_setup)
         const uint32_t tag_in = st_tag(epoch, p - 1u), tag_out = st_tag(epoch, p);
         fp ax, ay, cx, cy; bool ainf, cinf = true, oka, okc = true;
         if (!poisoned && (p < MILLER_TASKS || p == TASKS - 1)) {
@@ -726,7 +738,7 @@ __device__ __forceinline__ void pair3_fixed_queue_body(size_t n, const uint8_t* 
         if (!poisoned && p < MILLER_TASKS) {
             {
                 fp4 f;
-                if (p == 0) f12t_one(f, t); else poisoned = !stw_load<fp4, ST_DW_F>(f, st + STW_F * 64, lane, tag_in, spin_limit);
+                if (p == 0) f12t_one(f, t); else poisoned = !stw_load<fp4, ST_DW_F>(f, st + STW_F * 1024, lane, tag_in, spin_limit);
                 slot_store(H, f);
             }
             if (!poisoned) {
@@ -736,21 +748,21 @@ __device__ __forceinline__ void pair3_fixed_queue_body(size_t n, const uint8_t* 
                 if (p == MILLER_TASKS - 1) f12t_conj_h(H, t);
                 fp4 f;
                 slot_load(f, H);
-                stw_store<fp4, ST_DW_F>(st + STW_F * 64, lane, f, tag_out);
+                stw_store<fp4, ST_DW_F>(st + STW_F * 1024, lane, f, tag_out);
             }
         } else if (!poisoned) {
             const int step = (int)(p - MILLER_TASKS);
             fp4 r, y1, aux;
-            bool got = stw_load<fp4, ST_DW_F>(r, st + STW_F * 64, lane, tag_in, spin_limit);
-            if (step >= 1) got = stw_load<fp4, ST_DW_F>(y1, st + STW_Y1 * 64, lane, st_tag(epoch, MILLER_TASKS), spin_limit) && got;       // written by step 0
-            if (step == 5) got = stw_load<fp4, ST_DW_F>(aux, st + STW_TC1 * 64, lane, st_tag(epoch, MILLER_TASKS + 4u), spin_limit) && got;  // written by step 4
+            bool got = stw_load<fp4, ST_DW_F>(r, st + STW_F * 1024, lane, tag_in, spin_limit);
+            if (step >= 1) got = stw_load<fp4, ST_DW_F>(y1, st + STW_Y1 * 1024, lane, st_tag(epoch, MILLER_TASKS), spin_limit) && got;       // written by step 0
+            if (step == 5) got = stw_load<fp4, ST_DW_F>(aux, st + STW_TC1 * 1024, lane, st_tag(epoch, MILLER_TASKS + 4u), spin_limit) && got;  // written by step 4
             poisoned = !got;
             if (!poisoned) {
                 f12t_final_exp_step(step, r, y1, aux, H, t);
                 if (step < 5) {
-                    stw_store<fp4, ST_DW_F>(st + STW_F * 64, lane, r, tag_out);
-                    if (step == 0) stw_store<fp4, ST_DW_F>(st + STW_Y1 * 64, lane, y1, tag_out);
-                    if (step == 4) stw_store<fp4, ST_DW_F>(st + STW_TC1 * 64, lane, aux, tag_out);
+                    stw_store<fp4, ST_DW_F>(st + STW_F * 1024, lane, r, tag_out);
+                    if (step == 0) stw_store<fp4, ST_DW_F>(st + STW_Y1 * 1024, lane, y1, tag_out);
+                    if (step == 4) stw_store<fp4, ST_DW_F>(st + STW_TC1 * 1024, lane, aux, tag_out);
                 } else if (TWO) {
                     const bool one = f12t_is_one(r, t);
                     const bool valid = oka && okc;
