@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_kernel(size_t n, const uint8_t
     tri t; size_t i; bool active;
     tri_setup(t, i, active, n);
     __shared__ fp4_slot slots[BLOCK];
-    slot_fair_set(slots[threadIdx.x].v, 1);                      // plain grid: the two wavefronts of a SIMD take turns (pairing3.hpp C12381_FAIR_SHARE)
+    slot_fair_set(slots[threadIdx.x].v, 8);                      // plain grid: the two wavefronts of a SIMD take turns (pairing3.hpp C12381_FAIR_SHARE)
     pair3_whole_group<false>(i, active, g1, g2, nullptr, nullptr, 0, gt, bad_flag, slots[threadIdx.x].v, t);
 }
 
@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_eq_kernel(size_t n, const uint
     tri t; size_t i; bool active;
     tri_setup(t, i, active, n);
     __shared__ fp4_slot slots[BLOCK];
-    slot_fair_set(slots[threadIdx.x].v, 1);                      // plain grid: the two wavefronts of a SIMD take turns (pairing3.hpp C12381_FAIR_SHARE)
+    slot_fair_set(slots[threadIdx.x].v, 8);                      // plain grid: the two wavefronts of a SIMD take turns (pairing3.hpp C12381_FAIR_SHARE)
     pair3_whole_group<true>(i, active, a1, a2, b1, b2, b2_stride, out, bad_flag, slots[threadIdx.x].v, t);
 }
 
@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(BLOCK, 2) pair3_prod_kernel(size_t n, int k, c
     tri t; size_t i; bool active;
     tri_setup(t, i, active, n);
     __shared__ fp4_slot slots[BLOCK];
-    slot_fair_set(slots[threadIdx.x].v, 1);                      // plain grid: the two wavefronts of a SIMD take turns (pairing3.hpp C12381_FAIR_SHARE)
+    slot_fair_set(slots[threadIdx.x].v, 8);                      // plain grid: the two wavefronts of a SIMD take turns (pairing3.hpp C12381_FAIR_SHARE)
     fp4& H = slots[threadIdx.x].v;
     miller3_pair pr[MAX_PROD];
     bool ok = true;
@@ -620,13 +620,13 @@ __device__ __forceinline__ void split3_queue_body(size_t n, const uint8_t* in1, 
 __global__ void __launch_bounds__(BLOCK, 2) miller3_queue_kernel(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* out, int* bad_flag, uint4* state,
                                                               unsigned int* flags, unsigned int* counter, int spin_limit, unsigned int epoch, unsigned long long* wstats) {
     __shared__ fp4_slot slots[BLOCK];
-    slot_fair_set(slots[threadIdx.x].v, 0);
+    slot_fair_set(slots[threadIdx.x].v, 4);                      // a quarter of the younger wavefront's iterations at raised priority (pairing3.hpp C12381_FAIR_SHARE)
     split3_queue_body<true>(n, g1, g2, out, bad_flag, state, flags, counter, spin_limit, epoch, slots[threadIdx.x].v, wstats);
 }
 __global__ void __launch_bounds__(BLOCK, 2) fexp3_queue_kernel(size_t n, const uint8_t* in576, uint8_t* out, int* bad_flag, uint4* state,
                                                             unsigned int* flags, unsigned int* counter, int spin_limit, unsigned int epoch, unsigned long long* wstats) {
     __shared__ fp4_slot slots[BLOCK];
-    slot_fair_set(slots[threadIdx.x].v, 0);
+    slot_fair_set(slots[threadIdx.x].v, 4);
     split3_queue_body<false>(n, in576, nullptr, out, bad_flag, state, flags, counter, spin_limit, epoch, slots[threadIdx.x].v, wstats);
 }
 
@@ -810,7 +810,7 @@ __global__ void __launch_bounds__(BLOCK, 2) miller3_kernel(size_t n, const uint8
     pair_inputs(px, py, pinf, qx, qy, qinf, ok, g1 + 96 * i, g2 + 192 * i);
     if (!ok) { if (active) *bad_flag = 1; pinf = true; qinf = true; }
     __shared__ fp4_slot slots[BLOCK];
-    slot_fair_set(slots[threadIdx.x].v, 1);                      // plain grid: the two wavefronts of a SIMD take turns (pairing3.hpp C12381_FAIR_SHARE)
+    slot_fair_set(slots[threadIdx.x].v, 8);                      // plain grid: the two wavefronts of a SIMD take turns (pairing3.hpp C12381_FAIR_SHARE)
     fp4& H = slots[threadIdx.x].v;
     miller3_loop(H, px, py, pinf, qx, qy, qinf, t);
     if (active) {
@@ -826,7 +826,7 @@ __global__ void __launch_bounds__(BLOCK, 2) gt3_op_kernel(int op, size_t n, cons
     tri t; size_t i; bool active;
     tri_setup(t, i, active, n);
     __shared__ fp4_slot slots[BLOCK];
-    slot_fair_set(slots[threadIdx.x].v, 1);                      // plain grid: the two wavefronts of a SIMD take turns (pairing3.hpp C12381_FAIR_SHARE)
+    slot_fair_set(slots[threadIdx.x].v, 8);                      // plain grid: the two wavefronts of a SIMD take turns (pairing3.hpp C12381_FAIR_SHARE)
     fp4& H = slots[threadIdx.x].v;
     fp4 x, r;
     gt_load_coeff(x, a + 576 * i, t.role);

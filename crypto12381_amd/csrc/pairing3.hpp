@@ -74,17 +74,22 @@ C12381_HD int wave_uniform(int v) { return v; }
 // C12381_PHASE(): a scheduling fence.  The build schedules for instruction-level parallelism (build.py), and two independent Fp4
 // products in one routine are exactly what such a scheduler interleaves — doubling the live registers and spilling hundreds of
 // dwords.  The fence keeps the phases of a routine apart (no instruction crosses it), as a call boundary used to.
-// C12381_FAIR_SHARE(i, slot), once per iteration of the long loops, in the kernels that ask for it (slot_fair_set: the plain grids): the wavefront in
-// an ODD hardware slot of its SIMD raises its issue priority in every other iteration.  A SIMD serves the older of its two wavefronts first
-// whenever both can issue: the one in slot 0 ran a whole pairing in 15.0 M cycles, its partner in 37.7 M (tools/queue_whole_groups.py) — in a
-// launch that just fills the machine the partner then finishes alone, at the issue efficiency of a single wavefront.  Alternating the younger
-// one's priority evens the pair out: 2048 wavefronts of pairings 11.87 -> 11.35 ms.  NOT in the work-queue kernels: there the older wavefront's
-// head start is what the queued tasks fill, and a task holder that is held back stalls the wavefronts waiting for its hand-over (2^16
-// pairings 17.5 -> 20.3 ms with the alternation on; profiles/r04_ab_fair_share.txt).
+// C12381_FAIR_SHARE(i, slot), once per iteration of the long loops, in the kernels that ask for it (slot_fair_set(slot, k): k of every 16 iterations,
+// spread evenly): the wavefront in an ODD hardware slot of its SIMD raises its issue priority in those iterations.  A SIMD serves the older of its
+// two wavefronts first whenever both can issue: the one in slot 0 ran a whole pairing in 15.0 M cycles, its partner in 37.7 M (profiles/r04_ab_fair_share.txt).
+//   k = 8 in the PLAIN grids (every other iteration): in a launch that just fills the machine the younger wavefront otherwise finishes alone, at the issue
+//         efficiency of a single wavefront — 2048 wavefronts of pairings 11.87 -> 11.35 ms.
+//   k = 4 in the work-queue kernels of the Miller loop and of the final exponentiation alone (round 5): there the younger wavefront's one whole group
+//         spans the launch and the older ones run out of queue tasks 13 % before it ends (profiles/r05_queue_wave_stats.txt); a quarter of the
+//         iterations shifts enough issue slots to the younger one that both end together: Miller loop -1.6 ... -2.6 %, final exponentiation -1.7 %
+//         (profiles/r05_ab_queue_fair_share.txt).  The cliff is close: at 5 of 16 the pairing kernel loses 2 %, at 6 of 16 everything 5-13 % — a task
+//         holder that is held back stalls the wavefronts waiting for its hand-over (k = 8 there: 2^16 pairings 17.5 -> 20.3 ms, round 4) — so the
+//         pairing kernels (gain 0.4 %) stay at k = 0.
 #if defined(__HIP_DEVICE_COMPILE__)
 // (the conditions as scalars: on per-lane values the two branches become two exec-masked regions and BOTH s_setprio execute)
 #define C12381_FAIR_SHARE(i, slot) do { if ((__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1u) && __builtin_amdgcn_readfirstlane(slot_fair(slot)) != 0) { \
-        if (__builtin_amdgcn_readfirstlane((int)(i)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } } while (0)
+        if ((__builtin_bitreverse32((unsigned)__builtin_amdgcn_readfirstlane((int)(i))) >> 28) < (unsigned)__builtin_amdgcn_readfirstlane(slot_fair(slot))) \
+            __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } } while (0)
 #else
 #define C12381_FAIR_SHARE(i, slot) do { } while (0)
 #endif
@@ -111,7 +116,7 @@ C12381_HD void slot_load(fp4& r, const fp4& slot) { slot_rd(r, (const c12381_lds
 C12381_HD void slot_store(fp4& slot, const fp4& r) { slot_wr((c12381_lds_v4i*)(&slot), r); }
 C12381_HD void slot_unpark(fp4& r, const fp4& slot) { slot_rd(r, (const volatile c12381_lds_v4i*)(&slot)); }
 C12381_HD void slot_park(fp4& slot, const fp4& r) { slot_wr((volatile c12381_lds_v4i*)(&slot), r); }
-// the last row of the lane's pair_slot (pad[2]): "alternate the issue priority" (C12381_FAIR_SHARE); every kernel that declares slots sets it
+// the last row of the lane's pair_slot (pad[2]): in how many of every 16 iterations the younger wavefront raises its priority (C12381_FAIR_SHARE); every kernel that declares slots sets it
 typedef __attribute__((address_space(3))) int32_t c12381_lds_i32;
 C12381_HD void slot_fair_set(fp4& slot, int on) { ((volatile c12381_lds_i32*)(&slot))[72] = on; }
 C12381_HD int slot_fair(const fp4& slot) { return ((const volatile c12381_lds_i32*)(&slot))[72]; }
