@@ -34,7 +34,7 @@ FETCH_SIZE / WRITE_SIZE counter passes (profiles/traffic.json).  `hbm_roofline` 
 bytes / kernel time against 8 TB/s): evidence that the path is not memory bound.  Legs `g2_mul`, `miller`, `fexp` time the three
 remaining hot-path functions (PAIR_G2mul, PAIR_ate, PAIR_fexp) alone, each against the compiled reference on a sample.
 `roofline.issue` prices the kernel's vector-instruction count (SQ_INSTS_VALU pass, profiles/issue.json — a property of the build) at
-the clock the chip holds inside that kernel IN THIS RUN (one-lane probe beside the kernel, lib/libc12381_probe.so).
+the clock the chip holds inside that kernel IN THIS RUN (one sampling lane per XCD beside the kernel, lib/libc12381_probe.so).
 Only the parity / cpu_baseline legs touch oracle/: the compiled reference when oracle/_ref is present (`parity.pinned` true), else
 our C port — then every parity object says `"oracle": "port", "pinned": false`; nothing substitutes silently.
 """
@@ -167,17 +167,21 @@ def launch_ranks(ngpus: int) -> int:
 
 
 class ClockProbe:
-    """the clock the chip holds while fn() runs back to back: lib/libc12381_probe.so samples (s_memtime, s_memrealtime) from one lane on
-    a stream of its own (csrc/microbench/clock_probe.hip); median over the second half of the run"""
+    """the clock the chip holds while fn() runs back to back: lib/libc12381_probe.so samples (s_memtime, s_memrealtime) from one lane PER XCD on
+    a stream of its own (csrc/microbench/clock_probe.hip); per XCD the median over the second half of the run.  during() returns the MEAN over
+    the XCDs (a multi-round launch is dispatched to whichever XCD has room: the chip's throughput follows the sum of their clocks) and keeps
+    the per-XCD values in .last_xcd"""
 
     def __init__(self, dev_index, dev):
         path = os.path.join(ROOT, "crypto12381_amd", "lib", "libc12381_probe.so")
         self.lib = ctypes.CDLL(path) if os.path.exists(path) else None
         self.dev_index, self.dev = dev_index, dev
         self.nsamp, self.gap = 2500, 30                       # ~100 us per sample: 0.25 s
+        self.last_xcd = None
         if self.lib is not None:
             self.lib.c12381_probe_start.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
-            self.buf = torch.zeros(2 * self.nsamp, dtype=torch.int64, device=dev)
+            self.nx = self.lib.c12381_probe_xcc_max() if hasattr(self.lib, "c12381_probe_xcc_max") else 1
+            self.buf = torch.zeros(self.nx * (2 * self.nsamp + 2), dtype=torch.int64, device=dev)
 
     def during(self, fn, sync):
         if self.lib is None:
@@ -196,16 +200,23 @@ class ClockProbe:
         sync()
         el = time.perf_counter() - t0
         torch.cuda.synchronize(self.dev)
-        h = self.buf.cpu().numpy().reshape(self.nsamp, 2)
-        h = h[h[:, 1] != 0]
-        if len(h) < 16:
+        allx = self.buf.cpu().numpy().reshape(self.nx, 2 * self.nsamp + 2)
+        per = []
+        for row in allx:
+            k = int(row[1])
+            if row[0] == 0 or k < 16:
+                continue
+            h = row[2:2 + 2 * k].reshape(k, 2)
+            span = h[:, 1] - h[0, 1]                          # 100 MHz ticks since this sampler started
+            inrun = h[(span > 0.4 * el * 1e8) & (span < 0.95 * el * 1e8)]
+            if len(inrun) < 8:
+                continue
+            ghz = np.diff(inrun[:, 0]) / np.maximum(np.diff(inrun[:, 1]), 1) * 0.1
+            per.append(float(np.median(ghz)))
+        if not per:
             return None
-        span = h[:, 1] - h[0, 1]                              # 100 MHz ticks since the probe started
-        inrun = h[(span > 0.4 * el * 1e8) & (span < 0.95 * el * 1e8)]
-        if len(inrun) < 8:
-            return None
-        ghz = np.diff(inrun[:, 0]) / np.maximum(np.diff(inrun[:, 1]), 1) * 0.1
-        return float(np.median(ghz))
+        self.last_xcd = sorted(per)
+        return float(np.mean(per))
 
 
 def main():
@@ -315,9 +326,13 @@ def main():
     probe = None if args.no_clock_probe else ClockProbe(dev_index, dev)
     clocks = {}                                       # kernel name -> GHz held inside it in THIS run (rank 0 reports them)
 
+    xcd_clocks = {}                                   # kernel name -> (min, max) over the XCDs' samplers
+
     def probe_clock(name, fn):
         if probe is not None and rank == 0:
             clocks[name] = probe.during(fn, ctx.sync)
+            if clocks[name] and probe.last_xcd:
+                xcd_clocks[name] = (probe.last_xcd[0], probe.last_xcd[-1], len(probe.last_xcd))
 
     n = 1 << args.log2_batch
     # ---- synthetic inputs, resident in HBM before the timed region
@@ -713,10 +728,13 @@ def main():
                 insts = ik["valu_insts_per_launch"] * units / ik["units_per_launch"]
                 bound_s = insts * VALU_ISSUE_CYCLES / 1024 / (clk * 1e9)
                 # issue_secs: the launch time of the kernel the instructions were counted in, where `secs` is a longer time base (BBS+: the pipeline)
+                xc = xcd_clocks.get(clock_key or kernel)
                 d["issue"] = {"valu_insts": insts, "clock_GHz_in_run": clk, "issue_ms": bound_s * 1e3, "issue_over_launch": bound_s / (issue_secs or secs),
                               # the REFERENCE's work per issued lane-instruction — not the share of multiply-adds in the
                               # stream (that is 0.69-0.85, profiles/r05_isa_classes_*.txt)
                               "ref_mac32_per_inst": mac_per_unit * units / 64 / insts}
+                if head and xc:                                # the two headline kernels: the spread of the XCDs' clocks (the legs' lines stay short)
+                    d["issue"]["xcd_clock_min_max"] = [xc[0], xc[1]]
             elif ik:
                 d["issue"] = {"valu_insts": ik["valu_insts_per_launch"] * units / ik["units_per_launch"], "clock_GHz_in_run": None}
             d.update(more)
@@ -924,7 +942,7 @@ def main():
                         "issue rate measured in-kernel (62.06 lanes/clk/CU x 256 CUs x 2.4 GHz; theoretical 64); hbm_GBs = algorithmic bytes / same "
                         "time (peak 8000); traffic = FETCH_SIZE x2 + WRITE_SIZE passes (profiles/traffic.json)",
             "issue": "issue_ms = SQ_INSTS_VALU per launch of this build (profiles/issue.json) x 4.06 cycles / 1024 SIMDs / the clock held inside the "
-                     "kernel in THIS run (one-lane probe); ref_mac32_per_inst = the reference's MAC32 per issued lane-instruction",
+                     "kernel in THIS run (one sampling lane per XCD, mean; xcd_clock_min_max = their spread); ref_mac32_per_inst = the reference's MAC32 per issued lane-instruction",
             "bbs_plus": "MAC32 = the pipeline's own op sequence (wire leg: + decode of A); reference_sequence_gmac32_per_s prices the reference's "
                         "sequence over this wall time",
             "cpu_baseline": "%s, %d host threads, same inputs; samples under 2 s: median of 3; one_thread = 1 thread on its own sample, eff_cores = "
