@@ -733,7 +733,7 @@ def main():
                               # the REFERENCE's work per issued lane-instruction — not the share of multiply-adds in the
                               # stream (that is 0.69-0.85, profiles/r05_isa_classes_*.txt)
                               "ref_mac32_per_inst": mac_per_unit * units / 64 / insts}
-                if head and xc:                                # the two headline kernels: the spread of the XCDs' clocks (the legs' lines stay short)
+                if head and xc and kernel == "g1_mul_kernel":     # the headline kernel: the spread of the XCDs' clocks (the legs' lines stay short)
                     d["issue"]["xcd_clock_min_max"] = [xc[0], xc[1]]
             elif ik:
                 d["issue"] = {"valu_insts": ik["valu_insts_per_launch"] * units / ik["units_per_launch"], "clock_GHz_in_run": None}
@@ -759,7 +759,7 @@ def main():
                 raise SystemExit("bench: CPU baseline output differs from the GPU output")
             g1_checked = sample + len(idx)
             result["cpu_baseline"] = {"value": sample / cpu_s, "unit": "scalar-muls/s", "cores": cores, "kind": kind,
-                                      "sample": "first %d lanes; every lane equal to the GPU output" % sample,
+                                      "sample": "first %d lanes; all equal" % sample,
                                       "one_thread": 4096 / cpu1_s, "eff_cores": (sample / cpu_s) / (4096 / cpu1_s)}
         result["parity"] = par(checked_lanes=g1_checked)
 
@@ -797,7 +797,7 @@ def main():
                 _, cm1_s = cpu_time(lambda: orc.g1_msm(pts_h[:4096].tobytes(), msm["scalars"][:4096].tobytes(), 96, 1))
                 if cpu_m != ctx.g1_msm(pts_h[:sm].tobytes(), msm["scalars"][:sm].tobytes(), 96):
                     raise SystemExit("bench: CPU MSM baseline differs from the GPU product of the same sample")
-                result["msm"]["cpu_baseline"] = cpu_b(sm / cm_s, "terms/s", "first 2^15 terms (ECP_muln); equals the GPU's", 4096 / cm1_s)
+                result["msm"]["cpu_baseline"] = cpu_b(sm / cm_s, "terms/s", "first 2^15 terms (ECP_muln); equal", 4096 / cm1_s)
             if "sharded" in msm:
                 sh = msm["sharded"]
                 if not sh["same_on_every_rank"] or sh["equals_single_gpu"] is False:
@@ -867,7 +867,7 @@ def main():
                      "workload": workload, "parity": parity,
                      "roofline": valu(mac, units / lps, k_s, kernel, tr, nbytes, clock_key, units_per_launch=units / lps)}
                 if do_cpu:
-                    d["cpu_baseline"] = cpu_b(ns / cpu_s, unit, "first %d lanes of the same batch" % ns, one)
+                    d["cpu_baseline"] = cpu_b(ns / cpu_s, unit, "first %d lanes" % ns, one)
                 return d
             result["g2_mul"] = leg("G2 scalar-muls/s per MI355X (batch 2^%d per GPU), bit-exact vs CPU" % args.log2_g2, "scalar-muls/s", ng2, split["g2_el"],
                                    split["g2k"], MAC32_G2_MUL, BYTES_G2_MUL, "g2_mul2_kernel",
@@ -920,13 +920,13 @@ def main():
                 if cpu_ok != bbs["ok"][sl].tobytes():
                     raise SystemExit("bench: CPU BBS+ verdicts differ from the GPU verdicts")
                 result["bbs_plus"]["parity"].update(par(oracle_lanes=int(len(sl))))
-                result["bbs_plus"]["cpu_baseline"] = cpu_b(len(sl) / cb_s, "verifications/s", "%d signatures incl. corrupted ones; verdicts equal the GPU's" % len(sl), cb_one)
+                result["bbs_plus"]["cpu_baseline"] = cpu_b(len(sl) / cb_s, "verifications/s", "%d signatures incl. corrupted; verdicts equal" % len(sl), cb_one)
                 cpu_okw, cw_s = cpu_time(lambda: orc.bbs_plus_verify_wire(wr["pp"], wr["h49"], wr["pk"], wr["sig"][sl].tobytes(), wr["raw"][sl].tobytes(), BBS_MSG_LEN, cores))
                 cw_one = len(s1) / cpu_time(lambda: orc.bbs_plus_verify_wire(wr["pp"], wr["h49"], wr["pk"], wr["sig"][s1].tobytes(), wr["raw"][s1].tobytes(), BBS_MSG_LEN, 1))[1]
                 if cpu_okw != wr["ok"][sl].tobytes():
                     raise SystemExit("bench: CPU wire-format BBS+ verdicts differ from the GPU verdicts")
                 result["bbs_plus_wire"]["parity"].update(par(oracle_lanes=int(len(sl))))
-                result["bbs_plus_wire"]["cpu_baseline"] = cpu_b(len(sl) / cw_s, "verifications/s", "the same %d signatures from their bytes; verdicts equal the GPU's" % len(sl), cw_one)
+                result["bbs_plus_wire"]["cpu_baseline"] = cpu_b(len(sl) / cw_s, "verifications/s", "the same %d from their bytes; verdicts equal" % len(sl), cw_one)
             if "sharded" in bbs:
                 sh = bbs["sharded"]
                 if sh["accepted"] != sh["expected_accepted"]:
@@ -938,15 +938,14 @@ def main():
         if extras:
             result["extra_configs"] = extras
         result["notes"] = {
-            "roofline": "int-valu binds: SURVEY 8(d) 32x32 multiply-adds / avg launch time (HIP events on the library's stream) vs the v_mad_i64_i32 "
-                        "issue rate measured in-kernel (62.06 lanes/clk/CU x 256 CUs x 2.4 GHz; theoretical 64); hbm_GBs = algorithmic bytes / same "
-                        "time (peak 8000); traffic = FETCH_SIZE x2 + WRITE_SIZE passes (profiles/traffic.json)",
-            "issue": "issue_ms = SQ_INSTS_VALU per launch of this build (profiles/issue.json) x 4.06 cycles / 1024 SIMDs / the clock held inside the "
-                     "kernel in THIS run (one sampling lane per XCD, mean; xcd_clock_min_max = their spread); ref_mac32_per_inst = the reference's MAC32 per issued lane-instruction",
-            "bbs_plus": "MAC32 = the pipeline's own op sequence (wire leg: + decode of A); reference_sequence_gmac32_per_s prices the reference's "
-                        "sequence over this wall time",
-            "cpu_baseline": "%s, %d host threads, same inputs; samples under 2 s: median of 3; one_thread = 1 thread on its own sample, eff_cores = "
-                            "value / one_thread" % ("oracle/_ref = the reference's sources compiled here" if pinned else "C port (oracle/_ref absent)", cores),
+            "roofline": "int-valu binds: SURVEY 8(d) MAC32 / avg launch time (HIP events, the library's stream) vs the v_mad_i64_i32 issue rate measured "
+                        "in-kernel (62.06 lanes/clk/CU x 256 CUs x 2.4 GHz; theoretical 64); hbm_GBs = algorithmic bytes / same time (peak 8000); "
+                        "traffic = FETCH_SIZE x2 + WRITE_SIZE passes (profiles/traffic.json)",
+            "issue": "issue_ms = SQ_INSTS_VALU per launch (profiles/issue.json) x 4.06 cycles / 1024 SIMDs / the clock held inside the kernel in THIS "
+                     "run (one sampling lane per XCD, mean; xcd_clock_min_max = their spread); ref_mac32_per_inst = reference MAC32 per issued lane-instruction",
+            "bbs_plus": "MAC32 = the pipeline's own op sequence (wire leg: + decode of A); reference_sequence_gmac32_per_s: the reference's sequence over this time",
+            "cpu_baseline": "%s, %d host threads, same inputs; samples under 2 s: median of 3; one_thread: own sample; eff_cores = value / one_thread"
+                            % ("oracle/_ref = the reference's sources compiled here" if pinned else "C port (oracle/_ref absent)", cores),
         }
         # the pairing leg goes LAST: the second half of BASELINE's metric survives any truncation of the line's head
         if pair is not None:
@@ -961,7 +960,7 @@ def main():
                 "roofline": valu(MAC32_PAIRING, npair, avg_s, kname, pair_traffic, BYTES_PAIRING, "pair", head=True),
             }
             if do_cpu:
-                result["pairing"]["cpu_baseline"] = cpu_b(ps / cpu_ps, "pairings/s", ("the whole batch of %d pairings; every lane bit-exact vs GPU" % ps) if full
+                result["pairing"]["cpu_baseline"] = cpu_b(ps / cpu_ps, "pairings/s", ("all %d pairings; every lane equal" % ps) if full
                                                           else "%d sampled lanes" % ps, pair_one, full_keys=True)
         line = json.dumps(compact(result), separators=(",", ":"))
         print(line, flush=True)

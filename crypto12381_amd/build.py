@@ -55,7 +55,7 @@ def unit_cflags(unit: str):
     if unit in DEFAULT_SCHED_UNITS:
         return [f for i, f in enumerate(CFLAGS) if "amdgpu-sched-strategy" not in f and not (f == "-mllvm" and "amdgpu-sched-strategy" in CFLAGS[i + 1])]
     return list(CFLAGS)
-# Round 2 reproduced the wrong-values event with a rebuilt variant: whole wavefront groups wrong, plain grid as
+# Round 2 reproduced the wrong-values event with a rebuilt variant (docs/lab_notes.md 5b): whole wavefront groups wrong, plain grid as
 # well as queue, only with -amdgpu-use-amdgpu-trackers=1; the same source without it is exact on every lane.  The option is
 # refused outright — in CFLAGS and in every environment variable through which hipcc / clang accept extra flags — and the
 # compiler the full-batch parity tests were run with is recorded: another one STOPS the build (3-4 % of every kernel hang on an LLVM-internal
@@ -89,7 +89,7 @@ def _check_flags() -> None:
     seen = " ".join(CFLAGS) + " " + " ".join(os.environ.get(k, "") for k in FLAG_ENV)
     for bad in FORBIDDEN_FLAGS:
         if bad in seen:
-            raise RuntimeError("build flag known to produce wrong pairings at full size: %s (DESIGN.md 5b) — found in CFLAGS or in one of %s"
+            raise RuntimeError("build flag known to produce wrong pairings at full size: %s (docs/lab_notes.md 5b) — found in CFLAGS or in one of %s"
                                % (bad, ", ".join(FLAG_ENV)))
 
 

@@ -1,4 +1,4 @@
-// What does an instruction cost a wavefront when it is mixed with the 64-bit multiply-adds?  (round 3)
+// What does an instruction cost a wavefront when it is mixed with the 64-bit multiply-adds?  (round 3, docs/lab_notes.md 5c)
 //
 // valu_rates.hip times streams of ONE instruction with events: 16 instructions per loop iteration, so the loop's own scalar
 // instructions (28-32 cycles per iteration) and the uneven arrival of the workgroups are part of its numbers.  This program counts

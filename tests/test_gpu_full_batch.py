@@ -33,7 +33,7 @@ def _oracle_kind():
 
 
 # The checker is named in the test id (…[oracle-reference] / …[oracle-port]) and a missing compiled reference is announced, not
-# substituted silently: these are the gates that guard the wrong-lanes event.  The C port is itself pinned to the compiled
+# substituted silently: these are the gates that guard the wrong-lanes event (docs/lab_notes.md 5b).  The C port is itself pinned to the compiled
 # reference byte for byte (tests/test_oracle_golden.py), so the gate still runs where oracle/_ref did not travel — but says so.
 @pytest.fixture(scope="module", params=[_oracle_kind()], ids=lambda k: "oracle-" + k)
 def orc(request):

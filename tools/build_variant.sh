@@ -10,7 +10,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/crypto12381_amd/lib/exp; OBJ=$OUT/obj_$NAME
 mkdir -p $OBJ
 FLAGS=${BASEFLAGS:-"-O3 --offload-arch=gfx950 -fPIC -std=c++17 -fno-optimize-sibling-calls -mllvm -amdgpu-sched-strategy=max-ilp -mllvm -opt-disable=reassociate"}
-for f in "$@"; do case "$f" in *amdgpu-use-amdgpu-trackers*) echo "refused: $f (DESIGN.md 5b)"; exit 2;; esac; done
+for f in "$@"; do case "$f" in *amdgpu-use-amdgpu-trackers*) echo "refused: $f (docs/lab_notes.md 5b)"; exit 2;; esac; done
 pids=""
 for u in c12381_hip k_g1 k_g2gt k_g2h k_pair3 k_hash_zp k_fixed; do
   UF=$FLAGS
