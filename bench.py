@@ -530,9 +530,11 @@ def main():
     bbs = None
     if not args.no_bbs:
         nb = 1 << args.log2_bbs
-        # public parameters and key (setup / key_gen, bbs+.cpp:7-36): group elements = multiples of the generators
-        pub = ctx.g1_mul_fixed(G1_GEN, reduced_scalars(5100, 3).tobytes(), 96)
-        pub_g1, pub_h0, pub_h = pub[:96], pub[96:192], pub[192:288]
+        # public parameters and key as setup(16) / key_gen make them (bbs+.cpp:7-36, examples/bbs-plus/test.cpp:11-14): g1, h0 and SIXTEEN h_i,
+        # multiples of the generators; one-block messages use h_1 only, the wire leg decodes all sixteen (pp.h)
+        BBS_NH = 16
+        pub = ctx.g1_mul_fixed(G1_GEN, reduced_scalars(5100, 2 + BBS_NH).tobytes(), 96)
+        pub_g1, pub_h0, pub_h, pub_h_all = pub[:96], pub[96:192], pub[192:288], pub[192:192 + 96 * BBS_NH]
         g2p = ctx.g2_mul_fixed(G2_GEN, reduced_scalars(5101, 1).tobytes(), 192)
         gamma = reduced_scalars(5102, 1).tobytes()
         w = ctx.g2_mul_fixed(g2p, gamma, 192)
@@ -587,7 +589,7 @@ def main():
         sig[:, 0:49] = A49.view(nb, 49); sig[:, 65:97] = dx.view(nb, 32); sig[:, 113:145] = dr.view(nb, 32)
         one1 = (1).to_bytes(32, "big")
         pp195 = ctx.g1_mul(pub_g1, one1, 49) + ctx.g2_mul(g2p, one1, 97) + ctx.g1_mul(pub_h0, one1, 49)
-        h49, pk97 = ctx.g1_mul(pub_h, one1, 49), ctx.g2_mul(w, one1, 97)
+        h49, pk97 = ctx.g1_mul(pub_h_all, one1 * BBS_NH, 49), ctx.g2_mul(w, one1, 97)
         dwire = [dev_bytes(b, dev) for b in (pp195, h49, pk97)]
         draw = torch.from_numpy(raw_h).to(dev)
         okw = torch.empty(nb, dtype=torch.uint8, device=dev)
@@ -595,7 +597,7 @@ def main():
         inputs_ready()                                      # sig was assembled by torch kernels on torch's stream
 
         def wire_step():
-            ctx.bbs_plus_verify_wire_dev(nb, 1, BBS_MSG_LEN, dwire[0].data_ptr(), dwire[1].data_ptr(), dwire[2].data_ptr(), sig.data_ptr(), draw.data_ptr(),
+            ctx.bbs_plus_verify_wire_dev(nb, BBS_NH, BBS_MSG_LEN, dwire[0].data_ptr(), dwire[1].data_ptr(), dwire[2].data_ptr(), sig.data_ptr(), draw.data_ptr(),
                                          okw.data_ptr())
         wire_step()
         torch.cuda.synchronize(dev)
@@ -889,7 +891,7 @@ def main():
             result["bbs_plus"] = {
                 "metric": "BBS+ signature verifications/s (2^%d per GPU, 1 message block), decoded inputs" % args.log2_bbs,
                 "value": world * nb / per, "unit": "verifications/s", "steps": bbs["steps"], "ms_per_step": per * 1e3,
-                "workload": "configs[4]: real signatures, every 1009th message corrupted",
+                "workload": "configs[4]: setup(16), 1-block messages, real signatures, every 1009th message corrupted",
                 "parity": {"check": "all verdicts equal the construction", "bit_exact": True},
                 # the pipeline's OWN operation sequence (tools/count_ops.py -> profiles/r03_op_counts.json) over the wall time of the whole pipeline
                 "roofline": valu(MAC32_BBS_PIPELINE, nb, per, "pair3_prod_fixed_queue_kernel", bbs_traffic, BYTES_BBS_VERIFY,

@@ -145,3 +145,11 @@ def test_every_lane_of_2_16_g2_multiplications_vs_oracle(ctx, orc):
     comp = np.frombuffer(ctx.g2_mul(pts, scb, 97), dtype=np.uint8).reshape(n, 97)
     expc = np.frombuffer(orc.g2_mul(pts, scb, 97, THREADS), dtype=np.uint8).reshape(n, 97)
     assert (comp == expc).all()
+
+
+def test_port_is_pinned_to_the_compiled_reference_on_this_box(oracle_port, oracle_ref):
+    """Most small -m gpu tests compare with the C restatement (oracle_port); its pin to the compiled reference on fresh inputs
+    (test_oracle_golden.py::test_port_matches_reference_on_fresh_inputs, a CPU test) is repeated here, in the GPU suite and on the GPU box's own
+    build of both checkers, so that every comparison of this run rests on the reference itself."""
+    from test_oracle_golden import test_port_matches_reference_on_fresh_inputs as pin
+    pin(oracle_port, oracle_ref)
