@@ -840,7 +840,9 @@ def main():
         # ---------------------------------------------------------------- G2 multiplication, Miller loop, final exponentiation alone
         if split is not None:
             npair, ng2, st = pair["npair"], split["ng2"], split["steps"]
-            ns = min(npair, (1 << 13) if do_cpu else (1 << 12))
+            # 2^15 lanes with the CPU baseline: shorter samples ride the host's CPU-quota burst (2^13 Miller loops in 0.2 s read 16 cores' worth, the
+            # final exponentiations behind them 2.8: profiles/r05_bench_final_box_slow.json)
+            ns = min(npair, (1 << 15) if do_cpu else (1 << 12))
             g2o_h = split["g2_out"].cpu().numpy().reshape(ng2, 192)
             g2i_h = split["g2_in"].cpu().numpy().reshape(ng2, 192)
             mil_h = split["mil"].cpu().numpy().reshape(npair, 576)
