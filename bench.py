@@ -255,6 +255,15 @@ def main():
                          % (args.gpus, world, world, args.gpus))
     # RCCL ("nccl") over xGMI on the GPU node; C12381_BENCH_BACKEND=gloo lets the N>1 path be rehearsed on one GPU
     backend = os.environ.get("C12381_BENCH_BACKEND", "nccl")
+    # CPU baseline workers: one PROCESS per host core, forked here — before anything in this process touches the GPU — so that no worker
+    # ever holds a HIP context.  Processes, not threads: MIRACL's constant-time moves advance a function-level static on every call
+    # (oracle/pool.py), which costs the reference's G1 / G2 / final-exponentiation paths half their rate across threads of one process.
+    from oracle.bindings import Oracle, have_reference
+    from oracle.pool import OraclePool, OracleThreads
+    kind = "reference" if have_reference() else "port"        # the compiled reference when it travelled with the snapshot, else the C port
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)   # the GPU box gives one GPU a 16-CPU share
+    do_cpu = world == 1 and not args.no_cpu_baseline
+    cpu_pool = OraclePool(kind, cores) if do_cpu else None
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     ndev = torch.cuda.device_count()
@@ -651,15 +660,12 @@ def main():
         ctx.sync()
 
     # ================================================================== parity and CPU baselines (outside every timed region)
-    from oracle.bindings import Oracle, have_reference
-    # the compiled reference when it travelled with the snapshot (oracle/_ref), else the C port — said on every parity object, never silent
-    kind = "reference" if have_reference() else "port"
+    # kind: the compiled reference (oracle/_ref) or the C port — said on every parity object, never silent
     pinned = kind == "reference"
     orc = Oracle(kind)
+    cpuN = cpu_pool if cpu_pool is not None else OracleThreads(orc, cores)      # `cores` workers: processes with the baseline, threads without
     if rank == 0 and not pinned:
         print("bench.py: oracle/_ref/libc12381_ref.so is absent: parity is checked against the C port (parity.pinned = false)", file=sys.stderr, flush=True)
-    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)   # the GPU box gives one GPU a 16-CPU share
-    do_cpu = world == 1 and not args.no_cpu_baseline
 
     def cpu_time(fn):
         """CPU legs: a sample shorter than 2 s rides the host's CPU-quota burst and then its throttle — such a sample is run three times and
@@ -673,7 +679,7 @@ def main():
                 return o, float(np.median(ts))
     pts_h = pts.cpu().numpy().reshape(n, 96)
     out_h = out.cpu().numpy().reshape(n, 96)
-    # G1: with the CPU baseline the first 2^16 lanes are compared in full, otherwise 64 sampled lanes incl. every edge lane
+    # G1: with the CPU baseline the first 2^17 lanes are compared in full, otherwise 64 sampled lanes incl. every edge lane
     idx = list(range(8)) + [int(x) for x in np.random.Generator(np.random.PCG64(7)).integers(0, n, size=56)]
     exp = orc.g1_mul(pts_h[idx].tobytes(), sc_h[idx].tobytes(), 96, min(cores, 8))
     if exp != out_h[idx].tobytes():
@@ -753,14 +759,14 @@ def main():
                              peak_theoretical=VALU_PEAK_THEORETICAL_MAC32 / 1e9),
         }
         if do_cpu:
-            sample = min(n, 1 << 16)
+            sample = min(n, 1 << 17)
             sp, ss = pts_h[:sample].tobytes(), sc_h[:sample].tobytes()
-            cpu_out, cpu_s = cpu_time(lambda: orc.g1_mul(sp, ss, 96, cores))
+            cpu_out, cpu_s = cpu_time(lambda: cpuN.g1_mul(sp, ss, 96))
             _, cpu1_s = cpu_time(lambda: orc.g1_mul(sp[:96 * 4096], ss[:32 * 4096], 96, 1))
             if cpu_out != out_h[:sample].tobytes():
                 raise SystemExit("bench: CPU baseline output differs from the GPU output")
             g1_checked = sample + len(idx)
-            result["cpu_baseline"] = {"value": sample / cpu_s, "unit": "scalar-muls/s", "cores": cores, "kind": kind,
+            result["cpu_baseline"] = {"value": sample / cpu_s, "unit": "scalar-muls/s", "cores": cores, "workers": "processes", "kind": kind,
                                       "sample": "first %d lanes; all equal" % sample,
                                       "one_thread": 4096 / cpu1_s, "eff_cores": (sample / cpu_s) / (4096 / cpu1_s)}
         result["parity"] = par(checked_lanes=g1_checked)
@@ -795,7 +801,7 @@ def main():
             }
             if do_cpu:
                 sm = 1 << 15
-                cpu_m, cm_s = cpu_time(lambda: orc.g1_msm(pts_h[:sm].tobytes(), msm["scalars"][:sm].tobytes(), 96, cores))
+                cpu_m, cm_s = cpu_time(lambda: cpuN.g1_msm(pts_h[:sm].tobytes(), msm["scalars"][:sm].tobytes(), 96))
                 _, cm1_s = cpu_time(lambda: orc.g1_msm(pts_h[:4096].tobytes(), msm["scalars"][:4096].tobytes(), 96, 1))
                 if cpu_m != ctx.g1_msm(pts_h[:sm].tobytes(), msm["scalars"][:sm].tobytes(), 96):
                     raise SystemExit("bench: CPU MSM baseline differs from the GPU product of the same sample")
@@ -819,7 +825,7 @@ def main():
             full = do_cpu and not args.sampled_parity
             pair_one = None
             if full:
-                cpu_gt, cpu_ps = cpu_time(lambda: orc.pair(p1_h.tobytes(), q2_h.tobytes(), cores))
+                cpu_gt, cpu_ps = cpu_time(lambda: cpuN.pair(p1_h.tobytes(), q2_h.tobytes()))
                 cpu_gt = np.frombuffer(cpu_gt, dtype=np.uint8).reshape(npair, 576)
                 k1 = min(npair, 512)
                 pair_one = k1 / cpu_time(lambda: orc.pair(p1_h[:k1].tobytes(), q2_h[:k1].tobytes(), 1))[1]
@@ -840,17 +846,16 @@ def main():
         # ---------------------------------------------------------------- G2 multiplication, Miller loop, final exponentiation alone
         if split is not None:
             npair, ng2, st = pair["npair"], split["ng2"], split["steps"]
-            # 2^15 lanes with the CPU baseline: shorter samples ride the host's CPU-quota burst (2^13 Miller loops in 0.2 s read 16 cores' worth, the
-            # final exponentiations behind them 2.8: profiles/r05_bench_final_box_slow.json)
+            # 2^15 lanes with the CPU baseline (seconds of CPU work per leg, not a burst)
             ns = min(npair, (1 << 15) if do_cpu else (1 << 12))
             g2o_h = split["g2_out"].cpu().numpy().reshape(ng2, 192)
             g2i_h = split["g2_in"].cpu().numpy().reshape(ng2, 192)
             mil_h = split["mil"].cpu().numpy().reshape(npair, 576)
             fex_h = split["fex"].cpu().numpy().reshape(npair, 576)
             # lanes 0..4 carry the edge scalars 0, 1, r - 1, r, 2^256 - 1
-            q_cpu, g2_s = cpu_time(lambda: orc.g2_mul(g2i_h[:ns].tobytes(), split["g2_sc_h"][:ns].tobytes(), 192, cores))
-            m_cpu, mil_s = cpu_time(lambda: orc.miller_t(p1_h[:ns].tobytes(), q2_h[:ns].tobytes(), cores))
-            f_cpu, fx_s = cpu_time(lambda: orc.fexp_t(m_cpu, cores))
+            q_cpu, g2_s = cpu_time(lambda: cpuN.g2_mul(g2i_h[:ns].tobytes(), split["g2_sc_h"][:ns].tobytes(), 192))
+            m_cpu, mil_s = cpu_time(lambda: cpuN.miller_t(p1_h[:ns].tobytes(), q2_h[:ns].tobytes()))
+            f_cpu, fx_s = cpu_time(lambda: cpuN.fexp_t(m_cpu))
             g2_one = mil_one = fx_one = None
             if do_cpu:                                             # one thread, own short samples
                 g2_one = 1024 / cpu_time(lambda: orc.g2_mul(g2i_h[:1024].tobytes(), split["g2_sc_h"][:1024].tobytes(), 192, 1))[1]
@@ -916,8 +921,8 @@ def main():
                 sb = 1 << 11
                 pg1, pg2, ph0, ph, pw = bbs["pub"]
                 sl = np.r_[0:sb - 64, nb - 64:nb]                       # includes corrupted lanes (7, 1016, ...)
-                cpu_ok, cb_s = cpu_time(lambda: orc.bbs_plus_verify(pg1, pg2, ph0, ph, pw, bbs["A"][sl].tobytes(), bbs["x"][sl].tobytes(), bbs["r"][sl].tobytes(),
-                                                                    bbs["m"][sl].tobytes(), cores))
+                cpu_ok, cb_s = cpu_time(lambda: cpuN.bbs_plus_verify(pg1, pg2, ph0, ph, pw, bbs["A"][sl].tobytes(), bbs["x"][sl].tobytes(), bbs["r"][sl].tobytes(),
+                                                                     bbs["m"][sl].tobytes()))
                 s1 = sl[:256]
                 cb_one = len(s1) / cpu_time(lambda: orc.bbs_plus_verify(pg1, pg2, ph0, ph, pw, bbs["A"][s1].tobytes(), bbs["x"][s1].tobytes(),
                                                                         bbs["r"][s1].tobytes(), bbs["m"][s1].tobytes(), 1))[1]
@@ -925,7 +930,7 @@ def main():
                     raise SystemExit("bench: CPU BBS+ verdicts differ from the GPU verdicts")
                 result["bbs_plus"]["parity"].update(par(oracle_lanes=int(len(sl))))
                 result["bbs_plus"]["cpu_baseline"] = cpu_b(len(sl) / cb_s, "verifications/s", "%d signatures incl. corrupted; verdicts equal" % len(sl), cb_one)
-                cpu_okw, cw_s = cpu_time(lambda: orc.bbs_plus_verify_wire(wr["pp"], wr["h49"], wr["pk"], wr["sig"][sl].tobytes(), wr["raw"][sl].tobytes(), BBS_MSG_LEN, cores))
+                cpu_okw, cw_s = cpu_time(lambda: cpuN.bbs_plus_verify_wire(wr["pp"], wr["h49"], wr["pk"], wr["sig"][sl].tobytes(), wr["raw"][sl].tobytes(), BBS_MSG_LEN))
                 cw_one = len(s1) / cpu_time(lambda: orc.bbs_plus_verify_wire(wr["pp"], wr["h49"], wr["pk"], wr["sig"][s1].tobytes(), wr["raw"][s1].tobytes(), BBS_MSG_LEN, 1))[1]
                 if cpu_okw != wr["ok"][sl].tobytes():
                     raise SystemExit("bench: CPU wire-format BBS+ verdicts differ from the GPU verdicts")
@@ -948,7 +953,7 @@ def main():
             "issue": "issue_ms = SQ_INSTS_VALU per launch (profiles/issue.json) x 4.06 cycles / 1024 SIMDs / the clock held inside the kernel in THIS "
                      "run (one sampling lane per XCD, mean; xcd_clock_min_max = their spread); ref_mac32_per_inst = reference MAC32 per issued lane-instruction",
             "bbs_plus": "MAC32 = the pipeline's own op sequence (wire leg: + decode of A); reference_sequence_gmac32_per_s: the reference's sequence over this time",
-            "cpu_baseline": "%s, %d host threads, same inputs; samples under 2 s: median of 3; one_thread: own sample; eff_cores = value / one_thread"
+            "cpu_baseline": "%s, %d worker processes (not threads: oracle/pool.py), same inputs; under 2 s: median of 3; eff_cores = value / one_thread (own sample)"
                             % ("oracle/_ref = the reference's sources compiled here" if pinned else "C port (oracle/_ref absent)", cores),
         }
         # the pairing leg goes LAST: the second half of BASELINE's metric survives any truncation of the line's head
@@ -968,6 +973,8 @@ def main():
                                                           else "%d sampled lanes" % ps, pair_one, full_keys=True)
         line = json.dumps(compact(result), separators=(",", ":"))
         print(line, flush=True)
+    if cpu_pool is not None:
+        cpu_pool.close()
     if dist:
         dist.barrier()
     ctx.close()
