@@ -763,12 +763,14 @@ def main():
             sp, ss = pts_h[:sample].tobytes(), sc_h[:sample].tobytes()
             cpu_out, cpu_s = cpu_time(lambda: cpuN.g1_mul(sp, ss, 96))
             _, cpu1_s = cpu_time(lambda: orc.g1_mul(sp[:96 * 4096], ss[:32 * 4096], 96, 1))
+            nt = 1 << 15                                           # BASELINE.md 3(b) as written: std::thread shards in ONE process
+            _, cput_s = cpu_time(lambda: orc.g1_mul(sp[:96 * nt], ss[:32 * nt], 96, cores))
             if cpu_out != out_h[:sample].tobytes():
                 raise SystemExit("bench: CPU baseline output differs from the GPU output")
             g1_checked = sample + len(idx)
             result["cpu_baseline"] = {"value": sample / cpu_s, "unit": "scalar-muls/s", "cores": cores, "workers": "processes", "kind": kind,
                                       "sample": "first %d lanes; all equal" % sample,
-                                      "one_thread": 4096 / cpu1_s, "eff_cores": (sample / cpu_s) / (4096 / cpu1_s)}
+                                      "one_thread": 4096 / cpu1_s, "eff_cores": (sample / cpu_s) / (4096 / cpu1_s), "threads_value": nt / cput_s}
         result["parity"] = par(checked_lanes=g1_checked)
 
         def cpu_b(v, unit, sample, one=None, full_keys=False):
