@@ -697,7 +697,7 @@ def main():
         launches_per_step = mul_launches / max(args.steps, 1)
         units_per_launch = n / max(launches_per_step, 1)
         avg_launch_s = (mul_ms / max(mul_launches, 1)) * 1e-3
-        traffic = pair_traffic = msm_traffic = bbs_traffic = g2_traffic = None
+        traffic = pair_traffic = msm_traffic = bbs_traffic = g2_traffic = mil_traffic = fex_traffic = None
         tr_path = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tr_path):
             try:
@@ -707,12 +707,15 @@ def main():
                     pair_traffic = tj["pair_kernel"]["hbm_bytes_per_launch"] * pair["npair"] / tj["pair_kernel"]["units_per_launch"]
                 if split is not None and "g2_mul2_kernel" in tj:
                     g2_traffic = tj["g2_mul2_kernel"]["hbm_bytes_per_launch"] / tj["g2_mul2_kernel"]["units_per_launch"]     # per point; scaled per launch below
+                if split is not None and pair is not None and "miller3_queue_kernel" in tj and "fexp3_queue_kernel" in tj:   # per launch of the pairing leg's batch
+                    mil_traffic = tj["miller3_queue_kernel"]["hbm_bytes_per_launch"] * pair["npair"] / tj["miller3_queue_kernel"]["units_per_launch"]
+                    fex_traffic = tj["fexp3_queue_kernel"]["hbm_bytes_per_launch"] * pair["npair"] / tj["fexp3_queue_kernel"]["units_per_launch"]
                 if msm is not None and "msm_bucket_kernel" in tj:
                     msm_traffic = tj["msm_bucket_kernel"]["hbm_bytes_per_launch"] * msm["n"] / tj["msm_bucket_kernel"]["units_per_launch"]
                 if bbs is not None and "pair3_prod_fixed_queue_kernel" in tj:
                     bbs_traffic = tj["pair3_prod_fixed_queue_kernel"]["hbm_bytes_per_launch"] * bbs["n"] / tj["pair3_prod_fixed_queue_kernel"]["units_per_launch"]
             except Exception:
-                traffic = pair_traffic = msm_traffic = bbs_traffic = g2_traffic = None
+                traffic = pair_traffic = msm_traffic = bbs_traffic = g2_traffic = mil_traffic = fex_traffic = None
 
         issue_json = {}
         try:
@@ -887,11 +890,11 @@ def main():
                                    None if g2_traffic is None else g2_traffic * ng2 / max(split["g2k"][1] / max(st, 1), 1), one=g2_one)
             result["miller"] = leg("Miller loops/s per MI355X (batch 2^%d per GPU), the reference's field element" % args.log2_pairings, "Miller loops/s", npair,
                                    split["mil_el"], split["milk"], MAC32_MILLER, 96 + 192 + 576, "miller3_queue_kernel" if queued else "miller3_kernel",
-                                   "PAIR_ate on the pairing leg's inputs", par(checked_lanes=ns, of=npair), mil_s, None, "miller", mil_one)
+                                   "PAIR_ate on the pairing leg's inputs", par(checked_lanes=ns, of=npair), mil_s, mil_traffic if queued else None, "miller", mil_one)
             result["fexp"] = leg("final exponentiations/s per MI355X (batch 2^%d per GPU)" % args.log2_pairings, "final exponentiations/s", npair,
                                  split["fex_el"], split["fexk"], MAC32_FEXP, 2 * 576, "fexp3_queue_kernel" if queued else "gt3_op_kernel",
                                  "PAIR_fexp on those Miller values",
-                                 par(checked_lanes=ns, of=npair, check="+ every lane equals the pairing leg's output"), fx_s, None, "fexp", fx_one)
+                                 par(checked_lanes=ns, of=npair, check="+ every lane equals the pairing leg's output"), fx_s, fex_traffic if queued else None, "fexp", fx_one)
 
         # ---------------------------------------------------------------- BBS+ (decoded inputs, then the wire formats end to end)
         if bbs is not None:
@@ -950,10 +953,10 @@ def main():
             result["extra_configs"] = extras
         result["notes"] = {
             "roofline": "int-valu binds: SURVEY 8(d) MAC32 / avg launch time (HIP events, the library's stream) vs the v_mad_i64_i32 issue rate measured "
-                        "in-kernel (62.06 lanes/clk/CU x 256 CUs x 2.4 GHz; theoretical 64); hbm_GBs = algorithmic bytes / same time (peak 8000); "
+                        "in-kernel (62.06 lanes/clk/CU x 256 CUs x 2.4 GHz); hbm_GBs = algorithmic bytes / same time (peak 8000); "
                         "traffic = FETCH_SIZE x2 + WRITE_SIZE passes (profiles/traffic.json)",
             "issue": "issue_ms = SQ_INSTS_VALU per launch (profiles/issue.json) x 4.06 cycles / 1024 SIMDs / the clock held inside the kernel in THIS "
-                     "run (one sampling lane per XCD, mean; xcd_clock_min_max = their spread); ref_mac32_per_inst = reference MAC32 per issued lane-instruction",
+                     "run (one sampler per XCD, mean; xcd_clock_min_max); ref_mac32_per_inst = reference MAC32 per issued lane-instruction",
             "bbs_plus": "MAC32 = the pipeline's own op sequence (wire leg: + decode of A); reference_sequence_gmac32_per_s: the reference's sequence over this time",
             "cpu_baseline": "%s, %d worker processes (not threads: oracle/pool.py), same inputs; under 2 s: median of 3; eff_cores = value / one_thread (own sample)"
                             % ("oracle/_ref = the reference's sources compiled here" if pinned else "C port (oracle/_ref absent)", cores),
