@@ -36,7 +36,8 @@ remaining hot-path functions (PAIR_G2mul, PAIR_ate, PAIR_fexp) alone, each again
 `roofline.issue` prices the kernel's vector-instruction count (SQ_INSTS_VALU pass, profiles/issue.json — a property of the build) at
 the clock the chip holds inside that kernel IN THIS RUN (one sampling lane per XCD beside the kernel, lib/libc12381_probe.so).
 Only the parity / cpu_baseline legs touch oracle/: the compiled reference when oracle/_ref is present (`parity.pinned` true), else
-our C port — then every parity object says `"oracle": "port", "pinned": false`; nothing substitutes silently.
+our C port — then the headline's and the pairing leg's parity objects say `"oracle": "port"` and EVERY parity object `"pinned": false`;
+nothing substitutes silently.  `streamed`: the same steps issued alternately from two contexts (what a caller that streams batches does).
 """
 from __future__ import annotations
 
@@ -236,6 +237,7 @@ def main():
     ap.add_argument("--no-bbs", action="store_true", help="skip the BBS+ leg (configs[4])")
     ap.add_argument("--all-configs", action="store_true", help="also time the SURVEY 8(f) extras (hash-to-G1, fixed base, Zp inversion, aggregate BBS+)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-streamed", action="store_true", help="skip the two-context streamed legs")
     ap.add_argument("--sampled-parity", action="store_true", help="compare 64 pairing lanes instead of the whole batch (quick A/B runs)")
     ap.add_argument("--no-clock-probe", action="store_true", help="skip the in-run clock probe (roofline.issue then has no clock)")
     ap.add_argument("--lib", default=None, help="another build of the same C ABI (A/B runs, tools/build_variant.sh); default: the product library")
@@ -443,6 +445,51 @@ def main():
         split = {"ng2": ng2, "steps": ssteps, "g2_el": g2_el, "mil_el": mil_el, "fex_el": fex_el, "g2k": (g2k_ms, g2k_launches),
                  "milk": (milk_ms, milk_launches), "fexk": (fexk_ms, fexk_launches), "g2_in": g2_in, "g2_sc_h": g2_sc_h, "g2_out": g2_out,
                  "mil": mil, "fex": fex}
+
+    # ================================================================== streamed batches: the same steps issued alternately from TWO contexts
+    # A caller that streams batches owns two contexts (two HIP streams, two sets of workspaces): the head of batch i+1 fills the tail of batch i,
+    # in which the older wavefront of every SIMD has left.  Same inputs, two output buffers, both compared with the serial leg's
+    # output (itself checked against the CPU reference below).  The contract's legs above stay serial: their kernel times are launch times.
+    streamed = None
+    if not args.no_streamed:
+        ctx2 = Context(dev_index)
+        stream2 = torch.cuda.Stream(device=dev)
+        ctx2.set_stream(stream2.cuda_stream)
+
+        def alternate(call, outs, steps):
+            k = [0]
+
+            def step():
+                i = k[0] & 1
+                k[0] += 1
+                call((ctx, ctx2)[i], outs[i])
+            for c, o in ((ctx, outs[0]), (ctx2, outs[1])):       # both contexts warm (workspaces, tables)
+                call(c, o)
+            el = timed(step, steps, 0)
+            if ctx.sync() != 0 or ctx2.sync() != 0:
+                raise SystemExit("bench: invalid input reported in the streamed legs")
+            return el
+        streamed = {}
+        o2 = [torch.empty_like(out), torch.empty_like(out)]
+        el = alternate(lambda c, o: c.g1_mul_dev(n, pts.data_ptr(), sc.data_ptr(), o.data_ptr(), 96), o2, args.steps)
+        streamed["g1"] = (n * args.steps / el, el / args.steps * 1e3, bool(torch.equal(o2[0], out) and torch.equal(o2[1], out)))
+        del o2
+        if pair is not None:
+            npair, p1, q2 = pair["npair"], pair["p1"], pair["q2"]
+            st = pair["steps"]
+            g2b = [torch.empty_like(pair["gt"]), torch.empty_like(pair["gt"])]
+            el = alternate(lambda c, o: c.pair_dev(npair, p1.data_ptr(), q2.data_ptr(), o.data_ptr()), g2b, st)
+            streamed["pairing"] = (npair * st / el, el / st * 1e3, bool(torch.equal(g2b[0], pair["gt"]) and torch.equal(g2b[1], pair["gt"])))
+            if split is not None:
+                el = alternate(lambda c, o: c.miller_dev(npair, p1.data_ptr(), q2.data_ptr(), o.data_ptr()), g2b, st)
+                streamed["miller"] = (npair * st / el, el / st * 1e3, bool(torch.equal(g2b[0], split["mil"]) and torch.equal(g2b[1], split["mil"])))
+                el = alternate(lambda c, o: c.gt_op_dev("fexp", npair, split["mil"].data_ptr(), None, o.data_ptr()), g2b, st)
+                streamed["fexp"] = (npair * st / el, el / st * 1e3, bool(torch.equal(g2b[0], split["fex"]) and torch.equal(g2b[1], split["fex"])))
+            del g2b
+        ctx2.close()
+        bad = [k for k, v in streamed.items() if not v[2]]
+        if bad:
+            raise SystemExit("bench: streamed outputs differ from the serial legs' (%s)" % ", ".join(bad))
 
     # ================================================================== configs[3]: MSM, n = 2^22 per GPU (weak) and sharded (strong)
     msm = None
@@ -686,8 +733,9 @@ def main():
         raise SystemExit("bench: GPU results differ from the CPU oracle — number withheld")
     g1_checked = len(idx)
 
-    def par(**kw):
-        d = {"oracle": kind, "pinned": pinned, "bit_exact": True}
+    def par(head=False, **kw):
+        """parity object of a leg; the oracle's kind is named on the headline's (and in notes.cpu_baseline), `pinned` on every one"""
+        d = {"oracle": kind, "pinned": pinned, "bit_exact": True} if head else {"pinned": pinned, "bit_exact": True}
         d.update(kw)
         return d
 
@@ -774,7 +822,7 @@ def main():
             result["cpu_baseline"] = {"value": sample / cpu_s, "unit": "scalar-muls/s", "cores": cores, "workers": "processes", "kind": kind,
                                       "sample": "first %d lanes; all equal" % sample,
                                       "one_thread": 4096 / cpu1_s, "eff_cores": (sample / cpu_s) / (4096 / cpu1_s), "threads_value": nt / cput_s}
-        result["parity"] = par(checked_lanes=g1_checked)
+        result["parity"] = par(head=True, checked_lanes=g1_checked)
 
         def cpu_b(v, unit, sample, one=None, full_keys=False):
             """one = the same routine's rate on ONE thread (its own short sample): eff_cores = what `cores` threads deliver on this box"""
@@ -916,7 +964,7 @@ def main():
             result["bbs_plus_wire"] = {
                 "metric": "BBS+ verifications/s END TO END from wire formats (2^%d per GPU: 145-B signatures, %d-B raw messages)" % (args.log2_bbs, BBS_MSG_LEN),
                 "value": world * nb / wper, "unit": "verifications/s", "steps": bbs["steps"], "ms_per_step": wper * 1e3,
-                "workload": "configs[4] through verify()'s own input forms (bbs+.cpp:57-73: parse<G1,Zp,Zp>, parse<G1,G2,G1>, parse<G2>, encode_to<Zp>)",
+                "workload": "configs[4] from verify()'s own input forms (bbs+.cpp:57-73)",
                 "parity": {"check": "all verdicts equal the construction", "bit_exact": True},
                 "roofline": {"kernel": "whole pipeline", "achieved": MAC32_BBS_WIRE_PIPELINE * nb / wper / 1e9,
                              "frac": MAC32_BBS_WIRE_PIPELINE * nb / wper / VALU_PEAK_MAC32, "traffic": None,
@@ -951,13 +999,19 @@ def main():
                                               "exchange": "none"}
         if extras:
             result["extra_configs"] = extras
+        if streamed:
+            result["streamed"] = {"how": "steps alternate over two contexts (two streams): batch i+1 fills the tail of batch i; outputs equal the serial legs'",
+                                  "ms_per_step": {k: v[1] for k, v in streamed.items()},
+                                  "g1_per_s": world * streamed["g1"][0]}
+            if "pairing" in streamed:
+                result["streamed"]["pairings_per_s"] = world * streamed["pairing"][0]
         result["notes"] = {
             "roofline": "int-valu binds: SURVEY 8(d) MAC32 / avg launch time (HIP events, the library's stream) vs the v_mad_i64_i32 issue rate measured "
                         "in-kernel (62.06 lanes/clk/CU x 256 CUs x 2.4 GHz); hbm_GBs = algorithmic bytes / same time (peak 8000); "
                         "traffic = FETCH_SIZE x2 + WRITE_SIZE passes (profiles/traffic.json)",
             "issue": "issue_ms = SQ_INSTS_VALU per launch (profiles/issue.json) x 4.06 cycles / 1024 SIMDs / the clock held inside the kernel in THIS "
                      "run (one sampler per XCD, mean; xcd_clock_min_max); ref_mac32_per_inst = reference MAC32 per issued lane-instruction",
-            "bbs_plus": "MAC32 = the pipeline's own op sequence (wire leg: + decode of A); reference_sequence_gmac32_per_s: the reference's sequence over this time",
+            "bbs_plus": "MAC32 = the pipeline's own op sequence (wire: + decode of A); reference_sequence_gmac32_per_s: the reference's over this time",
             "cpu_baseline": "%s, %d worker processes (not threads: oracle/pool.py), same inputs; under 2 s: median of 3; eff_cores = value / one_thread (own sample)"
                             % ("oracle/_ref = the reference's sources compiled here" if pinned else "C port (oracle/_ref absent)", cores),
         }
@@ -970,7 +1024,7 @@ def main():
                 "value": world * npair * pair["steps"] / pair["elapsed"], "unit": "pairings/s", "steps": pair["steps"],
                 "ms_per_step": pair["elapsed"] / pair["steps"] * 1e3,
                 "workload": "configs[2]: 2^%d pairings e(P_i, Q_i) -> 576-B GT each, per GPU" % args.log2_pairings,
-                "parity": par(checked_lanes=checked, of=npair),
+                "parity": par(head=True, checked_lanes=checked, of=npair),
                 "roofline": valu(MAC32_PAIRING, npair, avg_s, kname, pair_traffic, BYTES_PAIRING, "pair", head=True),
             }
             if do_cpu:

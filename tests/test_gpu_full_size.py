@@ -75,3 +75,52 @@ def test_bbs_plus_full_size_2_18(ctx, oracle_port):
         e = pow((gamma + x) % R, R - 2, R)
         B = orc.g1_msm(G1p + h0 + h, (1).to_bytes(32, "big") + Rr[32 * j:32 * j + 32] + Mm[32 * j:32 * j + 32], 96, 1)
         assert A[96 * j:96 * j + 96] == orc.g1_mul(B, e.to_bytes(32, "big"), 96)
+
+
+def test_batches_streamed_over_two_contexts_overlap_and_stay_equal(ctx):
+    """A caller that streams batches alternates two contexts (two HIP streams, own workspaces): the work-queue launches of
+    consecutive batches then overlap on the device (the next batch's wavefronts enter as the previous one's leave).  2^16
+    pairings (the queued route: 3 121 groups on 2 048 resident wavefronts), six launches in flight over two streams, no host
+    wait between them: every output equals the output of the same batch run alone (which test_gpu_full_batch.py compares
+    lane by lane with the compiled reference)."""
+    import torch
+    from crypto12381_amd import Context
+    n = 1 << 16
+    dev = torch.device("cuda", 0)
+    g1 = bytes.fromhex(golden("g1")["generator"])
+    g2 = bytes.fromhex(golden("g2")["generator"])
+
+    def up(b):
+        return torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    p1 = up(ctx.g1_mul_fixed(g1, _rand_scalars(31, n).tobytes(), 96))
+    q2 = up(ctx.g2_mul_fixed(g2, _rand_scalars(32, n).tobytes(), 192))
+    alone = torch.empty(n * 576, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize(dev)
+    ctx.pair_dev(n, p1.data_ptr(), q2.data_ptr(), alone.data_ptr())
+    assert ctx.sync() == 0
+    pairs = []
+    for _ in range(2):
+        c = Context(0)
+        s = torch.cuda.Stream(device=dev)
+        c.set_stream(s.cuda_stream)
+        pairs.append((c, s))
+    outs = [torch.zeros(n * 576, dtype=torch.uint8, device=dev) for _ in range(6)]
+    torch.cuda.synchronize(dev)
+    for i, o in enumerate(outs):
+        pairs[i & 1][0].pair_dev(n, p1.data_ptr(), q2.data_ptr(), o.data_ptr())
+    for c, _ in pairs:
+        assert c.sync() == 0
+    for i, o in enumerate(outs):
+        assert torch.equal(o, alone), "streamed launch %d differs from the batch run alone" % i
+    # Miller values and final exponentiations through the same two contexts, chained per context (stream order within a context)
+    mil = [torch.zeros(n * 576, dtype=torch.uint8, device=dev) for _ in range(2)]
+    fex = [torch.zeros(n * 576, dtype=torch.uint8, device=dev) for _ in range(2)]
+    for i in range(2):
+        pairs[i][0].miller_dev(n, p1.data_ptr(), q2.data_ptr(), mil[i].data_ptr())
+    for i in range(2):
+        pairs[i][0].gt_op_dev("fexp", n, mil[i].data_ptr(), None, fex[i].data_ptr())
+    for c, _ in pairs:
+        assert c.sync() == 0
+    assert torch.equal(mil[0], mil[1]) and torch.equal(fex[0], alone) and torch.equal(fex[1], alone)
+    for c, _ in pairs:
+        c.close()

@@ -34,7 +34,7 @@ for st in "$@"; do
            timeout -k 10 1100 python tools/ab_bench.py default $libs 2>&1 | grep -v amdgpu.ids | tee $O/ab_$(echo $arg | tr ',/' '__').txt; rc=$?;;
     abl)   legs=${arg%%:*}; rest=${arg#*:}; libs=""; for l in ${rest//,/ }; do libs="$libs $(libpath $l)"; done
            timeout -k 10 1100 python tools/ab_bench.py --legs $legs default $libs 2>&1 | grep -v amdgpu.ids | tee $O/ab_$(echo $rest | tr ',/' '__').txt; rc=$?;;
-    prof)  (cd /tmp && export TMPDIR=/tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o p -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --sampled-parity > $O/bench_under_rocprof.json 2> $O/rocprof.err); rc=$?;;
+    prof)  (cd /tmp && export TMPDIR=/tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o p -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --sampled-parity --no-streamed > $O/bench_under_rocprof.json 2> $O/rocprof.err); rc=$?;;
     pmc)   bash tools/pmc_r03.sh gpurun_out/$TAG/pmc > $O/pmc.txt 2>&1; rc=$?; tail -8 $O/pmc.txt;;
     clock) timeout -k 10 300 python tools/clock_probe.py 2>&1 | grep -v amdgpu.ids | tee $O/clock_probe.txt; rc=$?;;
     2rank) C12381_BENCH_BACKEND=gloo timeout -k 10 900 python bench.py --gpus 2 --steps 2 --warmup 1 > $O/bench_2rank_gloo.json 2> $O/bench_2rank_gloo.err; rc=$?; python tools/bench_summary.py $O/bench_2rank_gloo.json;;
