@@ -956,13 +956,13 @@ def main():
                 # the pipeline's OWN operation sequence (tools/count_ops.py -> profiles/r03_op_counts.json) over the wall time of the whole pipeline
                 "roofline": valu(MAC32_BBS_PIPELINE, nb, per, "pair3_prod_fixed_queue_kernel", bbs_traffic, BYTES_BBS_VERIFY,
                                  issue_secs=bbs["pair_ms"] / max(bbs["pair_launches"], 1) * 1e-3,
-                                 pair_kernel_avg_ms=bbs["pair_ms"] / max(bbs["pair_launches"], 1), time_base="whole pipeline; issue: the pairing kernel"),
+                                 pair_kernel_avg_ms=bbs["pair_ms"] / max(bbs["pair_launches"], 1), time_base="pipeline; issue: pairing kernel"),
                 "reference_sequence_gmac32_per_s": MAC32_BBS_VERIFY * nb / per / 1e9,
             }
             wr = bbs["wire"]
             wper = wr["elapsed"] / bbs["steps"]
             result["bbs_plus_wire"] = {
-                "metric": "BBS+ verifications/s END TO END from wire formats (2^%d per GPU: 145-B signatures, %d-B raw messages)" % (args.log2_bbs, BBS_MSG_LEN),
+                "metric": "BBS+ verifications/s from wire formats (2^%d per GPU: 145-B signatures, %d-B messages)" % (args.log2_bbs, BBS_MSG_LEN),
                 "value": world * nb / wper, "unit": "verifications/s", "steps": bbs["steps"], "ms_per_step": wper * 1e3,
                 "workload": "configs[4] from verify()'s own input forms (bbs+.cpp:57-73)",
                 "parity": {"check": "all verdicts equal the construction", "bit_exact": True},
@@ -1000,13 +1000,13 @@ def main():
         if extras:
             result["extra_configs"] = extras
         if streamed:
-            result["streamed"] = {"how": "steps alternate over two contexts (two streams): batch i+1 fills the tail of batch i; outputs equal the serial legs'",
+            result["streamed"] = {"how": "steps alternate over two contexts / streams (INTEGRATION.md); outputs equal the serial legs'",
                                   "ms_per_step": {k: v[1] for k, v in streamed.items()},
                                   "g1_per_s": world * streamed["g1"][0]}
             if "pairing" in streamed:
                 result["streamed"]["pairings_per_s"] = world * streamed["pairing"][0]
         result["notes"] = {
-            "roofline": "int-valu binds: SURVEY 8(d) MAC32 / avg launch time (HIP events, the library's stream) vs the v_mad_i64_i32 issue rate measured "
+            "roofline": "int-valu binds: SURVEY 8(d) MAC32 / avg launch time (HIP events) vs the v_mad_i64_i32 issue rate measured "
                         "in-kernel (62.06 lanes/clk/CU x 256 CUs x 2.4 GHz); hbm_GBs = algorithmic bytes / same time (peak 8000); "
                         "traffic = FETCH_SIZE x2 + WRITE_SIZE passes (profiles/traffic.json)",
             "issue": "issue_ms = SQ_INSTS_VALU per launch (profiles/issue.json) x 4.06 cycles / 1024 SIMDs / the clock held inside the kernel in THIS "
