@@ -485,11 +485,11 @@ def main():
                 streamed["miller"] = (npair * st / el, el / st * 1e3, bool(torch.equal(g2b[0], split["mil"]) and torch.equal(g2b[1], split["mil"])))
                 el = alternate(lambda c, o: c.gt_op_dev("fexp", npair, split["mil"].data_ptr(), None, o.data_ptr()), g2b, st)
                 streamed["fexp"] = (npair * st / el, el / st * 1e3, bool(torch.equal(g2b[0], split["fex"]) and torch.equal(g2b[1], split["fex"])))
+                g2o = [torch.empty_like(split["g2_out"]), torch.empty_like(split["g2_out"])]
+                el = alternate(lambda c, o: c.g2_mul_dev(split["ng2"], split["g2_in"].data_ptr(), g2_sc.data_ptr(), o.data_ptr(), 192), g2o, st)
+                streamed["g2_mul"] = (split["ng2"] * st / el, el / st * 1e3, bool(torch.equal(g2o[0], split["g2_out"]) and torch.equal(g2o[1], split["g2_out"])))
+                del g2o
             del g2b
-        ctx2.close()
-        bad = [k for k, v in streamed.items() if not v[2]]
-        if bad:
-            raise SystemExit("bench: streamed outputs differ from the serial legs' (%s)" % ", ".join(bad))
 
     # ================================================================== configs[3]: MSM, n = 2^22 per GPU (weak) and sharded (strong)
     msm = None
@@ -676,6 +676,18 @@ def main():
             dist.all_reduce(cnt)                                        # bookkeeping only: number of accepted signatures in the job
             bbs["sharded"] = {"elapsed": sel, "steps": bsteps, "accepted": int(cnt.item()), "expected_accepted": int(nb - len(gbad))}
             del sA, sx, sr, sm
+
+    if streamed is not None:
+        if bbs is not None:
+            ok2 = [torch.empty_like(okb), torch.empty_like(okb)]
+            el = alternate(lambda c, o: c.bbs_plus_verify_dev(nb, 1, dpub[0].data_ptr(), dpub[1].data_ptr(), dpub[2].data_ptr(), dpub[3].data_ptr(),
+                                                              dpub[4].data_ptr(), dA.data_ptr(), dx.data_ptr(), dr.data_ptr(), dm.data_ptr(), o.data_ptr()),
+                           ok2, bbs["steps"])
+            streamed["bbs_plus"] = (nb * bbs["steps"] / el, el / bbs["steps"] * 1e3, bool(torch.equal(ok2[0], okb) and torch.equal(ok2[1], okb)))
+        ctx2.close()
+        bad = [k for k, v in streamed.items() if not v[2]]
+        if bad:
+            raise SystemExit("bench: streamed outputs differ from the serial legs' (%s)" % ", ".join(bad))
 
     # ================================================================== optional extras
     extras = {}
