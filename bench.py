@@ -826,7 +826,7 @@ def main():
             sp, ss = pts_h[:sample].tobytes(), sc_h[:sample].tobytes()
             cpu_out, cpu_s = cpu_time(lambda: cpuN.g1_mul(sp, ss, 96))
             _, cpu1_s = cpu_time(lambda: orc.g1_mul(sp[:96 * 4096], ss[:32 * 4096], 96, 1))
-            nt = 1 << 15                                           # BASELINE.md 3(b) as written: std::thread shards in ONE process
+            nt = min(sample, 1 << 15)                              # BASELINE.md 3(b) as written: std::thread shards in ONE process
             _, cput_s = cpu_time(lambda: orc.g1_mul(sp[:96 * nt], ss[:32 * nt], 96, cores))
             if cpu_out != out_h[:sample].tobytes():
                 raise SystemExit("bench: CPU baseline output differs from the GPU output")
@@ -865,7 +865,7 @@ def main():
                 "roofline_whole_step": {"frac": MAC32_MSM_TERM * nm / per / VALU_PEAK_MAC32, "achieved": MAC32_MSM_TERM * nm / per / 1e9},
             }
             if do_cpu:
-                sm = 1 << 15
+                sm = min(nm, 1 << 15)
                 cpu_m, cm_s = cpu_time(lambda: cpuN.g1_msm(pts_h[:sm].tobytes(), msm["scalars"][:sm].tobytes(), 96))
                 _, cm1_s = cpu_time(lambda: orc.g1_msm(pts_h[:4096].tobytes(), msm["scalars"][:4096].tobytes(), 96, 1))
                 if cpu_m != ctx.g1_msm(pts_h[:sm].tobytes(), msm["scalars"][:sm].tobytes(), 96):

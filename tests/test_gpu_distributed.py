@@ -217,3 +217,34 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     env1 = dict(env); env1.update({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + small, cwd=ROOT, env=env1, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "refusing" in (r.stdout + r.stderr)
+
+
+def test_bench_single_gpu_line_with_cpu_baseline_and_streamed_legs():
+    """`python3 bench.py` at N = 1 as the driver runs it (small sizes here): the CPU baseline comes from the process pool that is forked
+    before the GPU is touched (oracle/pool.py), every leg carries its own baseline with a one-thread rate, the streamed legs are present and
+    equal to the serial ones (bench.py withholds the line otherwise), `pairing` closes the line and the line fits the driver's log tail."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    small = ["--steps", "2", "--warmup", "1", "--log2-batch", "14", "--log2-pairings", "12", "--log2-g2", "12", "--log2-msm", "14", "--log2-bbs", "12"]
+    r = subprocess.run([sys.executable, "bench.py"] + small, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["workers"] == "processes" and cb["kind"] in ("reference", "port") and cb["cores"] >= 1
+    assert cb["value"] > 0 and cb["one_thread"] > 0 and cb["threads_value"] > 0
+    assert d["parity"]["bit_exact"] is True and d["parity"]["oracle"] == cb["kind"]
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["bound"] == "int-valu"
+    for leg in ("msm", "g2_mul", "miller", "fexp", "bbs_plus", "bbs_plus_wire", "pairing"):
+        assert d[leg]["value"] > 0 and d[leg]["cpu_baseline"]["value"] > 0 and d[leg]["cpu_baseline"]["one_thread"] > 0, leg
+        assert d[leg]["parity"]["bit_exact"] is True and d[leg]["parity"]["pinned"] == d["parity"]["pinned"], leg
+    assert set(d["streamed"]["ms_per_step"]) == {"g1", "pairing", "miller", "fexp", "g2_mul", "bbs_plus"}
+    assert d["streamed"]["g1_per_s"] > 0 and d["streamed"]["pairings_per_s"] > 0
+    assert list(d)[-1] == "pairing"
+    assert len(lines[0]) < 8000, "the JSON line outgrew the driver's log tail: %d characters" % len(lines[0])
