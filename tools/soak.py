@@ -97,3 +97,49 @@ for t in ths:
     t.join()
 assert res["a"] == res["b"] and res["a"][:576] == want
 print("two concurrent contexts ok (%.1f s)" % (time.time() - t0))
+
+# streamed launches: two contexts on two streams, no host wait between the launches, DIFFERENT queue kernels and odd sizes overlapping on
+# the device (the next launch's wavefronts enter as the previous one's leave): every output equals the serial result of the same inputs
+cs = []
+for ctx in (c, c2):
+    st = torch.cuda.Stream(device=dev)
+    ctx.set_stream(st.cuda_stream)
+    cs.append((ctx, st))
+sizes = (43009, 65536, 100003)
+data = {}
+for n in sizes:
+    rep = (n + base - 1) // base
+    dp = torch.frombuffer(bytearray((p * rep)[:96 * n]), dtype=torch.uint8).to(dev)
+    dq = torch.frombuffer(bytearray((q * rep)[:192 * n]), dtype=torch.uint8).to(dev)
+    ref = torch.empty(576 * n, dtype=torch.uint8, device=dev)
+    mref = torch.empty(576 * n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize(dev)
+    c.pair_dev(n, dp.data_ptr(), dq.data_ptr(), ref.data_ptr())
+    c.miller_dev(n, dp.data_ptr(), dq.data_ptr(), mref.data_ptr())
+    assert c.sync() == 0
+    data[n] = (dp, dq, ref, mref)
+t0 = time.time()
+streamed = 0
+for rnd in range(40):
+    outs = []
+    bufs = [torch.zeros(576 * sizes[(i + rnd) % 3], dtype=torch.uint8, device=dev) for i in range(12)]
+    torch.cuda.synchronize(dev)                    # the zero fills run on torch's stream: complete before the library's streams write
+    for i in range(12):
+        n = sizes[(i + rnd) % 3]
+        dp, dq, ref, mref = data[n]
+        ctx = cs[i & 1][0]
+        o = bufs[i]
+        kind = (i // 2 + rnd) % 3
+        if kind == 0:
+            ctx.pair_dev(n, dp.data_ptr(), dq.data_ptr(), o.data_ptr()); want_t = ref
+        elif kind == 1:
+            ctx.miller_dev(n, dp.data_ptr(), dq.data_ptr(), o.data_ptr()); want_t = mref
+        else:
+            ctx.gt_op_dev("fexp", n, mref.data_ptr(), None, o.data_ptr()); want_t = ref
+        outs.append((o, want_t, n, kind))
+        streamed += 1
+    for ctx, _ in cs:
+        assert ctx.sync() == 0
+    for o, want_t, n, kind in outs:
+        assert torch.equal(o, want_t), ("streamed", rnd, n, kind)
+print("streamed over two contexts ok: %d overlapping queue launches of three kinds and sizes (%.1f s)" % (streamed, time.time() - t0))
