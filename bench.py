@@ -260,6 +260,8 @@ def main():
     # CPU baseline workers: one PROCESS per host core, forked here — before anything in this process touches the GPU — so that no worker
     # ever holds a HIP context.  Processes, not threads: MIRACL's constant-time moves advance a function-level static on every call
     # (oracle/pool.py), which costs the reference's G1 / G2 / final-exponentiation paths half their rate across threads of one process.
+    if torch.cuda.device_count() == 0:                        # counting devices does not initialise the GPU; nothing is forked on a box without one
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     from oracle.bindings import Oracle, have_reference
     from oracle.pool import OraclePool, OracleThreads
     kind = "reference" if have_reference() else "port"        # the compiled reference when it travelled with the snapshot, else the C port
