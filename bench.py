@@ -145,9 +145,9 @@ def sum_of_products_mod_r(a: np.ndarray, b: np.ndarray) -> int:
 
 
 def compact(o):
-    """floats to 6 significant digits, recursively (the line has to fit a log tail)"""
+    """floats to 5 significant digits, recursively (the line has to fit a log tail)"""
     if isinstance(o, float):
-        return int(o) if o.is_integer() and abs(o) < 1e15 else float("%.6g" % o)     # counts stay exact
+        return int(o) if o.is_integer() and abs(o) < 1e15 else float("%.5g" % o)     # counts stay exact
     if isinstance(o, dict):
         return {k: compact(v) for k, v in o.items()}
     if isinstance(o, (list, tuple)):
@@ -1014,7 +1014,7 @@ def main():
         if extras:
             result["extra_configs"] = extras
         if streamed:
-            result["streamed"] = {"how": "steps alternate over two contexts / streams (INTEGRATION.md); outputs equal the serial legs'",
+            result["streamed"] = {"how": "two contexts alternate (INTEGRATION.md); outputs equal the serial legs'",
                                   "ms_per_step": {k: v[1] for k, v in streamed.items()},
                                   "g1_per_s": world * streamed["g1"][0]}
             if "pairing" in streamed:
